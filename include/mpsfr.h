@@ -1,0 +1,123 @@
+/* libmpsfr -- C ABI of the MI355X-native PSF-reconstruction hot path of muse-psfr.
+ *
+ * The reference (musevlt/muse-psfr) has no FFI: its boundary for this path is two Python
+ * functions.  This header is what a ctypes binding of those functions binds to; every entry
+ * point cites the reference interface it replaces (file:line in /root/reference/muse_psfr/).
+ *
+ * Conventions: plain pointers and sizes only; all arrays C-contiguous; every function returns 0
+ * on success or a negative error code (MPSFR_E_*), with a thread-local message available from
+ * mpsfr_last_error(); nothing is allocated across the ABI; no exceptions cross it.  A context
+ * owns one GPU (one process per GPU, one context per process is the intended use), one HIP
+ * stream and all device workspaces; it is not re-entrant.
+ */
+#ifndef MPSFR_H
+#define MPSFR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpsfr_ctx mpsfr_ctx;
+
+#define MPSFR_OK            0
+#define MPSFR_E_INVALID    -1   /* bad argument (message says which) */
+#define MPSFR_E_HIP        -2   /* a HIP runtime call failed */
+#define MPSFR_E_GRID       -3   /* wavelength too short for the grid: npixc(lambda) > dim.  The
+                                   reference raises ValueError from interpn here
+                                   (psfrec.py:663-664, 672-683) */
+#define MPSFR_E_NOMEM      -4
+
+/* precision modes */
+#define MPSFR_PREC_MIXED    0   /* fp64 PSD -> structure function, fp32 per-wavelength stage,
+                                   fp64 Moffat fit */
+#define MPSFR_PREC_F64      1   /* fp64 everywhere (reference arithmetic type) */
+
+/* number of doubles per fitted stamp in fit_out */
+#define MPSFR_NFIT         16
+/* fit_out[k]: 0 peak  1 p0 (row centre, px)  2 q0 (col centre, px)  3 alpha (px)  4 n (beta)
+ *             5 fwhm (px) = 2 alpha sqrt(2^(1/n) - 1)   6 chi2   7 iterations
+ *             8 err_peak  9 err_p0  10 err_q0  11 err_alpha  12 err_n  13 err_fwhm (px)
+ *             14 status (0 converged, 1 iteration cap, 2 singular)  15 flux = peak pi alpha^2/(n-1)
+ */
+
+/* Side of the AO-corrected zone grid (psfrec.py:103, 138: Dimpup * 2). */
+#define MPSFR_DIM_AO       80
+
+/* Create a context on HIP device `device_id` for an N x N spatial-frequency grid.
+ * dim      : N, the `dim` argument of simul_psd_wfm (psfrec.py:37; compute_psf hard-codes 1280,
+ *            psfrec.py:954-955).  Supported: 128, 256, 512, 1024, 1280.
+ * dimpsf   : side of the output stamps (psfrec.py:658); only 40 is supported.
+ * pixscale : arcsec per output pixel (psfrec.py:659, :899, :868).
+ * Builds the wavelength- and row-independent telescope OTF (psfrec.py:784-790) once. */
+int mpsfr_create(mpsfr_ctx** out, int device_id, int dim, int dimpsf, double pixscale,
+                 int precision);
+void mpsfr_destroy(mpsfr_ctx* ctx);
+const char* mpsfr_last_error(void);
+
+/* Tunables: "chunk_tasks" (tasks per pipeline pass), "fast_exp" (0/1, mixed mode only),
+ * "profile" (0/1: bracket every kernel launch with HIP events on the context's stream). */
+int mpsfr_set_option(mpsfr_ctx* ctx, const char* key, double value);
+
+/* Batched replacement of  Parallel(n_jobs)(delayed(compute_psf)(*args) ...)  (psfrec.py:1082-1083)
+ * i.e. of compute_psf (psfrec.py:933-978) = simul_psd_wfm (:36-151) -> psf_muse (:644-686) ->
+ * convolve_final_psf (:874-930) -> fit_psf_cube (:861-871), for ntask (seeing, GL, L0) triples.
+ *
+ * seeing, gl, l0 : [ntask] arcsec @500 nm, ground-layer fraction, outer scale [m]
+ * three_lgs      : [ntask] 0/1, three_lgs_mode of simul_psd_wfm (psfrec.py:86-91)
+ * h              : layer altitudes [m] (psfrec.py:60); exactly two layers (psfrec.py:66 fixes two
+ *                  wind directions)
+ * wind_speed     : m/s; the reference uses np.full_like(h, 12.5) = 12 for integer h, 12.5 for
+ *                  float h (psfrec.py:61) -- the caller decides
+ * npsflin        : linear number of evaluation directions (psfrec.py:154-158), 1..5
+ * lbda_nm        : [nl] wavelengths in nm
+ * mask_rec/res   : [80*80] 0/1 cut-off masks of psfrec.py:257 (>=) and :435 (>) indexed
+ *                  [i_fx][j_fy] like the reference's arrays, or NULL for the exact rule
+ *                  |k| >= 24 / |k| > 24 on the integer frequency grid.  (In the reference these
+ *                  masks depend on last-bit libm rounding; see DESIGN.md "cut-off masks".)
+ * psf_out        : [ntask][nl][dimpsf][dimpsf] final stamps (after both convolutions), or NULL
+ * psf_sum_out    : [nl][dimpsf][dimpsf] sum over the ntask stamps (the caller divides by the
+ *                  global task count to get PSF_MEAN, psfrec.py:1104), or NULL
+ * fit_out        : [ntask][nl][MPSFR_NFIT] Moffat fit of every stamp, or NULL
+ * on_device      : 0 = the three outputs are host pointers; 1 = device pointers on this
+ *                  context's device (results complete after mpsfr_sync)
+ * All outputs are float64.  The call is asynchronous when on_device = 1. */
+int mpsfr_reconstruct(mpsfr_ctx* ctx, int ntask, const double* seeing, const double* gl,
+                      const double* l0, const uint8_t* three_lgs, const double h[2],
+                      double wind_speed, int npsflin, int nl, const double* lbda_nm,
+                      const uint8_t* mask_rec, const uint8_t* mask_res, double* psf_out,
+                      double* psf_sum_out, double* fit_out, int on_device);
+
+/* Replacement of fit_psf_cube (psfrec.py:861-871) on caller-provided stamps, e.g. the mean PSF
+ * (psfrec.py:1105).  stamps: [nstamp][dimpsf][dimpsf] float64; fit_out: [nstamp][MPSFR_NFIT]. */
+int mpsfr_fit_stamps(mpsfr_ctx* ctx, int nstamp, const double* stamps, double* fit_out,
+                     int on_device);
+
+/* Block until everything queued on the context's stream has finished. */
+int mpsfr_sync(mpsfr_ctx* ctx);
+
+/* Copy an intermediate of the most recent mpsfr_reconstruct pipeline pass (last chunk) to the
+ * host as float64 (parity tests, tests/test_stages_gpu.py).  `what`:
+ *   "ao_tables"  [2 geometries][ndir][3 (T0,T1,noise)][80][80]   (psfrec.py:531-613)
+ *   "tel"        [dim/2+1][dim]  telescope OTF, transposed half plane (psfrec.py:784-790)
+ *   "dphi0"      [chunk tasks][ndir][dim/2+1][dim] structure function / lambda-factor,
+ *                transposed half plane (psfrec.py:717-722)
+ *   "pre"        [chunk tasks][nl][dimpsf][dimpsf] stamps before the convolutions (psfrec.py:685)
+ * Returns the number of doubles written (<= capacity) or a negative error. */
+long mpsfr_debug_fetch(mpsfr_ctx* ctx, const char* what, double* out, size_t capacity);
+
+/* Per-kernel timing with HIP events recorded on the context's stream (option "profile" = 1). */
+int mpsfr_profile_count(void);
+const char* mpsfr_profile_name(int kernel_id);
+int mpsfr_profile_get(mpsfr_ctx* ctx, int kernel_id, double* total_ms, long* launches);
+int mpsfr_profile_reset(mpsfr_ctx* ctx);
+
+/* Library/ABI version (major*100 + minor). */
+int mpsfr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPSFR_H */

@@ -1,0 +1,56 @@
+"""In-tree build of libmpsfr.so (HIP kernels + C ABI) for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
+git-ignored but travels with the tree to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libmpsfr.so')
+SOURCES = ['kernels.hip', 'mpsfr_api.cpp']
+HEADERS = ['kernels.h', 'fft_lds.h', 'coeff_l0_table.h', os.path.join('..', '..', 'include', 'mpsfr.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-result']
+
+
+def _hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found: cannot build libmpsfr.so')
+    return exe
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=True):
+    """Compile csrc/*.hip, csrc/*.cpp into muse_psfr_amd/libmpsfr.so.  Returns the path."""
+    if not force and not is_stale():
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+    bdir = os.path.join(HERE, 'build')
+    os.makedirs(bdir, exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(bdir, os.path.splitext(src)[0] + '.o')
+        cmd = [hipcc] + FLAGS + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_library(force=True))

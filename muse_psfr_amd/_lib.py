@@ -1,0 +1,188 @@
+"""ctypes binding of libmpsfr.so (include/mpsfr.h).  No CPU fallback: if the HIP library is
+missing or cannot be loaded this module raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libmpsfr.so')
+
+NFIT = 16
+DIM_AO = 80
+PREC_MIXED, PREC_F64 = 0, 1
+E_GRID = -3
+
+_lib = None
+
+
+class MpsfrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('libmpsfr error %d: %s' % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load libmpsfr.so (built by muse_psfr_amd._build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('%s not found: build it with `python -m muse_psfr_amd._build` '
+                          '(hipcc, gfx950); there is no CPU fallback' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    p = C.c_void_p
+    dp = C.POINTER(C.c_double)
+    u8p = C.POINTER(C.c_uint8)
+    lib.mpsfr_create.argtypes = [C.POINTER(p), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+    lib.mpsfr_create.restype = C.c_int
+    lib.mpsfr_destroy.argtypes = [p]
+    lib.mpsfr_destroy.restype = None
+    lib.mpsfr_last_error.argtypes = []
+    lib.mpsfr_last_error.restype = C.c_char_p
+    lib.mpsfr_set_option.argtypes = [p, C.c_char_p, C.c_double]
+    lib.mpsfr_set_option.restype = C.c_int
+    lib.mpsfr_reconstruct.argtypes = [p, C.c_int, dp, dp, dp, u8p, dp, C.c_double, C.c_int,
+                                      C.c_int, dp, u8p, u8p, p, p, p, C.c_int]
+    lib.mpsfr_reconstruct.restype = C.c_int
+    lib.mpsfr_fit_stamps.argtypes = [p, C.c_int, p, p, C.c_int]
+    lib.mpsfr_fit_stamps.restype = C.c_int
+    lib.mpsfr_sync.argtypes = [p]
+    lib.mpsfr_sync.restype = C.c_int
+    lib.mpsfr_debug_fetch.argtypes = [p, C.c_char_p, dp, C.c_size_t]
+    lib.mpsfr_debug_fetch.restype = C.c_long
+    lib.mpsfr_profile_count.argtypes = []
+    lib.mpsfr_profile_count.restype = C.c_int
+    lib.mpsfr_profile_name.argtypes = [C.c_int]
+    lib.mpsfr_profile_name.restype = C.c_char_p
+    lib.mpsfr_profile_get.argtypes = [p, C.c_int, dp, C.POINTER(C.c_long)]
+    lib.mpsfr_profile_get.restype = C.c_int
+    lib.mpsfr_profile_reset.argtypes = [p]
+    lib.mpsfr_profile_reset.restype = C.c_int
+    lib.mpsfr_version.argtypes = []
+    lib.mpsfr_version.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+EXPORTS = ['mpsfr_create', 'mpsfr_destroy', 'mpsfr_last_error', 'mpsfr_set_option',
+           'mpsfr_reconstruct', 'mpsfr_fit_stamps', 'mpsfr_sync', 'mpsfr_debug_fetch',
+           'mpsfr_profile_count', 'mpsfr_profile_name', 'mpsfr_profile_get',
+           'mpsfr_profile_reset', 'mpsfr_version']
+
+
+def _check(rc):
+    if rc < 0:
+        raise MpsfrError(rc, load().mpsfr_last_error().decode())
+    return rc
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _u8ptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+class Context:
+    """One GPU context: grid size, precision, HIP stream, workspaces."""
+
+    def __init__(self, dim=1280, pixscale=0.2, dimpsf=40, precision='mixed', device=0):
+        self.lib = load()
+        self.dim, self.pixscale, self.dimpsf = int(dim), float(pixscale), int(dimpsf)
+        self.precision = precision
+        prec = {'mixed': PREC_MIXED, 'f64': PREC_F64}[precision]
+        h = C.c_void_p()
+        _check(self.lib.mpsfr_create(C.byref(h), int(device), self.dim, self.dimpsf,
+                                     self.pixscale, prec))
+        self._h = h
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.mpsfr_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_option(self, key, value):
+        _check(self.lib.mpsfr_set_option(self._h, key.encode(), float(value)))
+
+    def sync(self):
+        _check(self.lib.mpsfr_sync(self._h))
+
+    def reconstruct(self, lbda, seeing, gl, l0, three_lgs=None, h=(100, 10000), wind_speed=None,
+                    npsflin=1, masks=None, want_psf=True, want_sum=True, want_fit=True):
+        """Host-buffer call.  Returns dict(psf, psf_sum, fit) of float64 arrays (or None)."""
+        seeing = np.ascontiguousarray(np.atleast_1d(seeing), dtype=np.float64)
+        gl = np.ascontiguousarray(np.atleast_1d(gl), dtype=np.float64)
+        l0 = np.ascontiguousarray(np.atleast_1d(l0), dtype=np.float64)
+        lbda = np.ascontiguousarray(np.atleast_1d(lbda), dtype=np.float64)
+        nt, nl = seeing.size, lbda.size
+        three = np.zeros(nt, np.uint8) if three_lgs is None else \
+            np.ascontiguousarray(np.atleast_1d(three_lgs)).astype(np.uint8)
+        if wind_speed is None:
+            wind_speed = float(np.full_like(np.array(h), 12.5)[0])      # psfrec.py:61
+        hh = np.ascontiguousarray(h, dtype=np.float64)
+        if hh.size != 2:
+            raise ValueError('exactly two layers are supported (psfrec.py:66)')
+        mrec = mres = None
+        if masks is not None:
+            mrec = np.ascontiguousarray(masks[0]).astype(np.uint8).reshape(-1)
+            mres = np.ascontiguousarray(masks[1]).astype(np.uint8).reshape(-1)
+            assert mrec.size == DIM_AO * DIM_AO and mres.size == DIM_AO * DIM_AO
+        n = self.dimpsf
+        psf = np.empty((nt, nl, n, n)) if want_psf else None
+        psum = np.empty((nl, n, n)) if want_sum else None
+        fit = np.empty((nt, nl, NFIT)) if want_fit else None
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        _check(self.lib.mpsfr_reconstruct(
+            self._h, nt, _dptr(seeing), _dptr(gl), _dptr(l0), _u8ptr(three), _dptr(hh),
+            float(wind_speed), int(npsflin), nl, _dptr(lbda), _u8ptr(mrec), _u8ptr(mres),
+            vp(psf), vp(psum), vp(fit), 0))
+        return dict(psf=psf, psf_sum=psum, fit=fit)
+
+    def reconstruct_device(self, lbda, seeing, gl, l0, three_lgs, h, wind_speed, npsflin, masks,
+                           psf_ptr, sum_ptr, fit_ptr):
+        """Device-buffer call (asynchronous): the three outputs are raw device pointers (int or
+        None) on this context's GPU, e.g. torch tensors' data_ptr()."""
+        seeing = np.ascontiguousarray(seeing, dtype=np.float64)
+        gl = np.ascontiguousarray(gl, dtype=np.float64)
+        l0 = np.ascontiguousarray(l0, dtype=np.float64)
+        lbda = np.ascontiguousarray(lbda, dtype=np.float64)
+        three = np.ascontiguousarray(three_lgs).astype(np.uint8)
+        hh = np.ascontiguousarray(h, dtype=np.float64)
+        mrec = mres = None
+        if masks is not None:
+            mrec = np.ascontiguousarray(masks[0]).astype(np.uint8).reshape(-1)
+            mres = np.ascontiguousarray(masks[1]).astype(np.uint8).reshape(-1)
+        _check(self.lib.mpsfr_reconstruct(
+            self._h, seeing.size, _dptr(seeing), _dptr(gl), _dptr(l0), _u8ptr(three), _dptr(hh),
+            float(wind_speed), int(npsflin), lbda.size, _dptr(lbda), _u8ptr(mrec), _u8ptr(mres),
+            C.c_void_p(psf_ptr), C.c_void_p(sum_ptr), C.c_void_p(fit_ptr), 1))
+
+    def fit_stamps(self, stamps):
+        st = np.ascontiguousarray(stamps, dtype=np.float64).reshape(-1, self.dimpsf, self.dimpsf)
+        out = np.empty((st.shape[0], NFIT))
+        _check(self.lib.mpsfr_fit_stamps(self._h, st.shape[0], st.ctypes.data_as(C.c_void_p),
+                                         out.ctypes.data_as(C.c_void_p), 0))
+        return out
+
+    def debug_fetch(self, what, shape):
+        out = np.empty(int(np.prod(shape)))
+        n = _check(self.lib.mpsfr_debug_fetch(self._h, what.encode(), _dptr(out), out.size))
+        if n != out.size:
+            raise ValueError('%s: library returned %d values, expected %d' % (what, n, out.size))
+        return out.reshape(shape)
+
+    def profile(self):
+        """{kernel name: (total_ms, launches)} accumulated since the last profile_reset()."""
+        res = {}
+        for i in range(self.lib.mpsfr_profile_count()):
+            ms, n = C.c_double(), C.c_long()
+            _check(self.lib.mpsfr_profile_get(self._h, i, C.byref(ms), C.byref(n)))
+            res[self.lib.mpsfr_profile_name(i).decode()] = (ms.value, n.value)
+        return res
+
+    def profile_reset(self):
+        _check(self.lib.mpsfr_profile_reset(self._h))

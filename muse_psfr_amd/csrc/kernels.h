@@ -1,0 +1,81 @@
+// Launchers for the HIP kernels of the PSF-reconstruction hot path (implemented in kernels.hip).
+// Host code (mpsfr_api.cpp) sees only these plain functions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mpsfr {
+
+constexpr int NS = 40;       // dimpsf, psfrec.py:658
+constexpr int KS = 41;       // Moffat kernel side, psfrec.py:911-916
+constexpr int NAO = 80;      // AO-corrected zone, psfrec.py:103, 138
+constexpr int NFIT = 16;
+constexpr int MAXLGS = 4;
+
+// per-task scalars of the PSD model
+struct TaskPar {
+    double r0m53;     // r0^(-5/3), r0 at 0.5 um (psfrec.py:108, 183-187)
+    double inv_l0sq;  // (1/L0)^2
+    double cn2_0;     // normalised Cn2 of the ground layer (psfrec.py:57-58)
+    double cn2_1;
+    int geom;         // 0 = 4 LGS, 1 = 3 LGS (psfrec.py:86-91)
+    int pad;
+};
+
+// per-wavelength scalars
+struct LamPar {
+    double c;         // -0.5 * (2 pi / lambda_nm)^2   (psfrec.py:717, 793)
+    int npixc;        // psfrec.py:663-664
+    int pad;
+};
+
+struct AoGeom {
+    double h[2];            // layer altitudes [m]
+    double wind[2][2];      // wind[xy][layer] m/s  (psfrec.py:594)
+    int nlgs[2];            // per geometry
+    double poslgs[2][2][MAXLGS];  // [geom][xy][lgs] arcmin (psfrec.py:536)
+    int ndir;
+    double dir[2][25];      // [xy][dir] arcmin
+};
+
+enum KernelId {
+    K_AO_TABLES = 0,
+    K_TEL_OTF,
+    K_PSD_ROWFFT,
+    K_DC_SUM,
+    K_COLFFT_DPHI,
+    K_GTABLE,
+    K_MOFFAT_KERNELS,
+    K_OTF_ROWFFT,
+    K_COLPASS,
+    K_CONV,
+    K_FIT,
+    K_STAMP_SUM,
+    K_COUNT
+};
+
+void launch_ao_tables(hipStream_t s, const AoGeom& g, const uint8_t* d_mask_rec,
+                      const uint8_t* d_mask_res, double* d_tab);
+void launch_tel_otf(hipStream_t s, int N, const uint64_t* d_rows, int words, double pupsum,
+                    void* d_tel, bool f64out);
+void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp,
+                       const double* d_aotab, double cfit, void* d_C, const void* d_tw64);
+void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00);
+void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,
+                        double scale2, void* d_D0t, bool f64out, const void* d_tw64);
+void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void* d_tw64,
+                   int* d_samp_p, void* d_samp_a, void* d_G, bool f64);
+void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
+                           void* d_out, bool f64);
+void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
+                       const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
+                       const void* d_samp_a, void* d_Tq, const void* d_tw, bool f64, bool fast_exp);
+void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, const void* d_G,
+                    double* d_pre, bool f64);
+void launch_conv(hipStream_t s, int ntask, int nl, const double* d_pre, const void* d_ktt,
+                 const void* d_kmuse, double* d_fin, bool f64);
+void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit);
+void launch_stamp_sum(hipStream_t s, int ntask, int nl, const double* d_fin, double* d_sum,
+                      int accumulate);
+
+}  // namespace mpsfr

@@ -1,0 +1,869 @@
+// HIP kernels of the muse-psfr PSF-reconstruction hot path, written for gfx950 (MI355X, wave64).
+// Reference citations are to /root/reference/muse_psfr/psfrec.py.  See DESIGN.md for the data
+// layout and the derivation of the restructured algorithm.
+#include "kernels.h"
+
+#include "fft_lds.h"
+
+namespace mpsfr {
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kArcminH = 60.0 / 206265.0;   // psfrec.py:279, 440
+constexpr double kTi = 1.0e-3;                 // 1/Fsamp, psfrec.py:584
+constexpr double kDeltaT = 1.0e-3 + 2.5e-3;    // ti.max() + td, psfrec.py:449, 585
+
+__device__ __forceinline__ double sinc_pi(double x) {   // np.sinc
+    return x == 0.0 ? 1.0 : sinpi(x) / (kPi * x);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// K_AO_TABLES: row-independent tables of the AO-corrected zone (dsp4muse, psfrec.py:531-613 with
+// calc_mat_rec_glao_finale :218-364 (LSE, one DM layer) and calc_dsp_res_glao_finale :367-528).
+// tab[geom][dir][{T0,T1,noise}][a][b] with (a, b) = (fy index, fx index), i.e. already
+// transposed as psfrec.py:613 does, so that  PSD_AO[a][b] = VK * (cn2_0 T0 + cn2_1 T1) + noise.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ao_tables(AoGeom g, const uint8_t* __restrict__ mrec,
+                                                   const uint8_t* __restrict__ mres,
+                                                   double* __restrict__ tab) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= NAO * NAO) return;
+    const int d = blockIdx.y, geom = blockIdx.z;
+    const int i = pix / NAO, j = pix % NAO;              // i <-> fx, j <-> fy (reference layout)
+    const int ki = i < NAO / 2 ? i : i - NAO, kj = j < NAO / 2 ? j : j - NAO;
+    const double fx = ki / 16.0, fy = kj / 16.0;         // fftfreq(80, 0.2), psfrec.py:548
+    const double f = sqrt(fx * fx + fy * fy);
+    // psfrec.py:552-554 + :241-242: arg = arctan(fy/fx) folds the grid onto fx >= 0
+    const double gx = fabs(fx), gy = ki < 0 ? -fy : fy;
+    bool mr, ms;
+    if (mrec != nullptr) {
+        mr = mrec[pix] != 0;
+        ms = mres[pix] != 0;
+    } else {   // exact rule on the integer grid: fc = 1.5 = 24/16 (psfrec.py:254-257, 432-435)
+        const int ai = ki < 0 ? -ki : ki, aj = kj < 0 ? -kj : kj;
+        mr = ai >= 24 || aj >= 24;
+        ms = ai > 24 || aj > 24;
+    }
+    const double pitch = 8.0 / 24.0;
+    const double wamp = 2.0 * kPi * f * sinc_pi(pitch * gx) * sinc_pi(pitch * gy);  // |wfs|, :252
+    const int n = g.nlgs[geom];
+    const bool haveW = !mr && wamp != 0.0 && pix != 0;     // psfrec.py:339, 351-352
+    const double b0 = g.dir[0][d], b1 = g.dir[1][d];
+    const double bf = b0 * gx + b1 * gy;
+    const double theta_dm = 2.0 * kPi * 1.0 * kArcminH * bf;                       // :464
+    double T[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const double ph = 2.0 * kPi * (g.h[l] * kArcminH * bf -
+                                       (g.wind[0][l] * kDeltaT * gx + g.wind[1][l] * kDeltaT * gy));
+        double pr, pi_;
+        sincos(ph, &pi_, &pr);                                                      // :454-457
+        if (haveW && !ms) {
+            // sum_g (PbetaDM W_g) Mv[l,g] = (www/n) sum_g exp(i (theta_dm + psi_lg - phi_g))
+            const double www = sinc_pi(g.wind[0][l] * kTi * gx + g.wind[1][l] * kTi * gy);  // :442
+            double sr = 0.0, si = 0.0;
+            for (int q = 0; q < n; ++q) {
+                const double pf = gx * g.poslgs[geom][0][q] + gy * g.poslgs[geom][1][q];
+                const double phi = 2.0 * kPi * pf * 1.0 * kArcminH;                 // :279-281
+                const double psi = 2.0 * kPi * pf * g.h[l] * kArcminH;              // :440-443
+                double s_, c_;
+                sincos(theta_dm + psi - phi, &s_, &c_);
+                sr += c_;
+                si += s_;
+            }
+            pr -= www / n * sr;
+            pi_ -= www / n * si;
+        }
+        T[l] = pr * pr + pi_ * pi_;                                                 // :489
+    }
+    double noise = haveW ? 1.0 / (n * wamp * wamp) : 0.0;                           // :515
+    if (pix == 0) { T[0] = 0.0; T[1] = 0.0; noise = 0.0; }                          // :490, :516
+    double* o = tab + ((size_t)(geom * g.ndir + d) * 3) * (NAO * NAO) + j * NAO + i;  // transpose :613
+    o[0] = T[0];
+    o[NAO * NAO] = T[1];
+    o[2 * NAO * NAO] = noise;
+}
+
+// ------------------------------------------------------------------------------------------
+// K_TEL_OTF: telescope OTF (psfrec.py:784-790) as the exact integer autocorrelation of the pupil
+// mask: fft2(|ifft2(tab)|^2) = (tab (*) tab) / N^2 for a real 0/1 array, so
+// dlFTO[u][v] * N^2 = count(u, v) / sum(pup).  Rows of the pupil are bit masks.
+// telT[v][u], v in [0, N/2], u in [0, N) (transposed half plane; the OTF is even and symmetric).
+// ------------------------------------------------------------------------------------------
+template <typename RO>
+__global__ void __launch_bounds__(256) k_tel_otf(int N, const uint64_t* __restrict__ rows,
+                                                 int words, double pupsum, RO* __restrict__ telT) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    if (u >= N) return;
+    const int H = N / 2;
+    const int su = u < H ? u : u - N;
+    const int wpad = 2 * words + 1;
+    const int ws = v >> 6, bs = v & 63;
+    long count = 0;
+    const int p0 = su < 0 ? -su : 0, p1 = su < 0 ? H : H - su;
+    for (int p = p0; p < p1; ++p) {
+        const uint64_t* A = rows + (size_t)p * wpad;
+        const uint64_t* B = rows + (size_t)(p + su) * wpad;
+        for (int w = 0; w < words; ++w) {
+            uint64_t sh = B[w + ws] >> bs;
+            if (bs) sh |= B[w + ws + 1] << (64 - bs);
+            count += __popcll(A[w] & sh);
+        }
+    }
+    telT[(size_t)v * N + u] = (RO)((double)count / pupsum);
+}
+
+// ------------------------------------------------------------------------------------------
+// K_PSD_ROWFFT: residual phase PSD (simul_psd_wfm psfrec.py:36-151: psd_fit :616-626 outside /
+// max(fit, AO) inside the 80x80 corrected zone :148-149) generated on the fly in FFT-native
+// layout, row r, and its forward FFT along the row.  C[td][r][y], y in [0, N/2].
+// ------------------------------------------------------------------------------------------
+template <int N>
+__global__ void __launch_bounds__(256)
+k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict__ aotab,
+             double cfit, cx<double>* __restrict__ C, const cx<double>* __restrict__ twg) {
+    constexpr int TPR = LineCfg<N>::TPR, SLOTS = LineCfg<N>::SLOTS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
+    cx<double>* bufA = tw + N;
+    cx<double>* bufB = bufA + SLOTS * N;
+    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
+    const int r = blockIdx.x * SLOTS + slot;
+    const int td = blockIdx.y;
+    const int task = td / ndir, d = td % ndir;
+    for (int i = threadIdx.x; i < N; i += 256) tw[i] = twg[i];
+    const TaskPar p = tp[task];
+    const int su = r < N / 2 ? r : r - N;
+    cx<double>* a = bufA + slot * N;
+    cx<double>* b = bufB + slot * N;
+    const double* tb = aotab + ((size_t)(p.geom * ndir + d) * 3) * (NAO * NAO);
+    const bool rowin = su >= -NAO / 2 && su < NAO / 2;
+    const double fy = su + 0.5;
+    for (int c = t; c < N; c += TPR) {
+        const int sv = c < N / 2 ? c : c - N;
+        const double fx = sv + 0.5;
+        const double f2 = (fx * fx + fy * fy) * (1.0 / 256.0);      // L = 16 m, psfrec.py:618
+        double psd = 0.0;
+        if (f2 >= 2.25)                                             // f >= fc = 1.5, :624
+            psd = cfit * p.r0m53 * pow(f2 + p.inv_l0sq, -11.0 / 6.0);
+        if (rowin && sv >= -NAO / 2 && sv < NAO / 2) {
+            const int ia = su < 0 ? su + NAO : su, ib = sv < 0 ? sv + NAO : sv;
+            const double g2 = (double)(su * su + sv * sv) * (1.0 / 256.0);
+            const double vk = 0.0229 * p.r0m53 * pow(g2 + p.inv_l0sq, -11.0 / 6.0);   // :569-571
+            const int o = ia * NAO + ib;
+            const double ao = vk * (p.cn2_0 * tb[o] + p.cn2_1 * tb[NAO * NAO + o]) +
+                              tb[2 * NAO * NAO + o];
+            psd = fmax(psd, ao);                                    // :149
+        }
+        a[c] = {psd, 0.0};
+    }
+    __syncthreads();
+    const cx<double>* res = fft_forward<double, N, TPR>(a, b, tw, t);
+    cx<double>* out = C + ((size_t)td * N + r) * (N / 2 + 1);
+    for (int y = t; y <= N / 2; y += TPR) out[y] = res[y];
+}
+
+// K_DC_SUM: S00[td] = Re sum_r C[td][r][0] = sum of the PSD (bg[0,0], psfrec.py:721)
+template <int N>
+__global__ void __launch_bounds__(256) k_dc_sum(const cx<double>* __restrict__ C,
+                                                double* __restrict__ s00) {
+    __shared__ double part[4];
+    const int td = blockIdx.x;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < N; r += 256) s += C[((size_t)td * N + r) * (N / 2 + 1)].x;
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) s00[td] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// K_COLFFT_DPHI: column FFTs of C and the structure function (psfrec.py:717-722 without the
+// wavelength factor): D0t[td][y][x] = 2 scale (S00 - Re S[x][y]), y in [0, N/2], x in [0, N).
+// ------------------------------------------------------------------------------------------
+template <int N, typename RO>
+__global__ void __launch_bounds__(256)
+k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, double scale2,
+              RO* __restrict__ D0t, const cx<double>* __restrict__ twg) {
+    constexpr int TPR = LineCfg<N>::TPR, SLOTS = LineCfg<N>::SLOTS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
+    cx<double>* bufA = tw + N;
+    cx<double>* bufB = bufA + SLOTS * N;
+    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
+    const int y0 = blockIdx.x * SLOTS;
+    const int td = blockIdx.y;
+    for (int i = threadIdx.x; i < N; i += 256) tw[i] = twg[i];
+    const cx<double>* Ct = C + (size_t)td * N * (N / 2 + 1);
+    // SLOTS adjacent columns: consecutive lanes read consecutive columns of one row
+    for (int idx = threadIdx.x; idx < N * SLOTS; idx += 256) {
+        const int r = idx / SLOTS, s = idx % SLOTS;
+        const int y = y0 + s;
+        cx<double> v = {0.0, 0.0};
+        if (y <= N / 2) v = Ct[(size_t)r * (N / 2 + 1) + y];
+        bufA[s * N + r] = v;
+    }
+    __syncthreads();
+    const cx<double>* res = fft_forward<double, N, TPR>(bufA + slot * N, bufB + slot * N, tw, t);
+    const int y = y0 + slot;
+    if (y <= N / 2) {
+        const double dc = s00[td];
+        RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N;
+        for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[x].x));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K_GTABLE: per-wavelength sampling tables.  Sample i of the 40-pixel stamp sits at i*npixc/40
+// in the centred crop (psfrec.py:672-683); its left neighbour is native index
+// p_i = (floor(i npixc/40) - npixc/2) mod N with weight 1-a_i, a_i = frac.
+// G[l][v][j] = w_v ((1-a_j) W^-(v p_j) + a_j W^-(v (p_j+1))), W = exp(-2 pi i/N), w_v = 1 for
+// v in {0, N/2} else 2: bilinear interpolation folded into the second (column) pass.
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256)
+k_gtable(int N, const LamPar* __restrict__ lp, const cx<double>* __restrict__ twg,
+         int* __restrict__ samp_p, R* __restrict__ samp_a, cx<R>* __restrict__ G) {
+    const int l = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int npixc = lp[l].npixc;
+    if (idx < NS) {
+        const int q = idx * npixc;
+        samp_p[l * NS + idx] = ((q / NS - npixc / 2) % N + N) % N;
+        samp_a[l * NS + idx] = (R)((double)(q % NS) / NS);
+    }
+    if (idx >= (N / 2 + 1) * NS) return;
+    const int v = idx / NS, j = idx % NS;
+    const int q = j * npixc;
+    const int p = ((q / NS - npixc / 2) % N + N) % N;
+    const double a = (double)(q % NS) / NS;
+    const cx<double> w0 = twg[(int)(((long)v * p) % N)];
+    const cx<double> w1 = twg[(int)(((long)v * (p + 1)) % N)];
+    const double wv = (v == 0 || v == N / 2) ? 1.0 : 2.0;
+    // conj(W^(v p)) = exp(+2 pi i v p / N)
+    G[((size_t)l * (N / 2 + 1) + v) * NS + j] = {(R)(wv * ((1.0 - a) * w0.x + a * w1.x)),
+                                                 (R)(-wv * ((1.0 - a) * w0.y + a * w1.y))};
+}
+
+// ------------------------------------------------------------------------------------------
+// K_MOFFAT_KERNELS: astropy Moffat2DKernel(gamma, alpha, 41, 41) (psfrec.py:916, 927):
+// (1 + r^2/gamma^2)^-alpha at integer offsets, normalised to sum 1.
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256)
+k_moffat_kernels(const double* __restrict__ gam, const double* __restrict__ alp,
+                 R* __restrict__ out) {
+    __shared__ double part[4];
+    __shared__ double tot;
+    const int k = blockIdx.x;
+    const double g2 = gam[k] * gam[k], al = alp[k];
+    double vals[(KS * KS + 255) / 256];
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m < (KS * KS + 255) / 256; ++m) {
+        const int e = threadIdx.x + m * 256;
+        double v = 0.0;
+        if (e < KS * KS) {
+            const int dy = e / KS - KS / 2, dx = e % KS - KS / 2;
+            v = pow(1.0 + (double)(dx * dx + dy * dy) / g2, -al);
+        }
+        vals[m] = v;
+        s += v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tot = (part[0] + part[1]) + (part[2] + part[3]);
+    __syncthreads();
+    const double inv = 1.0 / tot;
+#pragma unroll
+    for (int m = 0; m < (KS * KS + 255) / 256; ++m) {
+        const int e = threadIdx.x + m * 256;
+        if (e < KS * KS) out[(size_t)k * KS * KS + e] = (R)(vals[m] * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K_OTF_ROWFFT (dominant kernel): for one task and one line v of the transposed half plane, for
+// every wavelength: OTF line = tel * sum_dir exp(c_l * D0)  (psfrec.py:793-797; the mean over
+// directions of psfrec.py:674 commutes with the FFT), forward FFT along the line, and the
+// bilinear-weighted extraction of the NS sampled positions -> Tq[task][l][v][i].
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__device__ __forceinline__ R exp_sel(R x, bool fast);
+template <>
+__device__ __forceinline__ float exp_sel<float>(float x, bool fast) {
+    return fast ? __expf(x) : expf(x);
+}
+template <>
+__device__ __forceinline__ double exp_sel<double>(double x, bool) { return exp(x); }
+
+template <typename R, int N>
+__global__ void __launch_bounds__(256)
+k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ telT,
+             const LamPar* __restrict__ lp, const int* __restrict__ samp_p,
+             const R* __restrict__ samp_a, cx<R>* __restrict__ Tq, const cx<R>* __restrict__ twg,
+             int fast_exp) {
+    constexpr int TPR = LineCfg<N>::TPR, SLOTS = LineCfg<N>::SLOTS;
+    constexpr int EPT = N / TPR;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cx<R>* tw = reinterpret_cast<cx<R>*>(smem);
+    cx<R>* bufA = tw + N;
+    cx<R>* bufB = bufA + SLOTS * N;
+    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
+    const int v = blockIdx.x * SLOTS + slot;
+    const int task = blockIdx.y;
+    const bool valid = v <= N / 2;
+    const int vv = valid ? v : N / 2;
+    for (int i = threadIdx.x; i < N; i += 256) tw[i] = twg[i];
+    cx<R>* a = bufA + slot * N;
+    cx<R>* b = bufB + slot * N;
+    R tel[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) tel[e] = telT[(size_t)vv * N + t + e * TPR];
+    const R* dline = D0t + ((size_t)task * ndir * (N / 2 + 1) + vv) * N;
+    const size_t dstride = (size_t)(N / 2 + 1) * N;
+    for (int l = 0; l < nl; ++l) {
+        const R c = (R)lp[l].c;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int x = t + e * TPR;
+            R acc = (R)0;
+            for (int d = 0; d < ndir; ++d) acc += exp_sel<R>(c * dline[d * dstride + x], fast_exp);
+            a[x] = {tel[e] * acc, (R)0};
+        }
+        __syncthreads();
+        const cx<R>* res = fft_forward<R, N, TPR>(a, b, tw, t);
+        if (valid) {
+            cx<R>* out = Tq + (((size_t)task * nl + l) * (N / 2 + 1) + v) * NS;
+            for (int i = t; i < NS; i += TPR) {
+                const int p = samp_p[l * NS + i];
+                const R w = samp_a[l * NS + i];
+                const cx<R> f0 = res[p], f1 = res[p + 1 == N ? 0 : p + 1];
+                out[i] = {((R)1 - w) * f0.x + w * f1.x, ((R)1 - w) * f0.y + w * f1.y};
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K_COLPASS: second (column) pass restricted to the sampled positions,
+// stamp[i][j] = sum_v Re(G[l][v][j] * Tq[v][i]) -- with A = conj-FFT convention of K_OTF_ROWFFT
+// this is cos*Ar + sin*Ai -- then clamp >= 0 (psfrec.py:680) and normalise to sum 1 (:685).
+// ------------------------------------------------------------------------------------------
+template <typename R, int N>
+__global__ void __launch_bounds__(256)
+k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
+          double* __restrict__ pre) {
+    constexpr int VB = 16;
+    constexpr int NO = (NS * NS + 255) / 256;
+    __shared__ cx<R> sT[VB][NS];
+    __shared__ cx<R> sG[VB][NS];
+    __shared__ double part[4];
+    __shared__ double tot;
+    const int l = blockIdx.x, task = blockIdx.y;
+    const cx<R>* Tp = Tq + ((size_t)task * nl + l) * (N / 2 + 1) * NS;
+    const cx<R>* Gp = G + (size_t)l * (N / 2 + 1) * NS;
+    R acc[NO];
+    int oi[NO], oj[NO];
+#pragma unroll
+    for (int m = 0; m < NO; ++m) {
+        const int o = threadIdx.x + m * 256;
+        acc[m] = (R)0;
+        oi[m] = (o < NS * NS) ? o / NS : 0;
+        oj[m] = (o < NS * NS) ? o % NS : 0;
+    }
+    for (int v0 = 0; v0 <= N / 2; v0 += VB) {
+        const int nv = (N / 2 + 1 - v0) < VB ? (N / 2 + 1 - v0) : VB;
+        for (int e = threadIdx.x; e < VB * NS; e += 256) {
+            const int vb = e / NS;
+            cx<R> tv = {(R)0, (R)0}, gv = {(R)0, (R)0};
+            if (vb < nv) {
+                tv = Tp[(size_t)v0 * NS + e];
+                gv = Gp[(size_t)v0 * NS + e];
+            }
+            (&sT[0][0])[e] = tv;
+            (&sG[0][0])[e] = gv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int vb = 0; vb < VB; ++vb) {
+#pragma unroll
+            for (int m = 0; m < NO; ++m) {
+                const cx<R> tv = sT[vb][oi[m]], gv = sG[vb][oj[m]];
+                acc[m] += gv.x * tv.x + gv.y * tv.y;   // Re(G conj(A))
+            }
+        }
+        __syncthreads();
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m < NO; ++m) {
+        const int o = threadIdx.x + m * 256;
+        if (acc[m] < (R)0) acc[m] = (R)0;
+        if (o < NS * NS) s += (double)acc[m];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tot = (part[0] + part[1]) + (part[2] + part[3]);
+    __syncthreads();
+    const double inv = 1.0 / tot;
+    double* out = pre + ((size_t)task * nl + l) * NS * NS;
+#pragma unroll
+    for (int m = 0; m < NO; ++m) {
+        const int o = threadIdx.x + m * 256;
+        if (o < NS * NS) out[o] = (double)acc[m] * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K_CONV: convolve_final_psf (psfrec.py:874-930): two zero-padded 'same' convolutions with
+// 41x41 Moffat kernels (tip-tilt kernel of the task, instrument kernel of the wavelength).
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256)
+k_conv(int nl, const double* __restrict__ pre, const R* __restrict__ ktt,
+       const R* __restrict__ kmuse, double* __restrict__ fin) {
+    constexpr int PW = NS + KS - 1;   // 80: image at offset 20 inside a zero frame
+    constexpr int NO = (NS * NS + 255) / 256;
+    extern __shared__ __align__(16) unsigned char smem[];
+    R* img = reinterpret_cast<R*>(smem);   // [PW][PW]
+    R* ker = img + PW * PW;                // [KS*KS]
+    const int l = blockIdx.x, task = blockIdx.y;
+    const double* src = pre + ((size_t)task * nl + l) * NS * NS;
+    for (int e = threadIdx.x; e < PW * PW; e += 256) {
+        const int P = e / PW - KS / 2, Q = e % PW - KS / 2;
+        img[e] = (P >= 0 && P < NS && Q >= 0 && Q < NS) ? (R)src[P * NS + Q] : (R)0;
+    }
+    R acc[NO];
+    for (int pass = 0; pass < 2; ++pass) {
+        const R* kg = pass == 0 ? ktt + (size_t)task * KS * KS : kmuse + (size_t)l * KS * KS;
+        for (int e = threadIdx.x; e < KS * KS; e += 256) ker[e] = kg[e];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < NO; ++m) {
+            const int o = threadIdx.x + m * 256;
+            R s = (R)0;
+            if (o < NS * NS) {
+                const int i = o / NS, j = o % NS;
+                // out[i][j] = sum_{a,b} K[a][b] img[i - (a-20)][j - (b-20)]  (frame offset +20)
+                for (int a = 0; a < KS; ++a) {
+                    const R* irow = img + (i - a + 2 * (KS / 2)) * PW + j + 2 * (KS / 2);
+                    const R* krow = ker + a * KS;
+#pragma unroll
+                    for (int b = 0; b < KS; ++b) s += krow[b] * irow[-b];
+                }
+            }
+            acc[m] = s;
+        }
+        __syncthreads();
+        if (pass == 0) {
+#pragma unroll
+            for (int m = 0; m < NO; ++m) {
+                const int o = threadIdx.x + m * 256;
+                if (o < NS * NS) img[(o / NS + KS / 2) * PW + o % NS + KS / 2] = acc[m];
+            }
+        }
+    }
+    double* out = fin + ((size_t)task * nl + l) * NS * NS;
+#pragma unroll
+    for (int m = 0; m < NO; ++m) {
+        const int o = threadIdx.x + m * 256;
+        if (o < NS * NS) out[o] = (double)acc[m];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K_FIT: 5-parameter circular Moffat least-squares fit per stamp (fit_psf_cube psfrec.py:861-871
+// -> mpdaf Image.moffat_fit(circular=True, fit_back=False)): I (1 + ((p-p0)^2+(q-q0)^2)/a^2)^-n,
+// unweighted, all 1600 pixels.  One wavefront per stamp, 25 pixels per lane held in registers,
+// Levenberg-Marquardt in fp64 with wave-shuffle reductions of the 21 normal-equation sums.
+// ------------------------------------------------------------------------------------------
+constexpr int NPIX_LANE = NS * NS / 64;   // 25
+
+struct NormEq {
+    double a[15];   // upper triangle of J^T J, row-major: (0,0)(0,1)..(0,4)(1,1)..(4,4)
+    double g[5];    // J^T r
+    double chi2;
+};
+
+__device__ __forceinline__ void moffat_accumulate(const double* dpix, int lane, const double* v,
+                                                  NormEq& ne, bool with_jac) {
+    double a[15], g[5], chi2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) a[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) g[k] = 0.0;
+    const double I = v[0], p0 = v[1], q0 = v[2], al = v[3], n = v[4];
+    const double ia2 = 1.0 / (al * al);
+#pragma unroll 5
+    for (int m = 0; m < NPIX_LANE; ++m) {
+        const int o = lane + m * 64;
+        const double dp = (double)(o / NS) - p0, dq = (double)(o % NS) - q0;
+        const double u = dp * dp + dq * dq;
+        const double gg = 1.0 + u * ia2;
+        const double lg = log(gg);
+        const double e = exp(-n * lg);
+        const double r = I * e - dpix[m];
+        chi2 += r * r;
+        if (with_jac) {
+            const double cm = I * n * e / gg;
+            double J[5];
+            J[0] = e;
+            J[1] = cm * 2.0 * dp * ia2;
+            J[2] = cm * 2.0 * dq * ia2;
+            J[3] = cm * 2.0 * u * ia2 / al;
+            J[4] = -I * e * lg;
+            int k = 0;
+#pragma unroll
+            for (int x = 0; x < 5; ++x) {
+                g[x] += J[x] * r;
+#pragma unroll
+                for (int y = x; y < 5; ++y) a[k++] += J[x] * J[y];
+            }
+        }
+    }
+    ne.chi2 = wave_sum(chi2);
+    if (with_jac) {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) ne.a[k] = wave_sum(a[k]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) ne.g[k] = wave_sum(g[k]);
+    }
+}
+
+// solve (A + mu diag(A)) x = -g by Cholesky; returns false if not positive definite
+__device__ __forceinline__ bool lm_solve(const NormEq& ne, double mu, double* x) {
+    double L[5][5];
+    int k = 0;
+    for (int i = 0; i < 5; ++i)
+        for (int j = i; j < 5; ++j) {
+            L[i][j] = ne.a[k];
+            L[j][i] = ne.a[k];
+            ++k;
+        }
+    for (int i = 0; i < 5; ++i) L[i][i] *= (1.0 + mu);
+    for (int j = 0; j < 5; ++j) {
+        double s = L[j][j];
+        for (int q = 0; q < j; ++q) s -= L[j][q] * L[j][q];
+        if (!(s > 0.0)) return false;
+        const double dj = sqrt(s);
+        L[j][j] = dj;
+        for (int i = j + 1; i < 5; ++i) {
+            double t = L[i][j];
+            for (int q = 0; q < j; ++q) t -= L[i][q] * L[j][q];
+            L[i][j] = t / dj;
+        }
+    }
+    double y[5];
+    for (int i = 0; i < 5; ++i) {
+        double t = -ne.g[i];
+        for (int q = 0; q < i; ++q) t -= L[i][q] * y[q];
+        y[i] = t / L[i][i];
+    }
+    for (int i = 4; i >= 0; --i) {
+        double t = y[i];
+        for (int q = i + 1; q < 5; ++q) t -= L[q][i] * x[q];
+        x[i] = t / L[i][i];
+    }
+    return true;
+}
+
+// inverse of the symmetric 5x5 (Cholesky); false if singular
+__device__ __forceinline__ bool spd_inverse_diag(const NormEq& ne, double cov[5][5]) {
+    NormEq e = ne;
+    for (int c = 0; c < 5; ++c) {
+        for (int k = 0; k < 5; ++k) e.g[k] = (k == c) ? -1.0 : 0.0;
+        double x[5];
+        if (!lm_solve(e, 0.0, x)) return false;
+        for (int k = 0; k < 5; ++k) cov[k][c] = x[k];
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restrict__ stamps,
+                                             double* __restrict__ fit) {
+    const int lane = threadIdx.x & 63;
+    const int st = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (st >= nstamp) return;   // whole wave exits together
+    const double* src = stamps + (size_t)st * NS * NS;
+    double dpix[NPIX_LANE];
+    double best = -1.0e300;
+    int besto = 0;
+#pragma unroll
+    for (int m = 0; m < NPIX_LANE; ++m) {
+        dpix[m] = src[lane + m * 64];
+        if (dpix[m] > best) { best = dpix[m]; besto = lane + m * 64; }
+    }
+    // argmax over the wave (first maximum in C order, as np.argmax)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oo = __shfl_xor(besto, o, 64);
+        if (ob > best || (ob == best && oo < besto)) { best = ob; besto = oo; }
+    }
+    double v[5];
+    v[0] = best;
+    v[1] = (double)(besto / NS);
+    v[2] = (double)(besto % NS);
+    v[4] = 2.0;
+    v[3] = 4.0 / (2.0 * sqrt(sqrt(2.0) - 1.0));   // start fwhm = 4 px at n = 2
+    NormEq ne;
+    moffat_accumulate(dpix, lane, v, ne, true);
+    double mu = 1.0e-3;
+    int it = 0, status = 1;
+    const int maxit = 200;
+    while (it < maxit) {
+        ++it;
+        double dx[5];
+        if (!lm_solve(ne, mu, dx)) {
+            mu *= 10.0;
+            if (mu > 1.0e15) { status = 2; break; }
+            continue;
+        }
+        double vn[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) vn[k] = v[k] + dx[k];
+        bool ok = vn[3] > 1.0e-3 && vn[4] > 1.0e-2 && vn[4] < 1.0e3;
+        NormEq nn;
+        if (ok) {
+            moffat_accumulate(dpix, lane, vn, nn, true);
+            ok = nn.chi2 <= ne.chi2;     // NaN compares false
+        }
+        if (ok) {
+            double rel = 0.0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const double sc = fabs(vn[k]) + 1.0e-300;
+                rel = fmax(rel, fabs(dx[k]) / sc);
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] = vn[k];
+            ne = nn;
+            mu = fmax(mu * 0.1, 1.0e-14);
+            if (rel < 1.0e-12) { status = 0; break; }
+        } else {
+            mu *= 10.0;
+            if (mu > 1.0e15) { status = 0; break; }   // no further descent possible: at the minimum
+        }
+    }
+    if (lane == 0) {
+        double* o = fit + (size_t)st * NFIT;
+        const double al = fabs(v[3]), n = v[4];
+        const double s2 = exp2(1.0 / n) - 1.0;
+        const double sq = sqrt(s2);
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = al; o[4] = n;
+        o[5] = 2.0 * al * sq;
+        o[6] = ne.chi2;
+        o[7] = (double)it;
+        double cov[5][5];
+        const double dof = (double)(NS * NS - 5);
+        if (spd_inverse_diag(ne, cov)) {
+            const double s = ne.chi2 / dof;
+            for (int k = 0; k < 5; ++k) o[8 + k] = sqrt(fmax(cov[k][k] * s, 0.0));
+            const double da = 2.0 * sq;
+            const double dn = -al * exp2(1.0 / n) * 0.69314718055994530942 / (sq * n * n);
+            const double var = da * da * cov[3][3] + 2.0 * da * dn * cov[3][4] + dn * dn * cov[4][4];
+            o[13] = sqrt(fmax(var * s, 0.0));
+        } else {
+            for (int k = 0; k < 6; ++k) o[8 + k] = 0.0;
+            if (status == 0) status = 2;
+        }
+        o[14] = (double)status;
+        o[15] = v[0] * kPi * al * al / (n - 1.0);
+    }
+}
+
+// K_STAMP_SUM: deterministic sum of the final stamps over the tasks of a chunk (PSF_MEAN numerator,
+// psfrec.py:1104)
+__global__ void __launch_bounds__(256) k_stamp_sum(int ntask, int nl, const double* __restrict__ fin,
+                                                   double* __restrict__ sum, int accumulate) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per = (size_t)nl * NS * NS;
+    if (e >= per) return;
+    double s = accumulate ? sum[e] : 0.0;
+    for (int t = 0; t < ntask; ++t) s += fin[(size_t)t * per + e];
+    sum[e] = s;
+}
+
+template <typename T>
+size_t fft_smem(int N) {
+    const int tpr = (N == 1280) ? 128 : N / 8;
+    const int slots = 256 / tpr;
+    return (size_t)(N + 2 * slots * N) * sizeof(T) * 2;
+}
+
+}  // namespace
+
+#define DISPATCH_N(N, CALL)                      \
+    switch (N) {                                 \
+        case 128: { constexpr int NN = 128; CALL; } break;   \
+        case 256: { constexpr int NN = 256; CALL; } break;   \
+        case 512: { constexpr int NN = 512; CALL; } break;   \
+        case 1024: { constexpr int NN = 1024; CALL; } break; \
+        case 1280: { constexpr int NN = 1280; CALL; } break; \
+        default: break;                          \
+    }
+
+void launch_ao_tables(hipStream_t s, const AoGeom& g, const uint8_t* d_mask_rec,
+                      const uint8_t* d_mask_res, double* d_tab) {
+    dim3 grid((NAO * NAO + 255) / 256, g.ndir, 2);
+    hipLaunchKernelGGL(k_ao_tables, grid, dim3(256), 0, s, g, d_mask_rec, d_mask_res, d_tab);
+}
+
+void launch_tel_otf(hipStream_t s, int N, const uint64_t* d_rows, int words, double pupsum,
+                    void* d_tel, bool f64out) {
+    dim3 grid((N + 255) / 256, N / 2 + 1);
+    if (f64out)
+        hipLaunchKernelGGL(k_tel_otf<double>, grid, dim3(256), 0, s, N, d_rows, words, pupsum,
+                           (double*)d_tel);
+    else
+        hipLaunchKernelGGL(k_tel_otf<float>, grid, dim3(256), 0, s, N, d_rows, words, pupsum,
+                           (float*)d_tel);
+}
+
+template <typename K>
+static void allow_smem(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)bytes);
+}
+
+void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp,
+                       const double* d_aotab, double cfit, void* d_C, const void* d_tw64) {
+    const size_t sm = fft_smem<double>(N);
+    DISPATCH_N(N, {
+        allow_smem(k_psd_rowfft<NN>, sm);
+        dim3 grid(NN / LineCfg<NN>::SLOTS, ntd);
+        hipLaunchKernelGGL(k_psd_rowfft<NN>, grid, dim3(256), sm, s, ndir, d_tp, d_aotab, cfit,
+                           (cx<double>*)d_C, (const cx<double>*)d_tw64);
+    })
+}
+
+void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00) {
+    DISPATCH_N(N, {
+        hipLaunchKernelGGL(k_dc_sum<NN>, dim3(ntd), dim3(256), 0, s, (const cx<double>*)d_C,
+                           d_s00);
+    })
+}
+
+void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,
+                        double scale2, void* d_D0t, bool f64out, const void* d_tw64) {
+    const size_t sm = fft_smem<double>(N);
+    DISPATCH_N(N, {
+        constexpr int SL = LineCfg<NN>::SLOTS;
+        dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntd);
+        if (f64out) {
+            allow_smem(k_colfft_dphi<NN, double>, sm);
+            hipLaunchKernelGGL((k_colfft_dphi<NN, double>), grid, dim3(256), sm, s,
+                               (const cx<double>*)d_C, d_s00, scale2, (double*)d_D0t,
+                               (const cx<double>*)d_tw64);
+        } else {
+            allow_smem(k_colfft_dphi<NN, float>, sm);
+            hipLaunchKernelGGL((k_colfft_dphi<NN, float>), grid, dim3(256), sm, s,
+                               (const cx<double>*)d_C, d_s00, scale2, (float*)d_D0t,
+                               (const cx<double>*)d_tw64);
+        }
+    })
+}
+
+void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void* d_tw64,
+                   int* d_samp_p, void* d_samp_a, void* d_G, bool f64) {
+    dim3 grid(((N / 2 + 1) * NS + 255) / 256, nl);
+    if (f64)
+        hipLaunchKernelGGL(k_gtable<double>, grid, dim3(256), 0, s, N, d_lp,
+                           (const cx<double>*)d_tw64, d_samp_p, (double*)d_samp_a,
+                           (cx<double>*)d_G);
+    else
+        hipLaunchKernelGGL(k_gtable<float>, grid, dim3(256), 0, s, N, d_lp,
+                           (const cx<double>*)d_tw64, d_samp_p, (float*)d_samp_a, (cx<float>*)d_G);
+}
+
+void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
+                           void* d_out, bool f64) {
+    if (nker <= 0) return;
+    if (f64)
+        hipLaunchKernelGGL(k_moffat_kernels<double>, dim3(nker), dim3(256), 0, s, d_gamma, d_alpha,
+                           (double*)d_out);
+    else
+        hipLaunchKernelGGL(k_moffat_kernels<float>, dim3(nker), dim3(256), 0, s, d_gamma, d_alpha,
+                           (float*)d_out);
+}
+
+void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
+                       const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
+                       const void* d_samp_a, void* d_Tq, const void* d_tw, bool f64,
+                       bool fast_exp) {
+    DISPATCH_N(N, {
+        constexpr int SL = LineCfg<NN>::SLOTS;
+        dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntask);
+        if (f64) {
+            const size_t sm = fft_smem<double>(N);
+            allow_smem(k_otf_rowfft<double, NN>, sm);
+            hipLaunchKernelGGL((k_otf_rowfft<double, NN>), grid, dim3(256), sm, s, ndir, nl,
+                               (const double*)d_D0t, (const double*)d_tel, d_lp, d_samp_p,
+                               (const double*)d_samp_a, (cx<double>*)d_Tq, (const cx<double>*)d_tw,
+                               0);
+        } else {
+            const size_t sm = fft_smem<float>(N);
+            allow_smem(k_otf_rowfft<float, NN>, sm);
+            hipLaunchKernelGGL((k_otf_rowfft<float, NN>), grid, dim3(256), sm, s, ndir, nl,
+                               (const float*)d_D0t, (const float*)d_tel, d_lp, d_samp_p,
+                               (const float*)d_samp_a, (cx<float>*)d_Tq, (const cx<float>*)d_tw,
+                               fast_exp ? 1 : 0);
+        }
+    })
+}
+
+void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, const void* d_G,
+                    double* d_pre, bool f64) {
+    dim3 grid(nl, ntask);
+    DISPATCH_N(N, {
+        if (f64)
+            hipLaunchKernelGGL((k_colpass<double, NN>), grid, dim3(256), 0, s, nl,
+                               (const cx<double>*)d_Tq, (const cx<double>*)d_G, d_pre);
+        else
+            hipLaunchKernelGGL((k_colpass<float, NN>), grid, dim3(256), 0, s, nl,
+                               (const cx<float>*)d_Tq, (const cx<float>*)d_G, d_pre);
+    })
+}
+
+void launch_conv(hipStream_t s, int ntask, int nl, const double* d_pre, const void* d_ktt,
+                 const void* d_kmuse, double* d_fin, bool f64) {
+    dim3 grid(nl, ntask);
+    constexpr int PW = NS + KS - 1;
+    if (f64) {
+        const size_t sm = (size_t)(PW * PW + KS * KS) * sizeof(double);
+        allow_smem(k_conv<double>, sm);
+        hipLaunchKernelGGL(k_conv<double>, grid, dim3(256), sm, s, nl, d_pre, (const double*)d_ktt,
+                           (const double*)d_kmuse, d_fin);
+    } else {
+        const size_t sm = (size_t)(PW * PW + KS * KS) * sizeof(float);
+        hipLaunchKernelGGL(k_conv<float>, grid, dim3(256), sm, s, nl, d_pre, (const float*)d_ktt,
+                           (const float*)d_kmuse, d_fin);
+    }
+}
+
+void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit) {
+    if (nstamp <= 0) return;
+    hipLaunchKernelGGL(k_fit, dim3((nstamp + 3) / 4), dim3(256), 0, s, nstamp, d_stamps, d_fit);
+}
+
+void launch_stamp_sum(hipStream_t s, int ntask, int nl, const double* d_fin, double* d_sum,
+                      int accumulate) {
+    const size_t per = (size_t)nl * NS * NS;
+    hipLaunchKernelGGL(k_stamp_sum, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, ntask, nl,
+                       d_fin, d_sum, accumulate);
+}
+
+}  // namespace mpsfr

@@ -1,0 +1,639 @@
+// Host side of libmpsfr: context, workspaces, the chunked pipeline and the C ABI of
+// include/mpsfr.h.  Reference citations are to /root/reference/muse_psfr/psfrec.py.
+#include "../../include/mpsfr.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "coeff_l0_table.h"
+#include "kernels.h"
+
+using namespace mpsfr;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(MPSFR_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                              \
+    } while (0)
+
+const char* kKernelNames[K_COUNT] = {
+    "ao_tables", "tel_otf", "psd_rowfft", "dc_sum", "colfft_dphi", "gtable",
+    "moffat_kernels", "otf_rowfft", "colpass", "conv", "fit", "stamp_sum"};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct Pending {
+    int id;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct mpsfr_ctx {
+    int device = 0, N = 0, dimpsf = 0, prec = 0;
+    double pixscale = 0.2;
+    bool f64 = false;
+    hipStream_t stream = nullptr;
+    // options
+    int chunk_tasks = 32;
+    bool fast_exp = false;
+    bool profile = false;
+    // constant tables
+    DevBuf tw64, twR, tel, rows;
+    // per-call tables
+    DevBuf aotab, mask_rec, mask_res, tp, lp, samp_p, samp_a, G, gam, alp, ktt, kmuse;
+    // chunk workspaces
+    DevBuf C, s00, D0t, Tq, pre, fin, fit, sum, stage;
+    // bookkeeping for debug_fetch
+    int last_ndir = 0, last_nl = 0, last_chunk_tasks = 0;
+    // profiling
+    double prof_ms[K_COUNT] = {0};
+    long prof_n[K_COUNT] = {0};
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+namespace {
+
+size_t rsize(const mpsfr_ctx* c) { return c->f64 ? sizeof(double) : sizeof(float); }
+
+int ensure(mpsfr_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return MPSFR_OK;
+    if (b.p) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = bytes + bytes / 8;
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        b.p = nullptr;
+        return fail(MPSFR_E_NOMEM, "hipMalloc of %zu bytes failed", want);
+    }
+    b.cap = want;
+    return MPSFR_OK;
+}
+
+void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+hipEvent_t get_event(mpsfr_ctx* c) {
+    if (!c->pool.empty()) {
+        hipEvent_t e = c->pool.back();
+        c->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    mpsfr_ctx* c;
+    int id;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(mpsfr_ctx* ctx, int kid) : c(ctx), id(kid) {
+        if (c->profile) {
+            a = get_event(c);
+            b = get_event(c);
+            (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~ProfScope() {
+        if (c->profile) {
+            (void)hipEventRecord(b, c->stream);
+            c->pending.push_back({id, a, b});
+        }
+    }
+};
+
+int resolve_profile(mpsfr_ctx* c) {
+    if (c->pending.empty()) return MPSFR_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c->prof_ms[p.id] += ms;
+            c->prof_n[p.id] += 1;
+        }
+        c->pool.push_back(p.a);
+        c->pool.push_back(p.b);
+    }
+    c->pending.clear();
+    return MPSFR_OK;
+}
+
+bool supported_dim(int n) { return n == 128 || n == 256 || n == 512 || n == 1024 || n == 1280; }
+
+// np.interp(L0, arange(1, 201), coeff)  (psfrec.py:897)
+double interp_coeff(double l0) {
+    if (l0 <= 1.0) return kCoeffL0[0];
+    if (l0 >= 200.0) return kCoeffL0[kCoeffL0N - 1];
+    int j = (int)std::floor(l0) - 1;
+    if (j > kCoeffL0N - 2) j = kCoeffL0N - 2;
+    const double x0 = (double)(j + 1);
+    const double slope = (kCoeffL0[j + 1] - kCoeffL0[j]) / 1.0;
+    return slope * (l0 - x0) + kCoeffL0[j];
+}
+
+// Moffat alpha [px] of the residual tip-tilt kernel (psfrec.py:879-905)
+double tiptilt_alpha(double seeing, double gl, double l0, double pixscale) {
+    const double seeingHL = seeing * std::pow(1.0 - gl, 3.0 / 5.0);
+    const double r0HL = 0.976 * 0.5 / seeingHL / 4.85;
+    const double coeffHL = interp_coeff(l0);
+    const double two_pi = 2.0 * M_PI;
+    const double a = (0.5 * 1.0e-6 / two_pi);
+    const double fwhm = std::sqrt(coeffHL * 0.97 * 6.88 * (a * a) * std::pow(8.0, -1.0 / 3.0) *
+                                  std::pow(r0HL, -5.0 / 3.0)) /
+                        (4.85 * 1.0e-6) * 2.35 / pixscale;
+    return fwhm / (2.0 * std::sqrt(std::pow(2.0, 1.0 / 2.0) - 1.0));
+}
+
+double polyval6(const double* p, double x) {
+    double y = 0.0;
+    for (int i = 0; i < 6; ++i) y = y * x + p[i];
+    return y;
+}
+
+// muse_intrinsic_psf (psfrec.py:1144-1171) -> Moffat (alpha px, beta) of the instrument kernel
+void muse_kernel_params(double lbda_nm, double pixscale, double* alpha_px, double* beta) {
+    static const double pol_beta[6] = {-0.83704697, 1.1337153, 0.0609222,
+                                       -1.35581762, 1.15237178, 2.2106042};
+    static const double pol_fwhm[6] = {0.60467385, -1.58905792, 1.75293264,
+                                       -1.0368302, 0.21487023, 0.34851139};
+    const double lb = (10.0 * lbda_nm - 4750.0) / (9350.0 - 4750.0);
+    const double fwhm = polyval6(pol_fwhm, lb) / pixscale;
+    const double b = polyval6(pol_beta, lb);
+    *beta = b;
+    *alpha_px = fwhm / (2.0 * std::sqrt(std::pow(2.0, 1.0 / b) - 1.0));
+}
+
+// npixc, psfrec.py:663-664 (np.round = round half to even = nearbyint in the default mode)
+int npix_crop(double lbda_nm, int dimpsf, double pixscale) {
+    const double x = ((((dimpsf * pixscale) * 2) * 8) * 4.85) * 1000;
+    return (int)(std::nearbyint((x / lbda_nm) / 2.0) * 2.0);
+}
+
+int build_constant_tables(mpsfr_ctx* c) {
+    const int N = c->N;
+    // twiddles exp(-2 pi i m / N)
+    std::vector<double> tw(2 * (size_t)N);
+    std::vector<float> twf(2 * (size_t)N);
+    for (int m = 0; m < N; ++m) {
+        const long double ang = -2.0L * 3.141592653589793238462643383279502884L * m / N;
+        tw[2 * m] = (double)cosl(ang);
+        tw[2 * m + 1] = (double)sinl(ang);
+        twf[2 * m] = (float)tw[2 * m];
+        twf[2 * m + 1] = (float)tw[2 * m + 1];
+    }
+    int rc;
+    if ((rc = ensure(c, c->tw64, tw.size() * sizeof(double)))) return rc;
+    HIPCHK(hipMemcpy(c->tw64.p, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (c->f64) {
+        if ((rc = ensure(c, c->twR, tw.size() * sizeof(double)))) return rc;
+        HIPCHK(hipMemcpy(c->twR.p, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        if ((rc = ensure(c, c->twR, twf.size() * sizeof(float)))) return rc;
+        HIPCHK(hipMemcpy(c->twR.p, twf.data(), twf.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // pupil mask rows as bit masks: pupil_mask(dim/4, dim/2, oc=0.14), psfrec.py:190-203, 656
+    const int H = N / 2, words = (H + 63) / 64, wpad = 2 * words + 1;
+    std::vector<uint64_t> rows((size_t)H * wpad, 0);
+    const double cen = (H - 1) / 2.0, radius = N / 4.0;
+    long pupsum = 0;
+    for (int x = 0; x < H; ++x)
+        for (int y = 0; y < H; ++y) {
+            const double rho = std::hypot(x - cen, y - cen) / radius;
+            if (rho < 1.0 && rho >= 0.14) {
+                rows[(size_t)x * wpad + (y >> 6)] |= (uint64_t)1 << (y & 63);
+                ++pupsum;
+            }
+        }
+    if ((rc = ensure(c, c->rows, rows.size() * sizeof(uint64_t)))) return rc;
+    HIPCHK(hipMemcpy(c->rows.p, rows.data(), rows.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if ((rc = ensure(c, c->tel, (size_t)(H + 1) * N * rsize(c)))) return rc;
+    {
+        ProfScope ps(c, K_TEL_OTF);
+        launch_tel_otf(c->stream, N, (const uint64_t*)c->rows.p, words, (double)pupsum, c->tel.p,
+                       c->f64);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MPSFR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mpsfr_last_error(void) { return g_err.c_str(); }
+
+int mpsfr_version(void) { return 100; }
+
+int mpsfr_create(mpsfr_ctx** out, int device_id, int dim, int dimpsf, double pixscale,
+                 int precision) {
+    if (!out) return fail(MPSFR_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!supported_dim(dim))
+        return fail(MPSFR_E_INVALID, "dim=%d not supported (128, 256, 512, 1024, 1280)", dim);
+    if (dimpsf != NS) return fail(MPSFR_E_INVALID, "dimpsf=%d not supported (only 40)", dimpsf);
+    if (!(pixscale > 0.0)) return fail(MPSFR_E_INVALID, "pixscale must be > 0");
+    if (precision != MPSFR_PREC_MIXED && precision != MPSFR_PREC_F64)
+        return fail(MPSFR_E_INVALID, "precision must be 0 (mixed) or 1 (f64)");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev)
+        return fail(MPSFR_E_INVALID, "device_id=%d out of range (%d devices)", device_id, ndev);
+    HIPCHK(hipSetDevice(device_id));
+    mpsfr_ctx* c = new mpsfr_ctx();
+    c->device = device_id;
+    c->N = dim;
+    c->dimpsf = dimpsf;
+    c->pixscale = pixscale;
+    c->prec = precision;
+    c->f64 = precision == MPSFR_PREC_F64;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(MPSFR_E_HIP, "hipStreamCreate failed");
+    }
+    const int rc = build_constant_tables(c);
+    if (rc) {
+        mpsfr_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return MPSFR_OK;
+}
+
+void mpsfr_destroy(mpsfr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    DevBuf* all[] = {&c->tw64, &c->twR, &c->tel, &c->rows, &c->aotab, &c->mask_rec, &c->mask_res,
+                     &c->tp, &c->lp, &c->samp_p, &c->samp_a, &c->G, &c->gam, &c->alp, &c->ktt,
+                     &c->kmuse, &c->C, &c->s00, &c->D0t, &c->Tq, &c->pre, &c->fin, &c->fit,
+                     &c->sum, &c->stage};
+    for (auto b : all) release(*b);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
+    if (!c || !key) return fail(MPSFR_E_INVALID, "NULL argument");
+    if (!strcmp(key, "chunk_tasks")) {
+        if (value < 1 || value > 4096) return fail(MPSFR_E_INVALID, "chunk_tasks out of range");
+        c->chunk_tasks = (int)value;
+    } else if (!strcmp(key, "fast_exp")) {
+        c->fast_exp = value != 0.0;
+    } else if (!strcmp(key, "profile")) {
+        c->profile = value != 0.0;
+    } else {
+        return fail(MPSFR_E_INVALID, "unknown option '%s'", key);
+    }
+    return MPSFR_OK;
+}
+
+int mpsfr_sync(mpsfr_ctx* c) {
+    if (!c) return fail(MPSFR_E_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MPSFR_OK;
+}
+
+int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const double* gl,
+                      const double* l0, const uint8_t* three_lgs, const double h[2],
+                      double wind_speed, int npsflin, int nl, const double* lbda_nm,
+                      const uint8_t* mask_rec, const uint8_t* mask_res, double* psf_out,
+                      double* psf_sum_out, double* fit_out, int on_device) {
+    if (!c) return fail(MPSFR_E_INVALID, "ctx is NULL");
+    if (ntask < 1 || !seeing || !gl || !l0 || !h || !lbda_nm)
+        return fail(MPSFR_E_INVALID, "ntask < 1 or NULL input array");
+    if (nl < 1 || nl > 4096) return fail(MPSFR_E_INVALID, "nl=%d out of range", nl);
+    if (npsflin < 1 || npsflin > 5) return fail(MPSFR_E_INVALID, "npsflin=%d out of range 1..5", npsflin);
+    if ((mask_rec == nullptr) != (mask_res == nullptr))
+        return fail(MPSFR_E_INVALID, "mask_rec and mask_res must both be given or both be NULL");
+    const int N = c->N, H1 = N / 2 + 1, ndir = npsflin * npsflin;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int rc;
+
+    // ---- per-wavelength scalars (psfrec.py:662-665, 717)
+    std::vector<LamPar> lp(nl);
+    std::vector<double> gam, alp;
+    for (int l = 0; l < nl; ++l) {
+        if (!(lbda_nm[l] > 0.0)) return fail(MPSFR_E_INVALID, "lbda[%d] must be > 0", l);
+        const double k = 2.0 * M_PI / lbda_nm[l];
+        lp[l].c = -0.5 * k * k;
+        lp[l].npixc = npix_crop(lbda_nm[l], c->dimpsf, c->pixscale);
+        lp[l].pad = 0;
+        if (lp[l].npixc > N || lp[l].npixc < NS)
+            return fail(MPSFR_E_GRID,
+                        "lbda=%.3f nm needs a %d-pixel crop, outside [%d, dim=%d] "
+                        "(psfrec.py:663-683)", lbda_nm[l], lp[l].npixc, NS, N);
+    }
+    // ---- per-task scalars (psfrec.py:57-58, 108, 183-187) and Moffat kernel parameters
+    std::vector<TaskPar> tp(ntask);
+    gam.resize((size_t)ntask + nl);
+    alp.resize((size_t)ntask + nl);
+    for (int t = 0; t < ntask; ++t) {
+        if (!(seeing[t] > 0.0) || !(l0[t] > 0.0) || !(gl[t] >= 0.0) || !(gl[t] <= 1.0))
+            return fail(MPSFR_E_INVALID, "task %d: need seeing > 0, L0 > 0, 0 <= GL <= 1", t);
+        const double r0 = 0.976 * 0.5 / seeing[t] / 4.85;
+        double c0 = gl[t], c1 = 1.0 - gl[t];
+        const double cs = c0 + c1;
+        c0 /= cs;
+        c1 /= cs;
+        tp[t].r0m53 = std::pow(r0, -5.0 / 3.0);
+        tp[t].inv_l0sq = (1.0 / l0[t]) * (1.0 / l0[t]);
+        tp[t].cn2_0 = c0;
+        tp[t].cn2_1 = c1;
+        tp[t].geom = (three_lgs && three_lgs[t]) ? 1 : 0;
+        tp[t].pad = 0;
+        gam[t] = tiptilt_alpha(seeing[t], gl[t], l0[t], c->pixscale);
+        alp[t] = 2.0;                                    // beta_tt, psfrec.py:879
+    }
+    for (int l = 0; l < nl; ++l) muse_kernel_params(lbda_nm[l], c->pixscale, &gam[ntask + l], &alp[ntask + l]);
+
+    // ---- geometry of the AO tables (psfrec.py:61, 66, 86-93, 99, 154-158, 536-537, 594)
+    AoGeom g;
+    memset(&g, 0, sizeof g);
+    g.h[0] = h[0];
+    g.h[1] = h[1];
+    const double arg_v[2] = {0.628163, -0.326497};
+    for (int l = 0; l < 2; ++l) {
+        g.wind[0][l] = wind_speed * std::cos(arg_v[l]);
+        g.wind[1][l] = wind_speed * std::sin(arg_v[l]);
+    }
+    const double pos4[4][2] = {{1, 1}, {-1, -1}, {-1, 1}, {1, -1}};
+    g.nlgs[0] = 4;
+    g.nlgs[1] = 3;
+    for (int ge = 0; ge < 2; ++ge)
+        for (int q = 0; q < g.nlgs[ge]; ++q) {
+            g.poslgs[ge][0][q] = pos4[q][0] * 63.0 / 60;
+            g.poslgs[ge][1][q] = pos4[q][1] * 63.0 / 60;
+        }
+    g.ndir = ndir;
+    for (int d = 0; d < ndir; ++d) {
+        g.dir[0][d] = (double)(d / npsflin - npsflin / 2) * 60 / 2 / 60;
+        g.dir[1][d] = (double)(d % npsflin - npsflin / 2) * 60 / 2 / 60;
+    }
+
+    // ---- uploads (small) + per-call tables
+    if ((rc = ensure(c, c->lp, nl * sizeof(LamPar)))) return rc;
+    if ((rc = ensure(c, c->tp, ntask * sizeof(TaskPar)))) return rc;
+    if ((rc = ensure(c, c->gam, gam.size() * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->alp, alp.size() * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->aotab, (size_t)2 * ndir * 3 * NAO * NAO * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->samp_p, (size_t)nl * NS * sizeof(int)))) return rc;
+    if ((rc = ensure(c, c->samp_a, (size_t)nl * NS * rsize(c)))) return rc;
+    if ((rc = ensure(c, c->G, (size_t)nl * H1 * NS * 2 * rsize(c)))) return rc;
+    if ((rc = ensure(c, c->ktt, (size_t)ntask * KS * KS * rsize(c)))) return rc;
+    if ((rc = ensure(c, c->kmuse, (size_t)nl * KS * KS * rsize(c)))) return rc;
+    HIPCHK(hipMemcpyAsync(c->lp.p, lp.data(), nl * sizeof(LamPar), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->tp.p, tp.data(), ntask * sizeof(TaskPar), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->gam.p, gam.data(), gam.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->alp.p, alp.data(), alp.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    const uint8_t* d_mrec = nullptr;
+    const uint8_t* d_mres = nullptr;
+    if (mask_rec) {
+        if ((rc = ensure(c, c->mask_rec, NAO * NAO))) return rc;
+        if ((rc = ensure(c, c->mask_res, NAO * NAO))) return rc;
+        HIPCHK(hipMemcpyAsync(c->mask_rec.p, mask_rec, NAO * NAO, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->mask_res.p, mask_res, NAO * NAO, hipMemcpyHostToDevice, s));
+        d_mrec = (const uint8_t*)c->mask_rec.p;
+        d_mres = (const uint8_t*)c->mask_res.p;
+    }
+    // the host vectors above must outlive the async copies
+    HIPCHK(hipStreamSynchronize(s));
+    {
+        ProfScope ps(c, K_AO_TABLES);
+        launch_ao_tables(s, g, d_mrec, d_mres, (double*)c->aotab.p);
+    }
+    {
+        ProfScope ps(c, K_GTABLE);
+        launch_gtable(s, N, nl, (const LamPar*)c->lp.p, c->tw64.p, (int*)c->samp_p.p,
+                      c->samp_a.p, c->G.p, c->f64);
+    }
+    {
+        ProfScope ps(c, K_MOFFAT_KERNELS);
+        launch_moffat_kernels(s, ntask, (const double*)c->gam.p, (const double*)c->alp.p,
+                              c->ktt.p, c->f64);
+        launch_moffat_kernels(s, nl, (const double*)c->gam.p + ntask,
+                              (const double*)c->alp.p + ntask, c->kmuse.p, c->f64);
+    }
+
+    // ---- chunk workspaces
+    const int TC = ntask < c->chunk_tasks ? ntask : c->chunk_tasks;
+    const size_t per_stamp = (size_t)NS * NS;
+    if ((rc = ensure(c, c->C, (size_t)TC * ndir * N * H1 * 2 * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->s00, (size_t)TC * ndir * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->D0t, (size_t)TC * ndir * H1 * N * rsize(c)))) return rc;
+    if ((rc = ensure(c, c->Tq, (size_t)TC * nl * H1 * NS * 2 * rsize(c)))) return rc;
+    if ((rc = ensure(c, c->pre, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->sum, (size_t)nl * per_stamp * sizeof(double)))) return rc;
+    const bool dev_out = on_device != 0;
+    double* d_fin_all = nullptr;   // [ntask][nl][1600] if the caller gave a device buffer
+    double* d_fit_all = nullptr;
+    if (dev_out && psf_out) d_fin_all = psf_out;
+    if ((rc = ensure(c, c->fin, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
+    if (dev_out && fit_out) {
+        d_fit_all = fit_out;
+    } else {
+        if ((rc = ensure(c, c->fit, (size_t)ntask * nl * NFIT * sizeof(double)))) return rc;
+        d_fit_all = (double*)c->fit.p;
+    }
+    const double cfit = (std::tgamma(11.0 / 6.0) * std::tgamma(11.0 / 6.0) /
+                         (2.0 * std::pow(M_PI, 11.0 / 3.0))) *
+                        std::pow(24.0 * std::tgamma(6.0 / 5.0) / 5.0, 5.0 / 6.0);   // psfrec.py:622-623
+    const double k500 = 0.5 * 1000 / (2 * M_PI);                                    // psfrec.py:151
+    const double scale2 = 2.0 * (k500 * k500) / 256.0;       // 2 (.)/L^2, L = 16 m (psfrec.py:710, 718)
+    double* d_sum = (dev_out && psf_sum_out) ? psf_sum_out : (double*)c->sum.p;
+
+    for (int t0 = 0; t0 < ntask; t0 += TC) {
+        const int tc = (ntask - t0) < TC ? (ntask - t0) : TC;
+        const int ntd = tc * ndir;
+        {
+            ProfScope ps(c, K_PSD_ROWFFT);
+            launch_psd_rowfft(s, N, ntd, ndir, (const TaskPar*)c->tp.p + t0,
+                              (const double*)c->aotab.p, cfit, c->C.p, c->tw64.p);
+        }
+        {
+            ProfScope ps(c, K_DC_SUM);
+            launch_dc_sum(s, N, ntd, c->C.p, (double*)c->s00.p);
+        }
+        {
+            ProfScope ps(c, K_COLFFT_DPHI);
+            launch_colfft_dphi(s, N, ntd, c->C.p, (const double*)c->s00.p, scale2, c->D0t.p,
+                               c->f64, c->tw64.p);
+        }
+        {
+            ProfScope ps(c, K_OTF_ROWFFT);
+            launch_otf_rowfft(s, N, tc, ndir, nl, c->D0t.p, c->tel.p, (const LamPar*)c->lp.p,
+                              (const int*)c->samp_p.p, c->samp_a.p, c->Tq.p, c->twR.p, c->f64,
+                              c->fast_exp);
+        }
+        {
+            ProfScope ps(c, K_COLPASS);
+            launch_colpass(s, N, tc, nl, c->Tq.p, c->G.p, (double*)c->pre.p, c->f64);
+        }
+        double* d_fin = d_fin_all ? d_fin_all + (size_t)t0 * nl * per_stamp : (double*)c->fin.p;
+        {
+            ProfScope ps(c, K_CONV);
+            const size_t koff = (size_t)t0 * KS * KS * rsize(c);
+            launch_conv(s, tc, nl, (const double*)c->pre.p, (const char*)c->ktt.p + koff,
+                        c->kmuse.p, d_fin, c->f64);
+        }
+        if (fit_out) {
+            ProfScope ps(c, K_FIT);
+            launch_fit(s, tc * nl, d_fin, d_fit_all + (size_t)t0 * nl * NFIT);
+        }
+        if (psf_sum_out) {
+            ProfScope ps(c, K_STAMP_SUM);
+            launch_stamp_sum(s, tc, nl, d_fin, d_sum, t0 > 0 ? 1 : 0);
+        }
+        HIPCHK(hipGetLastError());
+        if (!dev_out && psf_out) {
+            HIPCHK(hipMemcpyAsync(psf_out + (size_t)t0 * nl * per_stamp, d_fin,
+                                  (size_t)tc * nl * per_stamp * sizeof(double),
+                                  hipMemcpyDeviceToHost, s));
+        }
+        c->last_chunk_tasks = tc;
+    }
+    c->last_ndir = ndir;
+    c->last_nl = nl;
+    if (!dev_out) {
+        if (fit_out)
+            HIPCHK(hipMemcpyAsync(fit_out, d_fit_all, (size_t)ntask * nl * NFIT * sizeof(double),
+                                  hipMemcpyDeviceToHost, s));
+        if (psf_sum_out)
+            HIPCHK(hipMemcpyAsync(psf_sum_out, d_sum, (size_t)nl * per_stamp * sizeof(double),
+                                  hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return MPSFR_OK;
+}
+
+int mpsfr_fit_stamps(mpsfr_ctx* c, int nstamp, const double* stamps, double* fit_out,
+                     int on_device) {
+    if (!c || !stamps || !fit_out || nstamp < 1) return fail(MPSFR_E_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t per = (size_t)NS * NS;
+    if (on_device) {
+        ProfScope ps(c, K_FIT);
+        launch_fit(s, nstamp, stamps, fit_out);
+        HIPCHK(hipGetLastError());
+        return MPSFR_OK;
+    }
+    int rc;
+    if ((rc = ensure(c, c->stage, (size_t)nstamp * (per + NFIT) * sizeof(double)))) return rc;
+    double* d_st = (double*)c->stage.p;
+    double* d_ft = d_st + (size_t)nstamp * per;
+    HIPCHK(hipMemcpyAsync(d_st, stamps, (size_t)nstamp * per * sizeof(double), hipMemcpyHostToDevice, s));
+    {
+        ProfScope ps(c, K_FIT);
+        launch_fit(s, nstamp, d_st, d_ft);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(fit_out, d_ft, (size_t)nstamp * NFIT * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return MPSFR_OK;
+}
+
+long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capacity) {
+    if (!c || !what || !out) return fail(MPSFR_E_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int N = c->N, H1 = N / 2 + 1;
+    size_t n = 0;
+    const void* src = nullptr;
+    bool is_real_r = false;   // stored in the context's R type
+    if (!strcmp(what, "ao_tables")) {
+        n = (size_t)2 * c->last_ndir * 3 * NAO * NAO;
+        src = c->aotab.p;
+    } else if (!strcmp(what, "tel")) {
+        n = (size_t)H1 * N;
+        src = c->tel.p;
+        is_real_r = true;
+    } else if (!strcmp(what, "dphi0")) {
+        n = (size_t)c->last_chunk_tasks * c->last_ndir * H1 * N;
+        src = c->D0t.p;
+        is_real_r = true;
+    } else if (!strcmp(what, "pre")) {
+        n = (size_t)c->last_chunk_tasks * c->last_nl * NS * NS;
+        src = c->pre.p;
+    } else {
+        return fail(MPSFR_E_INVALID, "unknown buffer '%s'", what);
+    }
+    if (n == 0 || !src) return fail(MPSFR_E_INVALID, "buffer '%s' is empty", what);
+    if (n > capacity) return fail(MPSFR_E_INVALID, "capacity %zu < %zu", capacity, n);
+    if (is_real_r && !c->f64) {
+        std::vector<float> tmp(n);
+        HIPCHK(hipMemcpy(tmp.data(), src, n * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) out[i] = (double)tmp[i];
+    } else {
+        HIPCHK(hipMemcpy(out, src, n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return (long)n;
+}
+
+int mpsfr_profile_count(void) { return K_COUNT; }
+
+const char* mpsfr_profile_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
+
+int mpsfr_profile_get(mpsfr_ctx* c, int id, double* total_ms, long* launches) {
+    if (!c || id < 0 || id >= K_COUNT) return fail(MPSFR_E_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    const int rc = resolve_profile(c);
+    if (rc) return rc;
+    if (total_ms) *total_ms = c->prof_ms[id];
+    if (launches) *launches = c->prof_n[id];
+    return MPSFR_OK;
+}
+
+int mpsfr_profile_reset(mpsfr_ctx* c) {
+    if (!c) return fail(MPSFR_E_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    const int rc = resolve_profile(c);
+    if (rc) return rc;
+    for (int i = 0; i < K_COUNT; ++i) {
+        c->prof_ms[i] = 0.0;
+        c->prof_n[i] = 0;
+    }
+    return MPSFR_OK;
+}
+
+}  // extern "C"
