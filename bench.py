@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Benchmark of the PSF-reconstruction hot path (BASELINE.json metric: PSFs/sec, one PSF = one
+(SPARTA row x wavelength) final 40x40 stamp including convolutions and Moffat fit).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload at every N (weak scaling): BASELINE.json configs[1] per GPU -- 100 synthetic SPARTA
+rows x 35 wavelengths (465-930 nm) on a 512^2 grid, pixscale 0.2*512/1344,
+npsflin=1.  One step = one pass of the hot path over the rank's 100-row batch plus, for N > 1,
+the RCCL all-gather of the fit tables and sum-reduce of the partial mean-PSF numerators.
+Rank 0 prints ONE JSON line.  See DESIGN.md "Measurement" for the roofline definition.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def _cpu_rows(args):
+    """Worker: reference-shaped oracle (4 FFTs per wavelength, fp64) for one row."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import psfr_oracle as O
+    lb, s, g, l, dim, ps, masks_exact = args
+    tabs = O.ao_tables((100, 10000), False, 1, exact_masks=masks_exact)
+    fit, psf = O.compute_psf(lb, s, g, l, 1, (100, 10000), False, dim=dim, pixscale=ps,
+                             tables=tabs)
+    return fit, psf
+
+
+def cpu_baseline(lb, see, gl, l0, dim, ps, nrows, cores):
+    """Time the CPU oracle (kind 'port': NumPy restatement of the reference, one process per
+    core over rows like the reference's joblib fan-out, psfrec.py:1082-1083) on `nrows` rows."""
+    import multiprocessing as mp
+    jobs = [(lb, see[i], gl[i], l0[i], dim, ps, True) for i in range(nrows)]
+    ctx = mp.get_context('fork')
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_rows, jobs[:min(cores, len(jobs))][:1])      # warm imports
+        t = time.time()
+        res = pool.map(_cpu_rows, jobs, chunksize=1)
+        dt = time.time() - t
+    fits = np.array([r[0] for r in res])
+    return dict(value=nrows * lb.size / dt, seconds=dt), fits
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--rows', type=int, default=100, help='rows per GPU per step')
+    ap.add_argument('--dim', type=int, default=512)
+    ap.add_argument('--nl', type=int, default=35)
+    ap.add_argument('--npsflin', type=int, default=1)
+    ap.add_argument('--precision', default='mixed', choices=['mixed', 'f64'])
+    ap.add_argument('--chunk', type=int, default=0)
+    ap.add_argument('--fast-exp', type=int, default=0)
+    ap.add_argument('--cpu-rows', type=int, default=-1,
+                    help='rows of the CPU-baseline sample (-1: two per core, 0: skip)')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run' % a.gpus)
+        a.gpus = world
+
+    from muse_psfr_amd import synthetic_rows, grid_pixscale
+    dim, nl, rows = a.dim, a.nl, a.rows
+    ps = grid_pixscale(dim)
+    lb = np.linspace(465.0, 930.0, nl) if dim != 1280 else np.linspace(490.0, 930.0, nl)
+    see, gl, l0 = synthetic_rows(rows * world)
+    sl = slice(rank * rows, (rank + 1) * rows)
+
+    # ---- CPU baseline first (fork pool, before this process touches the GPU)
+    cpu = None
+    cpu_fits = None
+    if rank == 0 and world == 1 and a.cpu_rows != 0 and a.npsflin == 1:
+        cores = os.cpu_count() or 1
+        ncpu = 2 * cores if a.cpu_rows < 0 else a.cpu_rows
+        ncpu = min(ncpu, rows)
+        r, cpu_fits = cpu_baseline(lb, see, gl, l0, dim, ps, ncpu, cores)
+        cpu = dict(value=round(r['value'], 3), unit='PSFs/sec', cores=cores, kind='port',
+                   sample='%d rows x %d lambda on %d^2 (first rows of the GPU workload), '
+                          'oracle/psfr_oracle.py reference-shaped (4 FFTs/lambda, fp64, scipy '
+                          'leastsq fit), one process per core, %.1f s wall' % (
+                              ncpu, nl, dim, r['seconds']))
+
+    import torch
+    import torch.distributed as dist
+    from muse_psfr_amd import Context, NFIT
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    ctx = Context(dim=dim, pixscale=ps, precision=a.precision, device=local)
+    if a.chunk:
+        ctx.set_option('chunk_tasks', a.chunk)
+    ctx.set_option('fast_exp', a.fast_exp)
+
+    fit = torch.zeros((rows, nl, NFIT), dtype=torch.float64, device=dev)
+    psum = torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev)
+    fit_all = torch.zeros((world * rows, nl, NFIT), dtype=torch.float64, device=dev) \
+        if world > 1 else fit
+    three = np.zeros(rows, np.uint8)
+    h = (100, 10000)
+
+    def step():
+        ctx.reconstruct_device(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, None,
+                               None, psum.data_ptr(), fit.data_ptr())
+        ctx.sync()
+        if world > 1:
+            dist.all_gather_into_tensor(fit_all, fit)
+            dist.reduce(psum, dst=0, op=dist.ReduceOp.SUM)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    ctx.set_option('profile', 1)
+    ctx.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    prof = ctx.profile()
+    ctx.set_option('profile', 0)
+
+    if rank == 0:
+        npsf = world * rows * nl * a.steps
+        ndir = a.npsflin ** 2
+        p = 4 if a.precision == 'mixed' else 8
+        # dominant kernel: otf_rowfft.  Algorithmic bytes per (task, dir, lambda) for this kernel:
+        # read D_phi0 (p N^2) + write the half-plane intermediate (p N^2) = 2 p N^2 of the
+        # 3 p N^2 of SURVEY.md 8(d); the third p N^2 (reading it back) belongs to colpass.
+        ms, nlaunch = prof['otf_rowfft']
+        chunk = a.chunk or 32
+        units_per_launch = rows * nl * ndir * a.steps / max(nlaunch, 1)
+        alg_bytes = 2 * p * dim * dim * units_per_launch
+        avg_s = ms / max(nlaunch, 1) * 1e-3
+        achieved = alg_bytes / avg_s / 1e9
+        bytes_per_psf = ndir * dim * dim * (3 * p + (5 * 8 + p) / nl)
+        pipe = (npsf / dt) * bytes_per_psf / 1e9
+        fitg = fit.cpu().numpy()
+        out = {
+            'metric': 'PSFs/sec (row x lambda) on %d^2 grid, %d lambda' % (dim, nl),
+            'value': round(npsf / dt, 1), 'unit': 'PSFs/sec', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64 PSD->structure function, f32 per-lambda OTF/FFT, f64 fit'
+                     if a.precision == 'mixed' else 'f64',
+            'data': 'synthetic',
+            'config': {'workload': '%d synthetic SPARTA rows/GPU x %d lambda (%.0f-%.0f nm), '
+                                   '%d^2 grid, pixscale %.5f, npsflin=%d (BASELINE.json '
+                                   'configs[1])' % (rows, nl, lb[0], lb[-1], dim, ps, a.npsflin),
+                       'rows_per_gpu': rows, 'nl': nl, 'dim': dim, 'npsflin': a.npsflin,
+                       'chunk_tasks': chunk, 'parallelism': 'rows sharded x%d' % world},
+            'roofline': {'bound': 'hbm', 'kernel': 'otf_rowfft',
+                         'achieved': round(achieved, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': round(achieved / 8000.0, 4), 'traffic': None,
+                         'avg_launch_ms': round(avg_s * 1e3, 4), 'launches': nlaunch,
+                         'algorithmic_bytes_per_launch': alg_bytes},
+            'roofline_pipeline': {'bytes_per_psf': bytes_per_psf,
+                                  'achieved_GBps': round(pipe, 1),
+                                  'frac_of_8TBps': round(pipe / 8000.0, 4),
+                                  'frac_of_6.29TBps': round(pipe / 6290.0, 4)},
+            'kernel_ms_per_step': {k: round(v[0] / a.steps, 4) for k, v in prof.items() if v[1]},
+        }
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
+            n = cpu_fits.shape[0]
+            out['parity'] = {
+                'rows_checked': n,
+                'max_abs_err_fwhm_arcsec': float(np.abs(fitg[:n, :, 5] * ps - cpu_fits[:, :, 3]).max()),
+                'max_abs_err_beta': float(np.abs(fitg[:n, :, 4] - cpu_fits[:, :, 4]).max()),
+                'tolerance': 1e-4}
+            out['speedup_vs_cpu_baseline'] = round(out['value'] / cpu['value'], 1)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
