@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/mpsfr.h
+declares (no compute calls -- there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'mpsfr.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(mpsfr_[a-z_]+)\s*\(', src)))
+
+
+def test_library_builds_and_exports_the_header():
+    from muse_psfr_amd._build import build_library
+    from muse_psfr_amd import _lib
+    path = build_library(force=False, verbose=False)
+    assert os.path.exists(path)
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.EXPORTS) == names
+    assert lib.mpsfr_version() == 100
+    assert lib.mpsfr_profile_count() == 12
+    assert lib.mpsfr_profile_name(7) == b'otf_rowfft'
+
+
+def test_header_constants_match_python():
+    from muse_psfr_amd import _lib
+    src = open(os.path.join(ROOT, 'include', 'mpsfr.h')).read()
+    assert int(re.search(r'#define MPSFR_NFIT\s+(\d+)', src).group(1)) == _lib.NFIT
+    assert int(re.search(r'#define MPSFR_DIM_AO\s+(\d+)', src).group(1)) == _lib.DIM_AO
+    assert int(re.search(r'#define MPSFR_E_GRID\s+(-\d+)', src).group(1)) == _lib.E_GRID
+
+
+def test_no_cpu_fallback_in_the_product():
+    """The package must never import the oracle."""
+    pkg = os.path.join(ROOT, 'muse_psfr_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith('.py'):
+                txt = open(os.path.join(dp, f)).read()
+                assert 'psfr_oracle' not in txt and 'import oracle' not in txt, f
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from muse_psfr_amd import Context, MpsfrError
+    with pytest.raises(MpsfrError):
+        Context(dim=128, pixscale=0.019)

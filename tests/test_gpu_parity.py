@@ -1,0 +1,290 @@
+"""GPU: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the same
+inputs, against the golden vectors captured from the real reference, and -- at BASELINE.json's
+full sizes -- through size-independent properties.
+
+Tolerances (relative to the stamp maximum for stamps, absolute for fit parameters):
+  f64 mode   : stamps 1e-9,  fwhm/beta 1e-6
+  mixed mode : stamps 2e-5,  fwhm/beta 1e-4   (north_star: Moffat (fwhm, beta) within 1e-4)
+"""
+import numpy as np
+import pytest
+
+import psfr_oracle as O
+from conftest import H, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {'f64': dict(stamp=1e-9, fit=1e-6), 'mixed': dict(stamp=2e-5, fit=1e-4)}
+
+
+@pytest.fixture(scope='module')
+def api():
+    import muse_psfr_amd
+    return muse_psfr_amd
+
+
+def _oracle_tables(npl, masks=None):
+    if masks is None:
+        return {g: O.ao_tables(H, bool(g), npl, exact_masks=True) for g in (0, 1)}
+    return {g: O.ao_tables(H, bool(g), npl, masks=masks) for g in (0, 1)}
+
+
+@pytest.mark.parametrize('dim,npl', [(128, 1), (256, 3), (512, 1)])
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_every_stage_against_the_oracle(api, dim, npl, prec):
+    ps = api.grid_pixscale(dim)
+    lb = np.array([465.0, 600.0, 930.0])
+    cases = [(1.0, 0.7, 25.0, 0), (1.5, 0.3, 10.0, 1), (0.45, 0.93, 28.5, 0)]
+    see, gl, l0, three = (np.array([c[k] for c in cases]) for k in range(4))
+    ctx = api.Context(dim=dim, pixscale=ps, precision=prec)
+    r = ctx.reconstruct(lb, see, gl, l0, three, H, npsflin=npl)
+    ndir = npl * npl
+    tab = ctx.debug_fetch('ao_tables', (2, ndir, 3, 80, 80))
+    tel = ctx.debug_fetch('tel', (dim // 2 + 1, dim))
+    d0 = ctx.debug_fetch('dphi0', (len(cases), ndir, dim // 2 + 1, dim))
+    pre = ctx.debug_fetch('pre', (len(cases), lb.size, 40, 40))
+    ctx.close()
+    tabs = _oracle_tables(npl)
+    eps = 1e-12 if prec == 'f64' else 2e-7
+    for g in (0, 1):
+        T, noise = tabs[g]
+        T = T.copy()
+        T[..., 0, 0] = 0                                  # psfrec.py:490
+        ot = np.stack([np.swapaxes(T[0], -1, -2), np.swapaxes(T[1], -1, -2),
+                       np.swapaxes(noise, -1, -2)], axis=1)
+        assert rel_err(tab[g], ot) < 1e-12
+    otel = O.telescope_otf(dim) * dim * dim
+    assert rel_err(tel, otel[:, :dim // 2 + 1].T) < eps
+    for k, (s, g_, l, th) in enumerate(cases):
+        psd = O.residual_psd([g_, 1 - g_], H, s, l, npl, dim, bool(th), tables=tabs[th])
+        od0 = np.array([O.structure_function0(p) for p in psd])
+        assert rel_err(d0[k], np.swapaxes(od0, -1, -2)[:, :dim // 2 + 1, :]) < eps
+        opre = O.psf_stamps_refshaped(psd, lb, 40, ps)
+        assert rel_err(pre[k], opre) < TOL[prec]['stamp']
+        ofin = O.convolve_final_psf(lb, s, g_, l, opre, ps)
+        assert rel_err(r['psf'][k], ofin) < TOL[prec]['stamp']
+        if dim == 512:           # smaller grids: the stamp is narrower than the PSF, fit ill-posed
+            ofit = O.fit_psf_cube(ofin, ps)
+            assert np.abs(r['fit'][k][:, 5] * ps - ofit[:, 3]).max() < TOL[prec]['fit']
+            assert np.abs(r['fit'][k][:, 4] - ofit[:, 4]).max() < TOL[prec]['fit']
+            assert np.abs(r['fit'][k][:, 1:3] - ofit[:, 1:3]).max() < 1e-4
+            assert np.all(r['fit'][k][:, 14] == 0)
+    np.testing.assert_allclose(r['psf_sum'], r['psf'].sum(axis=0), rtol=1e-13)
+
+
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_native_grid_against_reference_goldens(api, golden, ref_masks, prec):
+    """N = 1280, pixscale 0.2: the configuration compute_psf hard-codes (psfrec.py:954-955)."""
+    g = golden('g2_native1280')
+    lb = g['lbda']
+    ctx = api.Context(dim=1280, pixscale=0.2, precision=prec)
+    for npl in (1, 3):
+        runs = [k for k in range(len(g['meta'])) if int(g['meta'][k][3]) == npl]
+        meta = g['meta'][runs]
+        r = ctx.reconstruct(lb, meta[:, 0], meta[:, 1], meta[:, 2], meta[:, 4].astype(np.uint8), H,
+                            npsflin=npl, masks=ref_masks)
+        pre = ctx.debug_fetch('pre', (len(runs), lb.size, 40, 40))
+        for i, k in enumerate(runs):
+            assert rel_err(pre[i], g['pre_%d' % k]) < TOL[prec]['stamp']
+            assert rel_err(r['psf'][i], g['fin_%d' % k]) < TOL[prec]['stamp']
+            fit = g['fit_%d' % k]
+            assert np.abs(r['fit'][i][:, 5] * 0.2 - fit[:, 3]).max() < TOL[prec]['fit']
+            assert np.abs(r['fit'][i][:, 4] - fit[:, 4]).max() < TOL[prec]['fit']
+            assert np.abs(r['fit'][i][:, 0] / fit[:, 0] - 1).max() < TOL[prec]['fit']
+    ctx.close()
+
+
+def test_reference_known_answers_through_the_gpu(api, ref_masks):
+    """test_psfrec.py:121-127 (the reference's CLI table) reproduced by the HIP path."""
+    ctx = api.Context(dim=1280, pixscale=0.2, precision='mixed')
+    r = ctx.reconstruct(np.array([500.0, 700.0, 900.0]), [1.0], [0.7], [25.0], [0], H,
+                        masks=ref_masks)
+    ctx.close()
+    f = r['fit'][0]
+    assert ['%.2f' % v for v in f[:, 5] * 0.2] == ['0.85', '0.73', '0.62']
+    assert ['%.2f' % v for v in f[:, 4]] == ['2.73', '2.55', '2.23']
+    np.testing.assert_allclose(f[:, 1:3], 20, atol=1e-3)
+
+
+@pytest.mark.parametrize('dim', [512, 1024])
+def test_patched_grid_goldens(api, golden, ref_masks, dim):
+    g = golden('g6_grids')
+    lb = g['n%d_lbda' % dim]
+    ps = api.grid_pixscale(dim)
+    ctx = api.Context(dim=dim, pixscale=ps, precision='mixed')
+    k = 0
+    while 'n%d_r%d_in' % (dim, k) in g:
+        s, gl, l0, npl, three, ps_g = g['n%d_r%d_in' % (dim, k)]
+        assert abs(ps_g - ps) < 1e-15
+        r = ctx.reconstruct(lb, [s], [gl], [l0], [int(three)], H, npsflin=int(npl), masks=ref_masks)
+        assert rel_err(r['psf'][0], g['n%d_r%d_fin' % (dim, k)]) < TOL['mixed']['stamp']
+        fit = g['n%d_r%d_fit' % (dim, k)]
+        assert np.abs(r['fit'][0][:, 5] * ps - fit[:, 3]).max() < 1e-4
+        assert np.abs(r['fit'][0][:, 4] - fit[:, 4]).max() < 1e-4
+        k += 1
+    assert k >= 2
+    ctx.close()
+
+
+def test_sparta_table_goldens(api, golden, ref_masks):
+    """G5: 18 tasks (two in 3-LGS mode) x 35 wavelengths on the native grid: FIT_ROWS, PSF_MEAN,
+    FIT_MEAN semantics of compute_psf_from_sparta (psfrec.py:1086-1113)."""
+    g = golden('g5_sparta18')
+    ctx = api.Context(dim=1280, pixscale=0.2, precision='mixed')
+    ctx.set_option('chunk_tasks', 7)                     # ragged chunks: 7 + 7 + 4
+    r = ctx.reconstruct(g['lbda'], g['seeing'], g['gl'], g['l0'], g['three'].astype(np.uint8), H,
+                        masks=ref_masks)
+    assert np.abs(r['fit'][:, :, 5] * 0.2 - g['fit_rows'][:, :, 3]).max() < 1e-4
+    assert np.abs(r['fit'][:, :, 4] - g['fit_rows'][:, :, 4]).max() < 1e-4
+    mean = r['psf_sum'] / 18
+    assert rel_err(mean, g['psf_mean']) < 1e-5
+    fm = ctx.fit_stamps(mean)
+    assert np.abs(fm[:, 5] * 0.2 - g['fit_mean'][:, 3]).max() < 1e-4
+    assert np.abs(fm[:, 4] - g['fit_mean'][:, 4]).max() < 1e-4
+    assert rel_err(r['psf'][0], g['fin_row0']) < 2e-5
+    assert rel_err(r['psf'][17], g['fin_row17']) < 2e-5
+    ctx.close()
+
+
+def test_fit_kernel_against_minpack_on_golden_stamps(api, golden):
+    """The LM kernel alone: reference-produced stamps in, scipy.optimize.leastsq answers out."""
+    g = golden('g2_native1280')
+    ctx = api.Context(dim=128, pixscale=0.2, precision='f64')
+    for k in range(len(g['meta'])):
+        f = ctx.fit_stamps(g['fin_%d' % k])
+        want = g['fit_%d' % k]
+        np.testing.assert_allclose(f[:, 0], want[:, 0], rtol=1e-7)
+        np.testing.assert_allclose(f[:, 1:3], want[:, 1:3], atol=1e-6)
+        np.testing.assert_allclose(f[:, 5] * 0.2, want[:, 3], atol=1e-7)
+        np.testing.assert_allclose(f[:, 4], want[:, 4], atol=1e-6)
+        assert np.all(f[:, 14] == 0)
+    ctx.close()
+
+
+def test_chunking_and_repeat_are_bitwise_invariant(api):
+    see, gl, l0 = api.synthetic_rows(9)
+    lb = np.linspace(465, 930, 5)
+    ps = api.grid_pixscale(256)
+    ctx = api.Context(dim=256, pixscale=ps, precision='mixed')
+    three = np.array([0, 1, 0, 0, 1, 0, 0, 0, 1], np.uint8)
+    a = ctx.reconstruct(lb, see, gl, l0, three, H)
+    b = ctx.reconstruct(lb, see, gl, l0, three, H)
+    ctx.set_option('chunk_tasks', 2)
+    c = ctx.reconstruct(lb, see, gl, l0, three, H)
+    ctx.close()
+    assert np.array_equal(a['psf'], b['psf']) and np.array_equal(a['fit'], b['fit'])
+    assert np.array_equal(a['psf'], c['psf']) and np.array_equal(a['fit'], c['fit'])
+    np.testing.assert_allclose(a['psf_sum'], c['psf_sum'], rtol=1e-14)
+    # row order equivariance
+    perm = np.array([3, 0, 8, 1, 7, 2, 6, 4, 5])
+    ctx = api.Context(dim=256, pixscale=ps, precision='mixed')
+    d = ctx.reconstruct(lb, see[perm], gl[perm], l0[perm], three[perm], H)
+    ctx.close()
+    assert np.array_equal(d['psf'], a['psf'][perm])
+
+
+def test_edge_cases_and_errors(api):
+    from muse_psfr_amd import MpsfrError
+    ps = api.grid_pixscale(128)
+    ctx = api.Context(dim=128, pixscale=ps, precision='mixed')
+    r = ctx.reconstruct([700.0], [1.0], [0.7], [25.0], [0], H)           # 1 task, 1 wavelength
+    assert r['psf'].shape == (1, 1, 40, 40) and np.isfinite(r['psf']).all()
+    r2 = ctx.reconstruct([700.0], [1.0], [0.7], [25.0], [0], H, want_psf=False, want_fit=False)
+    assert r2['psf'] is None and r2['fit'] is None
+    np.testing.assert_array_equal(r2['psf_sum'][0], r['psf'][0, 0])
+    with pytest.raises(MpsfrError) as e:                                 # psfrec.py:663-683
+        ctx.reconstruct([300.0], [1.0], [0.7], [25.0], [0], H)
+    assert e.value.code == -3
+    with pytest.raises(MpsfrError):
+        ctx.reconstruct([700.0], [-1.0], [0.7], [25.0], [0], H)
+    with pytest.raises(MpsfrError):
+        ctx.reconstruct([700.0], [1.0], [0.7], [25.0], [0], H, npsflin=9)
+    ctx.close()
+    with pytest.raises(MpsfrError):
+        api.Context(dim=500, pixscale=0.2)
+    with pytest.raises(MpsfrError):
+        api.Context(dim=512, pixscale=0.2, dimpsf=64)
+    # reference grid with the reference's pixel scale: 465 nm does not fit (npixc = 1336 > 1280)
+    ctx = api.Context(dim=1280, pixscale=0.2)
+    with pytest.raises(MpsfrError) as e:
+        ctx.reconstruct([465.0], [1.0], [0.7], [25.0], [0], H)
+    assert e.value.code == -3
+    ctx.close()
+
+
+def test_float_altitudes_use_wind_12p5(api):
+    """psfrec.py:61: np.full_like(h, 12.5) truncates to 12 only for integer altitudes."""
+    ps = api.grid_pixscale(256)
+    lb = np.array([500.0, 900.0])
+    ctx = api.Context(dim=256, pixscale=ps, precision='f64')
+    r = ctx.reconstruct(lb, [1.0], [0.7], [25.0], [0], (100.0, 10000.0))
+    ctx.close()
+    tabs = O.ao_tables((100.0, 10000.0), False, 1, exact_masks=True)
+    _, fin = O.compute_psf(lb, 1.0, 0.7, 25.0, 1, (100.0, 10000.0), False, dim=256, pixscale=ps,
+                           tables=tabs, fit=False)
+    assert rel_err(r['psf'][0], fin) < 1e-9
+    tabs12 = O.ao_tables((100, 10000), False, 1, exact_masks=True)
+    _, fin12 = O.compute_psf(lb, 1.0, 0.7, 25.0, 1, (100, 10000), False, dim=256, pixscale=ps,
+                             tables=tabs12, fit=False)
+    assert rel_err(fin12, fin) > 1e-7        # the two wind speeds are distinguishable
+
+
+def test_device_pointer_path_matches_host_path(api):
+    import torch
+    from muse_psfr_amd import NFIT
+    see, gl, l0 = api.synthetic_rows(5)
+    lb = np.linspace(465, 930, 4)
+    ps = api.grid_pixscale(256)
+    ctx = api.Context(dim=256, pixscale=ps, precision='mixed')
+    a = ctx.reconstruct(lb, see, gl, l0, np.zeros(5, np.uint8), H)
+    dev = torch.device('cuda', 0)
+    psf = torch.zeros((5, 4, 40, 40), dtype=torch.float64, device=dev)
+    psum = torch.zeros((4, 40, 40), dtype=torch.float64, device=dev)
+    fit = torch.zeros((5, 4, NFIT), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    ctx.reconstruct_device(lb, see, gl, l0, np.zeros(5, np.uint8), H, 12.0, 1, None,
+                           psf.data_ptr(), psum.data_ptr(), fit.data_ptr())
+    ctx.sync()
+    assert np.array_equal(psf.cpu().numpy(), a['psf'])
+    assert np.array_equal(fit.cpu().numpy(), a['fit'])
+    assert np.array_equal(psum.cpu().numpy(), a['psf_sum'])
+    ctx.close()
+
+
+def test_full_size_properties(api):
+    """BASELINE.json configs[1]: 100 rows x 35 wavelengths on 512^2 -- too large for the oracle
+    in a unit test, so size-independent properties are checked instead."""
+    see, gl, l0 = api.synthetic_rows(100)
+    lb = np.linspace(465, 930, 35)
+    ps = api.grid_pixscale(512)
+    ctx = api.Context(dim=512, pixscale=ps, precision='mixed')
+    r = ctx.reconstruct(lb, see, gl, l0, np.zeros(100, np.uint8), H)
+    psf, fit = r['psf'], r['fit']
+    assert np.isfinite(psf).all() and np.isfinite(fit).all()
+    # checksum of checksums: the deterministic chunked reduction equals the sum of the stamps
+    np.testing.assert_allclose(r['psf_sum'], psf.sum(axis=0), rtol=1e-13)
+    # zero-padded 'same' convolutions lose a little flux and never gain any (psfrec.py:917, 928)
+    flux = psf.sum(axis=(2, 3))
+    assert np.all(flux < 1.0) and np.all(flux > 0.9)
+    assert np.all(psf >= 0)
+    # the peak sits on the stamp centre (test_psfrec.py:28 'center == 20')
+    am = psf.reshape(100, 35, -1).argmax(axis=2)
+    assert np.all(am == 20 * 40 + 20)
+    assert np.abs(fit[:, :, 1:3] - 20).max() < 1e-2
+    assert np.all(fit[:, :, 14] == 0)
+    # FWHM decreases with wavelength for every row; worse seeing gives a wider PSF
+    assert np.all(np.diff(fit[:, :, 5], axis=1) < 0)
+    order = np.argsort(see)
+    assert fit[order[-1], 0, 5] > fit[order[0], 0, 5]
+    # idempotence of the fit: refitting the returned stamps reproduces the fit table
+    f2 = ctx.fit_stamps(psf[:3].reshape(-1, 40, 40))
+    np.testing.assert_array_equal(f2, fit[:3].reshape(-1, fit.shape[-1]))
+    # the oracle on a sample of rows at full size
+    for k in (0, 57):
+        tabs = O.ao_tables(H, False, 1, exact_masks=True)
+        ofit, ofin = O.compute_psf(lb[[0, 17, 34]], see[k], gl[k], l0[k], 1, H, False, dim=512,
+                                   pixscale=ps, tables=tabs)
+        assert rel_err(psf[k][[0, 17, 34]], ofin) < 2e-5
+        assert np.abs(fit[k][[0, 17, 34], 5] * ps - ofit[:, 3]).max() < 1e-4
+        assert np.abs(fit[k][[0, 17, 34], 4] - ofit[:, 4]).max() < 1e-4
+    ctx.close()
