@@ -22,6 +22,23 @@ class MpsfrError(RuntimeError):
         self.code = code
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as
+    /opt/rocm's).  If libmpsfr.so pulled in the system runtime first and torch were imported
+    later, the process would hold two runtimes and the second finds no GPU.  So when torch is
+    installed, its runtime is loaded first (without importing torch) and libmpsfr binds to it."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load libmpsfr.so (built by muse_psfr_amd._build / __graft_entry__.build)."""
     global _lib
@@ -30,6 +47,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError('%s not found: build it with `python -m muse_psfr_amd._build` '
                           '(hipcc, gfx950); there is no CPU fallback' % LIB_PATH)
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     p = C.c_void_p
     dp = C.POINTER(C.c_double)
