@@ -151,7 +151,7 @@ def main():
         # read D_phi0 (p N^2) + write the half-plane intermediate (p N^2) = 2 p N^2 of the
         # 3 p N^2 of SURVEY.md 8(d); the third p N^2 (reading it back) belongs to colpass.
         ms, nlaunch = prof['otf_rowfft']
-        chunk = a.chunk or 32
+        chunk = a.chunk or 'auto'
         units_per_launch = rows * nl * ndir * a.steps / max(nlaunch, 1)
         alg_bytes = 2 * p * dim * dim * units_per_launch
         avg_s = ms / max(nlaunch, 1) * 1e-3

@@ -57,7 +57,7 @@ int mpsfr_create(mpsfr_ctx** out, int device_id, int dim, int dimpsf, double pix
 void mpsfr_destroy(mpsfr_ctx* ctx);
 const char* mpsfr_last_error(void);
 
-/* Tunables: "chunk_tasks" (tasks per pipeline pass), "fast_exp" (0/1, mixed mode only),
+/* Tunables: "chunk_tasks" (tasks per pipeline pass, 0 = automatic), "fast_exp" (0/1, mixed mode only),
  * "profile" (0/1: bracket every kernel launch with HIP events on the context's stream). */
 int mpsfr_set_option(mpsfr_ctx* ctx, const char* key, double value);
 

@@ -357,63 +357,94 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
 
 // ------------------------------------------------------------------------------------------
 // K_COLPASS: second (column) pass restricted to the sampled positions,
-// stamp[i][j] = sum_v Re(G[l][v][j] * Tq[v][i]) -- with A = conj-FFT convention of K_OTF_ROWFFT
-// this is cos*Ar + sin*Ai -- then clamp >= 0 (psfrec.py:680) and normalise to sum 1 (:685).
+// stamp[i][j] = sum_v Re(G[l][v][j] * conj(A[v][i])) = sum_v (Gx Ax + Gy Ay), a real
+// (40 x 2(N/2+1)) x (2(N/2+1) x 40) product per stamp, then clamp >= 0 (psfrec.py:680) and
+// normalise to sum 1 (:685).  One workgroup per stamp; every lane holds a 5x5 register tile and
+// the four waves split the v range (32 lines staged in LDS per step, 8 per wave), the partial
+// tiles being summed through LDS at the end.
 // ------------------------------------------------------------------------------------------
 template <typename R, int N>
 __global__ void __launch_bounds__(256)
 k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
           double* __restrict__ pre) {
-    constexpr int VB = 16;
-    constexpr int NO = (NS * NS + 255) / 256;
-    __shared__ cx<R> sT[VB][NS];
-    __shared__ cx<R> sG[VB][NS];
+    constexpr int VW = 8, VB = 4 * VW, TL = 5, NV = N / 2 + 1;
+    constexpr int NE = VB * NS / 256;    // staged elements per thread and array (5)
+    // one raw buffer: staging [2][VB][NS] complex during the loop, then [4][NS*NS] partial tiles
+    static_assert(4 * NS * NS * sizeof(R) >= 2 * VB * NS * sizeof(cx<R>), "overlay");
+    __shared__ __align__(16) unsigned char raw[4 * NS * NS * sizeof(R)];
+    cx<R>(*sT)[NS] = reinterpret_cast<cx<R>(*)[NS]>(raw);
+    cx<R>(*sG)[NS] = reinterpret_cast<cx<R>(*)[NS]>(raw + VB * NS * sizeof(cx<R>));
     __shared__ double part[4];
     __shared__ double tot;
     const int l = blockIdx.x, task = blockIdx.y;
-    const cx<R>* Tp = Tq + ((size_t)task * nl + l) * (N / 2 + 1) * NS;
-    const cx<R>* Gp = G + (size_t)l * (N / 2 + 1) * NS;
-    R acc[NO];
-    int oi[NO], oj[NO];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i0 = TL * (lane >> 3), j0 = TL * (lane & 7);
+    const cx<R>* Tp = Tq + ((size_t)task * nl + l) * NV * NS;
+    const cx<R>* Gp = G + (size_t)l * NV * NS;
+    R acc[TL][TL];
 #pragma unroll
-    for (int m = 0; m < NO; ++m) {
-        const int o = threadIdx.x + m * 256;
-        acc[m] = (R)0;
-        oi[m] = (o < NS * NS) ? o / NS : 0;
-        oj[m] = (o < NS * NS) ? o % NS : 0;
-    }
-    for (int v0 = 0; v0 <= N / 2; v0 += VB) {
-        const int nv = (N / 2 + 1 - v0) < VB ? (N / 2 + 1 - v0) : VB;
-        for (int e = threadIdx.x; e < VB * NS; e += 256) {
-            const int vb = e / NS;
-            cx<R> tv = {(R)0, (R)0}, gv = {(R)0, (R)0};
-            if (vb < nv) {
-                tv = Tp[(size_t)v0 * NS + e];
-                gv = Gp[(size_t)v0 * NS + e];
-            }
-            (&sT[0][0])[e] = tv;
-            (&sG[0][0])[e] = gv;
+    for (int a = 0; a < TL; ++a)
+#pragma unroll
+        for (int b = 0; b < TL; ++b) acc[a][b] = (R)0;
+    cx<R> rt[NE], rg[NE];
+    auto fetch = [&](int v0) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = threadIdx.x + k * 256;
+            const bool in = v0 * NS + e < NV * NS;
+            rt[k] = in ? Tp[(size_t)v0 * NS + e] : cx<R>{(R)0, (R)0};
+            rg[k] = in ? Gp[(size_t)v0 * NS + e] : cx<R>{(R)0, (R)0};
+        }
+    };
+    fetch(0);
+    for (int v0 = 0; v0 < NV; v0 += VB) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            (&sT[0][0])[threadIdx.x + k * 256] = rt[k];
+            (&sG[0][0])[threadIdx.x + k * 256] = rg[k];
         }
         __syncthreads();
+        if (v0 + VB < NV) fetch(v0 + VB);      // prefetch the next block behind the FMAs
 #pragma unroll
-        for (int vb = 0; vb < VB; ++vb) {
+        for (int vb = 0; vb < VW; ++vb) {
+            const int vr = wave * VW + vb;
+            cx<R> t[TL], g[TL];
 #pragma unroll
-            for (int m = 0; m < NO; ++m) {
-                const cx<R> tv = sT[vb][oi[m]], gv = sG[vb][oj[m]];
-                acc[m] += gv.x * tv.x + gv.y * tv.y;   // Re(G conj(A))
+            for (int k = 0; k < TL; ++k) {
+                t[k] = sT[vr][i0 + k];
+                g[k] = sG[vr][j0 + k];
             }
+#pragma unroll
+            for (int a = 0; a < TL; ++a)
+#pragma unroll
+                for (int b = 0; b < TL; ++b) acc[a][b] += g[b].x * t[a].x + g[b].y * t[a].y;
         }
         __syncthreads();
     }
+    // sum the four partial tiles
+    R* red = reinterpret_cast<R*>(raw);
+    R* dst = red + wave * NS * NS;
+#pragma unroll
+    for (int a = 0; a < TL; ++a)
+#pragma unroll
+        for (int b = 0; b < TL; ++b) dst[(i0 + a) * NS + j0 + b] = acc[a][b];
+    __syncthreads();
+    constexpr int NO = (NS * NS + 255) / 256;
+    R val[NO];
     double s = 0.0;
 #pragma unroll
     for (int m = 0; m < NO; ++m) {
         const int o = threadIdx.x + m * 256;
-        if (acc[m] < (R)0) acc[m] = (R)0;
-        if (o < NS * NS) s += (double)acc[m];
+        R x = (R)0;
+        if (o < NS * NS) {
+            x = (red[o] + red[NS * NS + o]) + (red[2 * NS * NS + o] + red[3 * NS * NS + o]);
+            if (x < (R)0) x = (R)0;
+            s += (double)x;
+        }
+        val[m] = x;
     }
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    if (lane == 0) part[wave] = s;
     __syncthreads();
     if (threadIdx.x == 0) tot = (part[0] + part[1]) + (part[2] + part[3]);
     __syncthreads();
@@ -422,64 +453,98 @@ k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
 #pragma unroll
     for (int m = 0; m < NO; ++m) {
         const int o = threadIdx.x + m * 256;
-        if (o < NS * NS) out[o] = (double)acc[m] * inv;
+        if (o < NS * NS) out[o] = (double)val[m] * inv;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // K_CONV: convolve_final_psf (psfrec.py:874-930): two zero-padded 'same' convolutions with
 // 41x41 Moffat kernels (tip-tilt kernel of the task, instrument kernel of the wavelength).
+// One workgroup per stamp.  The stamp sits at offset 20 inside an 80-row zero frame in LDS, so
+// the tap loops need no bounds checks.  Each thread owns a 1x8 strip of outputs (200 strips,
+// column-block major: consecutive lanes take consecutive rows); the frame pitch of 84 words
+// makes the 16-byte row reads of a wave hit distinct banks.  The kernel is symmetric in its
+// row index (K[a][b] = K[40-a][b]), so image rows i-a and i+a are added first and the tap
+// count halves.  The taps K[a][b] are wave-uniform and arrive through scalar loads, so the
+// inner loop is pure FMA with an SGPR operand.  Each 41-tap row sum is accumulated in R and
+// then added to an fp64 accumulator.
 // ------------------------------------------------------------------------------------------
+template <typename R>
+struct Vec4;
+template <>
+struct Vec4<float> { using type = float4; };
+template <>
+struct Vec4<double> { using type = double4; };
+
 template <typename R>
 __global__ void __launch_bounds__(256)
 k_conv(int nl, const double* __restrict__ pre, const R* __restrict__ ktt,
        const R* __restrict__ kmuse, double* __restrict__ fin) {
-    constexpr int PW = NS + KS - 1;   // 80: image at offset 20 inside a zero frame
-    constexpr int NO = (NS * NS + 255) / 256;
-    extern __shared__ __align__(16) unsigned char smem[];
-    R* img = reinterpret_cast<R*>(smem);   // [PW][PW]
-    R* ker = img + PW * PW;                // [KS*KS]
+    constexpr int PH = NS + KS - 1;   // 80 frame rows
+    constexpr int PW = 84;            // frame pitch (80 used)
+    constexpr int HK = KS / 2;        // 20
+    constexpr int SW = 8;             // strip width
+    constexpr int LW = SW + KS - 1;   // 48 frame columns feed one strip
+    constexpr int NSTRIP = NS * NS / SW;
+    using V4 = typename Vec4<R>::type;
+    extern __shared__ __align__(32) unsigned char smem[];
+    R* img = reinterpret_cast<R*>(smem);   // [PH][PW]
     const int l = blockIdx.x, task = blockIdx.y;
     const double* src = pre + ((size_t)task * nl + l) * NS * NS;
-    for (int e = threadIdx.x; e < PW * PW; e += 256) {
-        const int P = e / PW - KS / 2, Q = e % PW - KS / 2;
+    for (int e = threadIdx.x; e < PH * PW; e += 256) {
+        const int P = e / PW - HK, Q = e % PW - HK;
         img[e] = (P >= 0 && P < NS && Q >= 0 && Q < NS) ? (R)src[P * NS + Q] : (R)0;
     }
-    R acc[NO];
+    const bool active = threadIdx.x < NSTRIP;
+    const int sid = active ? threadIdx.x : 0;
+    const int i = sid % NS, j0 = (sid / NS) * SW;
+    double acc[SW];
     for (int pass = 0; pass < 2; ++pass) {
-        const R* kg = pass == 0 ? ktt + (size_t)task * KS * KS : kmuse + (size_t)l * KS * KS;
-        for (int e = threadIdx.x; e < KS * KS; e += 256) ker[e] = kg[e];
+        const R* __restrict__ kg = pass == 0 ? ktt + (size_t)task * KS * KS
+                                             : kmuse + (size_t)l * KS * KS;
         __syncthreads();
 #pragma unroll
-        for (int m = 0; m < NO; ++m) {
-            const int o = threadIdx.x + m * 256;
-            R s = (R)0;
-            if (o < NS * NS) {
-                const int i = o / NS, j = o % NS;
-                // out[i][j] = sum_{a,b} K[a][b] img[i - (a-20)][j - (b-20)]  (frame offset +20)
-                for (int a = 0; a < KS; ++a) {
-                    const R* irow = img + (i - a + 2 * (KS / 2)) * PW + j + 2 * (KS / 2);
-                    const R* krow = ker + a * KS;
+        for (int o = 0; o < SW; ++o) acc[o] = 0.0;
+        for (int a = 0; a <= HK; ++a) {
+            // frame rows i-a+40 and (a < 20) i+a, columns j0 .. j0+47
+            const V4* r1 = reinterpret_cast<const V4*>(img + (i - a + 2 * HK) * PW + j0);
+            const V4* r2 = reinterpret_cast<const V4*>(img + (i + a) * PW + j0);
+            R sv[LW];
 #pragma unroll
-                    for (int b = 0; b < KS; ++b) s += krow[b] * irow[-b];
+            for (int c = 0; c < LW / 4; ++c) {
+                const V4 q = r1[c];
+                sv[4 * c] = q.x; sv[4 * c + 1] = q.y; sv[4 * c + 2] = q.z; sv[4 * c + 3] = q.w;
+            }
+            if (a < HK) {
+#pragma unroll
+                for (int c = 0; c < LW / 4; ++c) {
+                    const V4 q = r2[c];
+                    sv[4 * c] += q.x; sv[4 * c + 1] += q.y; sv[4 * c + 2] += q.z; sv[4 * c + 3] += q.w;
                 }
             }
-            acc[m] = s;
+            R part[SW];
+#pragma unroll
+            for (int o = 0; o < SW; ++o) part[o] = (R)0;
+            const R* __restrict__ krow = kg + a * KS;
+#pragma unroll
+            for (int b = 0; b < KS; ++b) {
+                const R kv = krow[b];
+#pragma unroll
+                for (int o = 0; o < SW; ++o) part[o] += kv * sv[o - b + 2 * HK];
+            }
+#pragma unroll
+            for (int o = 0; o < SW; ++o) acc[o] += (double)part[o];
         }
         __syncthreads();
-        if (pass == 0) {
+        if (pass == 0 && active) {
 #pragma unroll
-            for (int m = 0; m < NO; ++m) {
-                const int o = threadIdx.x + m * 256;
-                if (o < NS * NS) img[(o / NS + KS / 2) * PW + o % NS + KS / 2] = acc[m];
-            }
+            for (int o = 0; o < SW; ++o) img[(i + HK) * PW + j0 + HK + o] = (R)acc[o];
         }
     }
-    double* out = fin + ((size_t)task * nl + l) * NS * NS;
+    if (active) {
+        double* out = fin + ((size_t)task * nl + l) * NS * NS + i * NS + j0;
 #pragma unroll
-    for (int m = 0; m < NO; ++m) {
-        const int o = threadIdx.x + m * 256;
-        if (o < NS * NS) out[o] = (double)acc[m];
+        for (int o = 0; o < SW; ++o) out[o] = acc[o];
     }
 }
 
@@ -612,12 +677,22 @@ __global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restric
         const int oo = __shfl_xor(besto, o, 64);
         if (ob > best || (ob == best && oo < besto)) { best = ob; besto = oo; }
     }
+    // start values: peak and its position, FWHM from the area above half maximum, n = 2.5.
+    // (The least-squares minimum is unique -- SURVEY.md 8(c) -- so the start only sets the
+    // iteration count; the oracle starts from fwhm = 4 px, n = 2.)
+    int cnt = 0;
+#pragma unroll
+    for (int m = 0; m < NPIX_LANE; ++m) cnt += dpix[m] > 0.5 * best ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    double fw0 = 2.0 * sqrt((double)cnt / kPi);
+    fw0 = fmin(fmax(fw0, 1.5), (double)NS);
     double v[5];
     v[0] = best;
     v[1] = (double)(besto / NS);
     v[2] = (double)(besto % NS);
-    v[4] = 2.0;
-    v[3] = 4.0 / (2.0 * sqrt(sqrt(2.0) - 1.0));   // start fwhm = 4 px at n = 2
+    v[4] = 2.5;
+    v[3] = fw0 / (2.0 * sqrt(exp2(1.0 / 2.5) - 1.0));
     NormEq ne;
     moffat_accumulate(dpix, lane, v, ne, true);
     double mu = 1.0e-3;
@@ -651,7 +726,7 @@ __global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restric
             for (int k = 0; k < 5; ++k) v[k] = vn[k];
             ne = nn;
             mu = fmax(mu * 0.1, 1.0e-14);
-            if (rel < 1.0e-12) { status = 0; break; }
+            if (rel < 1.0e-10) { status = 0; break; }
         } else {
             mu *= 10.0;
             if (mu > 1.0e15) { status = 0; break; }   // no further descent possible: at the minimum
@@ -841,14 +916,13 @@ void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, c
 void launch_conv(hipStream_t s, int ntask, int nl, const double* d_pre, const void* d_ktt,
                  const void* d_kmuse, double* d_fin, bool f64) {
     dim3 grid(nl, ntask);
-    constexpr int PW = NS + KS - 1;
+    constexpr int PH = NS + KS - 1, PW = 84;
     if (f64) {
-        const size_t sm = (size_t)(PW * PW + KS * KS) * sizeof(double);
-        allow_smem(k_conv<double>, sm);
+        const size_t sm = (size_t)(PH * PW) * sizeof(double);
         hipLaunchKernelGGL(k_conv<double>, grid, dim3(256), sm, s, nl, d_pre, (const double*)d_ktt,
                            (const double*)d_kmuse, d_fin);
     } else {
-        const size_t sm = (size_t)(PW * PW + KS * KS) * sizeof(float);
+        const size_t sm = (size_t)(PH * PW) * sizeof(float);
         hipLaunchKernelGGL(k_conv<float>, grid, dim3(256), sm, s, nl, d_pre, (const float*)d_ktt,
                            (const float*)d_kmuse, d_fin);
     }

@@ -60,7 +60,7 @@ struct mpsfr_ctx {
     bool f64 = false;
     hipStream_t stream = nullptr;
     // options
-    int chunk_tasks = 32;
+    int chunk_tasks = 0;   // 0 = automatic
     bool fast_exp = false;
     bool profile = false;
     // constant tables
@@ -314,7 +314,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
 int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
     if (!c || !key) return fail(MPSFR_E_INVALID, "NULL argument");
     if (!strcmp(key, "chunk_tasks")) {
-        if (value < 1 || value > 4096) return fail(MPSFR_E_INVALID, "chunk_tasks out of range");
+        if (value < 0 || value > 4096) return fail(MPSFR_E_INVALID, "chunk_tasks out of range");
         c->chunk_tasks = (int)value;
     } else if (!strcmp(key, "fast_exp")) {
         c->fast_exp = value != 0.0;
@@ -456,7 +456,18 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     }
 
     // ---- chunk workspaces
-    const int TC = ntask < c->chunk_tasks ? ntask : c->chunk_tasks;
+    // tasks per pipeline pass: enough stamps (~4096) to fill 256 CUs with several waves each,
+    // bounded so that the fp64 half-plane workspace C stays under 4 GiB
+    int TC = c->chunk_tasks;
+    if (TC <= 0) {
+        TC = (4096 + nl - 1) / nl;
+        if (TC < 8) TC = 8;
+        if (TC > 256) TC = 256;
+        const double per_task = (double)ndir * N * H1 * 16.0;
+        const int cap = (int)(4.0 * 1024 * 1024 * 1024 / per_task);
+        if (TC > cap) TC = cap < 1 ? 1 : cap;
+    }
+    if (TC > ntask) TC = ntask;
     const size_t per_stamp = (size_t)NS * NS;
     if ((rc = ensure(c, c->C, (size_t)TC * ndir * N * H1 * 2 * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->s00, (size_t)TC * ndir * sizeof(double)))) return rc;
