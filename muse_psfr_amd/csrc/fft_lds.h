@@ -1,9 +1,17 @@
 // LDS-resident Stockham FFTs for gfx950 (wave64), used by every transform on the hot path.
 //
-// One length-N line is transformed by TPR cooperating threads; a 256-thread workgroup carries
-// 256/TPR independent lines ("slots") in lock-step, so the only synchronisation is one
-// workgroup barrier per radix pass.  Radix plans: 128 = 8.4.4, 256 = 8.8.4, 512 = 8.8.8,
-// 1024 = 8.8.4.4, 1280 = 8.8.4.5 (the reference-native grid of psfrec.py:954-955 needs radix 5).
+// One length-N line is transformed by TPR cooperating threads ("slot"); a workgroup carries
+// SLOTS independent lines.  Radix plans: 128 = 8.4.4, 256 = 8.8.4, 512 = 8.8.8, 1024 = 8.8.4.4,
+// 1280 = 4.4.4.4.5 (the reference-native grid of psfrec.py:954-955 needs radix 5).
+//
+// gfx950 specifics:
+//  * LDS images are padded (x -> x + x/8): the autosort writes of a pass have a lane stride of
+//    `radix` elements, which without padding lands 8-16 lanes on one bank
+//    (SQ_LDS_BANK_CONFLICT was 41 % of the LDS cycles of the first version).
+//  * When a slot is at most one wavefront (TPR <= 64) the passes need no s_barrier at all: LDS
+//    operations of one wave execute in order, so a wave-scope fence is enough.
+//  * The pass twiddles of a thread depend only on its butterfly index, so kernels that run many
+//    transforms per thread (one per wavelength) keep them in registers (TwRegs).
 // Forward sign convention: X[k] = sum_n x[n] exp(-2 pi i n k / N).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -88,87 +96,168 @@ __device__ __forceinline__ void dftr(cx<R>* v) {
     if constexpr (RADIX == 5) dft5(v);
 }
 
-// One Stockham autosort pass.  NS = product of the radices of the previous passes.
-// tw[m] = exp(-2 pi i m / N), m in [0, N).
-template <typename R, int N, int RADIX, int NS, int TPR>
+// ---- plan ---------------------------------------------------------------------------------
+template <int N>
+struct Plan;
+template <>
+struct Plan<128> {
+    static constexpr int NP = 3, TPR = 16, SLOTS = 16;
+    static constexpr int radix[5] = {8, 4, 4, 1, 1};
+};
+template <>
+struct Plan<256> {
+    static constexpr int NP = 3, TPR = 32, SLOTS = 8;
+    static constexpr int radix[5] = {8, 8, 4, 1, 1};
+};
+template <>
+struct Plan<512> {
+    static constexpr int NP = 3, TPR = 64, SLOTS = 4;
+    static constexpr int radix[5] = {8, 8, 8, 1, 1};
+};
+template <>
+struct Plan<1024> {
+    static constexpr int NP = 4, TPR = 128, SLOTS = 2;
+    static constexpr int radix[5] = {8, 8, 4, 4, 1};
+};
+template <>
+struct Plan<1280> {
+    static constexpr int NP = 5, TPR = 64, SLOTS = 2;
+    static constexpr int radix[5] = {4, 4, 4, 4, 5};
+};
+
+template <int N>
+struct LineCfg {
+    static constexpr int TPR = Plan<N>::TPR;
+    static constexpr int SLOTS = Plan<N>::SLOTS;
+    static constexpr int THREADS = TPR * SLOTS;
+    static constexpr int NPAD = N + N / 8;          // padded line length in LDS
+    static constexpr bool WSYNC = TPR <= 64;        // a slot never spans two wavefronts
+};
+
+__device__ __forceinline__ int lds_pad(int x) { return x + (x >> 3); }
+
+constexpr int plan_ns(const int* radix, int p) {
+    int ns = 1;
+    for (int i = 0; i < p; ++i) ns *= radix[i];
+    return ns;
+}
+
+// number of twiddle factors one thread needs over all passes after the first
+template <int N>
+constexpr int tw_count() {
+    int n = 0;
+    for (int p = 1; p < Plan<N>::NP; ++p)
+        n += (N / Plan<N>::radix[p] / Plan<N>::TPR) * (Plan<N>::radix[p] - 1);
+    return n;
+}
+
+// Synchronisation between passes: workgroup barrier, or (slot within one wave) a wave-scope fence.
+template <bool WSYNC>
+__device__ __forceinline__ void fft_sync() {
+    if constexpr (WSYNC) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+// Per-thread twiddles of every pass, kept in registers.  twg[m] = exp(-2 pi i m / N) (global).
+template <typename R, int N>
+struct TwRegs {
+    cx<R> w[tw_count<N>() > 0 ? tw_count<N>() : 1];
+    template <typename RT>
+    __device__ __forceinline__ void init(const cx<RT>* __restrict__ twg, int t) {
+        using P = Plan<N>;
+        int o = 0;
+#pragma unroll
+        for (int p = 1; p < P::NP; ++p) {
+            const int RADIX = P::radix[p];
+            const int NS_ = plan_ns(P::radix, p);
+            const int NB = N / RADIX, TS = N / (NS_ * RADIX);
+#pragma unroll
+            for (int b = 0; b < NB / P::TPR; ++b) {
+                const int k = (t + b * P::TPR) % NS_;
+#pragma unroll
+                for (int q = 1; q < RADIX; ++q) {
+                    const cx<RT> v = twg[q * k * TS];
+                    w[o++] = {(R)v.x, (R)v.y};
+                }
+            }
+        }
+    }
+};
+
+// One Stockham autosort pass p of the plan (padded LDS images).  REGTW: `wreg` is the thread's
+// TwRegs array; otherwise it is the table tw[m] = exp(-2 pi i m / N), m in [0, N) (in LDS).
+template <typename R, int N, int P_, bool REGTW>
 __device__ __forceinline__ void fft_pass(const cx<R>* __restrict__ in, cx<R>* __restrict__ out,
-                                         const cx<R>* __restrict__ tw, int t) {
+                                         const cx<R>* __restrict__ wreg, int t) {
+    using P = Plan<N>;
+    constexpr int RADIX = P::radix[P_];
+    constexpr int NS_ = plan_ns(P::radix, P_);
     constexpr int NB = N / RADIX;
-    for (int j = t; j < NB; j += TPR) {
-        const int k = j % NS;
+    static_assert(NB % P::TPR == 0, "plan must give every thread the same number of butterflies");
+    constexpr int WOFF = [] {
+        int n = 0;
+        for (int p = 1; p < P_; ++p) n += (N / P::radix[p] / P::TPR) * (P::radix[p] - 1);
+        return n;
+    }();
+#pragma unroll
+    for (int b = 0; b < NB / P::TPR; ++b) {
+        const int j = t + b * P::TPR;
+        const int k = j % NS_;
         cx<R> v[RADIX];
 #pragma unroll
-        for (int q = 0; q < RADIX; ++q) v[q] = in[j + q * NB];
-        if constexpr (NS > 1) {
-            constexpr int TS = N / (NS * RADIX);
+        for (int q = 0; q < RADIX; ++q) v[q] = in[lds_pad(j + q * NB)];
+        if constexpr (P_ > 0) {
+            if constexpr (REGTW) {
 #pragma unroll
-            for (int q = 1; q < RADIX; ++q) v[q] = cmul(v[q], tw[q * k * TS]);
+                for (int q = 1; q < RADIX; ++q)
+                    v[q] = cmul(v[q], wreg[WOFF + b * (RADIX - 1) + q - 1]);
+            } else {
+                constexpr int TS = N / (NS_ * RADIX);
+#pragma unroll
+                for (int q = 1; q < RADIX; ++q) v[q] = cmul(v[q], wreg[q * k * TS]);
+            }
         }
         dftr<R, RADIX>(v);
         const int base = (j - k) * RADIX + k;
 #pragma unroll
-        for (int q = 0; q < RADIX; ++q) out[base + q * NS] = v[q];
+        for (int q = 0; q < RADIX; ++q) out[lds_pad(base + q * NS_)] = v[q];
     }
 }
 
-// Full forward FFT of one line held in LDS buffer `a` (natural order), scratch `b`.
-// Every thread of the workgroup must call this (it contains workgroup barriers).
-// Returns the buffer that holds the result in natural order.
-template <typename R, int N, int TPR>
+// Full forward FFT of one line held in padded LDS buffer `a` (natural order), scratch `b`.
+// Every thread of the slot (of the workgroup if !WSYNC) must call this.  The caller must have
+// made the input visible (fft_sync) before the call; on return the result is visible to the slot.
+// Returns the buffer that holds the result in natural order (padded: index with lds_pad).
+template <typename R, int N, bool REGTW>
 __device__ __forceinline__ cx<R>* fft_forward(cx<R>* a, cx<R>* b, const cx<R>* tw, int t) {
-    static_assert(N == 128 || N == 256 || N == 512 || N == 1024 || N == 1280, "unsupported N");
-    if constexpr (N == 128) {
-        fft_pass<R, N, 8, 1, TPR>(a, b, tw, t);
-        __syncthreads();
-        fft_pass<R, N, 4, 8, TPR>(b, a, tw, t);
-        __syncthreads();
-        fft_pass<R, N, 4, 32, TPR>(a, b, tw, t);
-        __syncthreads();
-        return b;
-    } else if constexpr (N == 256) {
-        fft_pass<R, N, 8, 1, TPR>(a, b, tw, t);
-        __syncthreads();
-        fft_pass<R, N, 8, 8, TPR>(b, a, tw, t);
-        __syncthreads();
-        fft_pass<R, N, 4, 64, TPR>(a, b, tw, t);
-        __syncthreads();
-        return b;
-    } else if constexpr (N == 512) {
-        fft_pass<R, N, 8, 1, TPR>(a, b, tw, t);
-        __syncthreads();
-        fft_pass<R, N, 8, 8, TPR>(b, a, tw, t);
-        __syncthreads();
-        fft_pass<R, N, 8, 64, TPR>(a, b, tw, t);
-        __syncthreads();
-        return b;
-    } else if constexpr (N == 1024) {
-        fft_pass<R, N, 8, 1, TPR>(a, b, tw, t);
-        __syncthreads();
-        fft_pass<R, N, 8, 8, TPR>(b, a, tw, t);
-        __syncthreads();
-        fft_pass<R, N, 4, 64, TPR>(a, b, tw, t);
-        __syncthreads();
-        fft_pass<R, N, 4, 256, TPR>(b, a, tw, t);
-        __syncthreads();
-        return a;
-    } else {
-        fft_pass<R, N, 8, 1, TPR>(a, b, tw, t);
-        __syncthreads();
-        fft_pass<R, N, 8, 8, TPR>(b, a, tw, t);
-        __syncthreads();
-        fft_pass<R, N, 4, 64, TPR>(a, b, tw, t);
-        __syncthreads();
-        fft_pass<R, N, 5, 256, TPR>(b, a, tw, t);
-        __syncthreads();
-        return a;
+    using P = Plan<N>;
+    constexpr bool WS = LineCfg<N>::WSYNC;
+    fft_pass<R, N, 0, REGTW>(a, b, tw, t);
+    fft_sync<WS>();
+    fft_pass<R, N, 1, REGTW>(b, a, tw, t);
+    fft_sync<WS>();
+    fft_pass<R, N, 2, REGTW>(a, b, tw, t);
+    fft_sync<WS>();
+    if constexpr (P::NP == 3) return b;
+    if constexpr (P::NP >= 4) {
+        fft_pass<R, N, 3, REGTW>(b, a, tw, t);
+        fft_sync<WS>();
+        if constexpr (P::NP == 4) return a;
     }
+    if constexpr (P::NP == 5) {
+        fft_pass<R, N, 4, REGTW>(a, b, tw, t);
+        fft_sync<WS>();
+        return b;
+    }
+    return a;
 }
 
-// threads per line for a given N (8 or 10 points per thread)
+// whether a kernel that runs many transforms per thread should keep its twiddles in registers
 template <int N>
-struct LineCfg {
-    static constexpr int TPR = (N == 1280) ? 128 : N / 8;
-    static constexpr int SLOTS = 256 / TPR;
-};
+constexpr bool use_reg_twiddles() { return tw_count<N>() <= 20; }
 
 }  // namespace mpsfr

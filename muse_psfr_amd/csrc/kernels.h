@@ -69,7 +69,7 @@ void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const
                            void* d_out, bool f64);
 void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
                        const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
-                       const void* d_samp_a, void* d_Tq, const void* d_tw, bool f64, bool fast_exp);
+                       const void* d_samp_a, void* d_Tq, const void* d_tw64, bool f64, bool fast_exp);
 void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, const void* d_G,
                     double* d_pre, bool f64);
 void launch_conv(hipStream_t s, int ntask, int nl, const double* d_pre, const void* d_ktt,

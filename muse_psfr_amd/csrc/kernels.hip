@@ -127,23 +127,24 @@ __global__ void __launch_bounds__(256) k_tel_otf(int N, const uint64_t* __restri
 // layout, row r, and its forward FFT along the row.  C[td][r][y], y in [0, N/2].
 // ------------------------------------------------------------------------------------------
 template <int N>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(LineCfg<N>::THREADS)
 k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict__ aotab,
              double cfit, cx<double>* __restrict__ C, const cx<double>* __restrict__ twg) {
-    constexpr int TPR = LineCfg<N>::TPR, SLOTS = LineCfg<N>::SLOTS;
+    using L = LineCfg<N>;
+    constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
     extern __shared__ __align__(16) unsigned char smem[];
     cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
     cx<double>* bufA = tw + N;
-    cx<double>* bufB = bufA + SLOTS * N;
+    cx<double>* bufB = bufA + SLOTS * NPAD;
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
     const int r = blockIdx.x * SLOTS + slot;
     const int td = blockIdx.y;
     const int task = td / ndir, d = td % ndir;
-    for (int i = threadIdx.x; i < N; i += 256) tw[i] = twg[i];
+    for (int i = threadIdx.x; i < N; i += THREADS) tw[i] = twg[i];
     const TaskPar p = tp[task];
     const int su = r < N / 2 ? r : r - N;
-    cx<double>* a = bufA + slot * N;
-    cx<double>* b = bufB + slot * N;
+    cx<double>* a = bufA + slot * NPAD;
+    cx<double>* b = bufB + slot * NPAD;
     const double* tb = aotab + ((size_t)(p.geom * ndir + d) * 3) * (NAO * NAO);
     const bool rowin = su >= -NAO / 2 && su < NAO / 2;
     const double fy = su + 0.5;
@@ -163,12 +164,12 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
                               tb[2 * NAO * NAO + o];
             psd = fmax(psd, ao);                                    // :149
         }
-        a[c] = {psd, 0.0};
+        a[lds_pad(c)] = {psd, 0.0};
     }
     __syncthreads();
-    const cx<double>* res = fft_forward<double, N, TPR>(a, b, tw, t);
+    const cx<double>* res = fft_forward<double, N, false>(a, b, tw, t);
     cx<double>* out = C + ((size_t)td * N + r) * (N / 2 + 1);
-    for (int y = t; y <= N / 2; y += TPR) out[y] = res[y];
+    for (int y = t; y <= N / 2; y += TPR) out[y] = res[lds_pad(y)];
 }
 
 // K_DC_SUM: S00[td] = Re sum_r C[td][r][0] = sum of the PSD (bg[0,0], psfrec.py:721)
@@ -190,34 +191,36 @@ __global__ void __launch_bounds__(256) k_dc_sum(const cx<double>* __restrict__ C
 // wavelength factor): D0t[td][y][x] = 2 scale (S00 - Re S[x][y]), y in [0, N/2], x in [0, N).
 // ------------------------------------------------------------------------------------------
 template <int N, typename RO>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(LineCfg<N>::THREADS)
 k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, double scale2,
               RO* __restrict__ D0t, const cx<double>* __restrict__ twg) {
-    constexpr int TPR = LineCfg<N>::TPR, SLOTS = LineCfg<N>::SLOTS;
+    using L = LineCfg<N>;
+    constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
     extern __shared__ __align__(16) unsigned char smem[];
     cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
     cx<double>* bufA = tw + N;
-    cx<double>* bufB = bufA + SLOTS * N;
+    cx<double>* bufB = bufA + SLOTS * NPAD;
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
     const int y0 = blockIdx.x * SLOTS;
     const int td = blockIdx.y;
-    for (int i = threadIdx.x; i < N; i += 256) tw[i] = twg[i];
+    for (int i = threadIdx.x; i < N; i += THREADS) tw[i] = twg[i];
     const cx<double>* Ct = C + (size_t)td * N * (N / 2 + 1);
     // SLOTS adjacent columns: consecutive lanes read consecutive columns of one row
-    for (int idx = threadIdx.x; idx < N * SLOTS; idx += 256) {
-        const int r = idx / SLOTS, s = idx % SLOTS;
-        const int y = y0 + s;
+    for (int idx = threadIdx.x; idx < N * SLOTS; idx += THREADS) {
+        const int r = idx / SLOTS, sl = idx % SLOTS;
+        const int y = y0 + sl;
         cx<double> v = {0.0, 0.0};
         if (y <= N / 2) v = Ct[(size_t)r * (N / 2 + 1) + y];
-        bufA[s * N + r] = v;
+        bufA[sl * NPAD + lds_pad(r)] = v;
     }
     __syncthreads();
-    const cx<double>* res = fft_forward<double, N, TPR>(bufA + slot * N, bufB + slot * N, tw, t);
+    const cx<double>* res =
+        fft_forward<double, N, false>(bufA + slot * NPAD, bufB + slot * NPAD, tw, t);
     const int y = y0 + slot;
     if (y <= N / 2) {
         const double dc = s00[td];
         RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N;
-        for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[x].x));
+        for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[lds_pad(x)].x));
     }
 }
 
@@ -306,52 +309,95 @@ __device__ __forceinline__ float exp_sel<float>(float x, bool fast) {
 template <>
 __device__ __forceinline__ double exp_sel<double>(double x, bool) { return exp(x); }
 
-template <typename R, int N>
-__global__ void __launch_bounds__(256)
+template <typename R, int N, int ND>
+__global__ void __launch_bounds__(LineCfg<N>::THREADS)
 k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ telT,
              const LamPar* __restrict__ lp, const int* __restrict__ samp_p,
-             const R* __restrict__ samp_a, cx<R>* __restrict__ Tq, const cx<R>* __restrict__ twg,
-             int fast_exp) {
-    constexpr int TPR = LineCfg<N>::TPR, SLOTS = LineCfg<N>::SLOTS;
+             const R* __restrict__ samp_a, cx<R>* __restrict__ Tq,
+             const cx<double>* __restrict__ twg, int fast_exp) {
+    using L = LineCfg<N>;
+    constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
     constexpr int EPT = N / TPR;
+    constexpr bool REGTW = use_reg_twiddles<N>(), WS = L::WSYNC;
     extern __shared__ __align__(16) unsigned char smem[];
-    cx<R>* tw = reinterpret_cast<cx<R>*>(smem);
-    cx<R>* bufA = tw + N;
-    cx<R>* bufB = bufA + SLOTS * N;
+    cx<R>* twl = reinterpret_cast<cx<R>*>(smem);          // only used when !REGTW
+    cx<R>* bufA = twl + (REGTW ? 0 : N);
+    cx<R>* bufB = bufA + SLOTS * NPAD;
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
     const int v = blockIdx.x * SLOTS + slot;
     const int task = blockIdx.y;
     const bool valid = v <= N / 2;
     const int vv = valid ? v : N / 2;
-    for (int i = threadIdx.x; i < N; i += 256) tw[i] = twg[i];
-    cx<R>* a = bufA + slot * N;
-    cx<R>* b = bufB + slot * N;
+    TwRegs<R, N> twr;
+    const cx<R>* twp;
+    if constexpr (REGTW) {
+        twr.init(twg, t);
+        twp = twr.w;
+    } else {
+        for (int i = threadIdx.x; i < N; i += THREADS) twl[i] = {(R)twg[i].x, (R)twg[i].y};
+        twp = twl;
+        __syncthreads();
+    }
+    cx<R>* a = bufA + slot * NPAD;
+    cx<R>* b = bufB + slot * NPAD;
     R tel[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) tel[e] = telT[(size_t)vv * N + t + e * TPR];
     const R* dline = D0t + ((size_t)task * ndir * (N / 2 + 1) + vv) * N;
     const size_t dstride = (size_t)(N / 2 + 1) * N;
-    for (int l = 0; l < nl; ++l) {
-        const R c = (R)lp[l].c;
+    R dreg[ND == 1 ? EPT : 1];
+    if constexpr (ND == 1) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) dreg[e] = dline[t + e * TPR];
+    }
+    // two wavelengths per complex transform: z = otf(la) + i otf(lb), both real lines
+    for (int l = 0; l < nl; l += 2) {
+        const bool two = l + 1 < nl;
+        const R ca = (R)lp[l].c, cb = (R)lp[two ? l + 1 : l].c;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int x = t + e * TPR;
-            R acc = (R)0;
-            for (int d = 0; d < ndir; ++d) acc += exp_sel<R>(c * dline[d * dstride + x], fast_exp);
-            a[x] = {tel[e] * acc, (R)0};
+            R ra = (R)0, rb = (R)0;
+            if constexpr (ND == 1) {
+                ra = exp_sel<R>(ca * dreg[e], fast_exp);
+                rb = exp_sel<R>(cb * dreg[e], fast_exp);
+            } else {
+                for (int d = 0; d < ndir; ++d) {
+                    const R dv = dline[d * dstride + x];
+                    ra += exp_sel<R>(ca * dv, fast_exp);
+                    rb += exp_sel<R>(cb * dv, fast_exp);
+                }
+            }
+            a[lds_pad(x)] = {tel[e] * ra, two ? tel[e] * rb : (R)0};
         }
-        __syncthreads();
-        const cx<R>* res = fft_forward<R, N, TPR>(a, b, tw, t);
+        fft_sync<WS>();
+        const cx<R>* res = fft_forward<R, N, REGTW>(a, b, twp, t);
         if (valid) {
-            cx<R>* out = Tq + (((size_t)task * nl + l) * (N / 2 + 1) + v) * NS;
-            for (int i = t; i < NS; i += TPR) {
-                const int p = samp_p[l * NS + i];
-                const R w = samp_a[l * NS + i];
-                const cx<R> f0 = res[p], f1 = res[p + 1 == N ? 0 : p + 1];
-                out[i] = {((R)1 - w) * f0.x + w * f1.x, ((R)1 - w) * f0.y + w * f1.y};
+            // F_a[p] = (Z[p] + conj Z[-p]) / 2,  F_b[p] = (Z[p] - conj Z[-p]) / 2i
+            for (int idx = t; idx < 2 * NS; idx += TPR) {
+                const int which = idx / NS, i = idx - which * NS;
+                if (which == 1 && !two) continue;
+                const int ll = l + which;
+                const int p = samp_p[ll * NS + i];
+                const R w = samp_a[ll * NS + i];
+                const int q = p + 1 == N ? 0 : p + 1;
+                const int mp = p == 0 ? 0 : N - p, mq = q == 0 ? 0 : N - q;
+                const cx<R> zp = res[lds_pad(p)], zmp = res[lds_pad(mp)];
+                const cx<R> zq = res[lds_pad(q)], zmq = res[lds_pad(mq)];
+                cx<R> f0, f1;
+                const R h = (R)0.5;
+                if (which == 0) {
+                    f0 = {h * (zp.x + zmp.x), h * (zp.y - zmp.y)};
+                    f1 = {h * (zq.x + zmq.x), h * (zq.y - zmq.y)};
+                } else {
+                    f0 = {h * (zp.y + zmp.y), -h * (zp.x - zmp.x)};
+                    f1 = {h * (zq.y + zmq.y), -h * (zq.x - zmq.x)};
+                }
+                Tq[(((size_t)task * nl + ll) * (N / 2 + 1) + v) * NS + i] = {
+                    ((R)1 - w) * f0.x + w * f1.x, ((R)1 - w) * f0.y + w * f1.y};
             }
         }
-        __syncthreads();
+        fft_sync<WS>();
     }
 }
 
@@ -771,23 +817,21 @@ __global__ void __launch_bounds__(256) k_stamp_sum(int ntask, int nl, const doub
     sum[e] = s;
 }
 
-template <typename T>
-size_t fft_smem(int N) {
-    const int tpr = (N == 1280) ? 128 : N / 8;
-    const int slots = 256 / tpr;
-    return (size_t)(N + 2 * slots * N) * sizeof(T) * 2;
+template <typename T, int N>
+constexpr size_t fft_smem(bool with_table) {
+    return (size_t)((with_table ? N : 0) + 2 * LineCfg<N>::SLOTS * LineCfg<N>::NPAD) * sizeof(T) * 2;
 }
 
 }  // namespace
 
-#define DISPATCH_N(N, CALL)                      \
-    switch (N) {                                 \
-        case 128: { constexpr int NN = 128; CALL; } break;   \
-        case 256: { constexpr int NN = 256; CALL; } break;   \
-        case 512: { constexpr int NN = 512; CALL; } break;   \
-        case 1024: { constexpr int NN = 1024; CALL; } break; \
-        case 1280: { constexpr int NN = 1280; CALL; } break; \
-        default: break;                          \
+#define DISPATCH_N(N, ...)                                          \
+    switch (N) {                                                    \
+        case 128: { constexpr int NN = 128; __VA_ARGS__; } break;   \
+        case 256: { constexpr int NN = 256; __VA_ARGS__; } break;   \
+        case 512: { constexpr int NN = 512; __VA_ARGS__; } break;   \
+        case 1024: { constexpr int NN = 1024; __VA_ARGS__; } break; \
+        case 1280: { constexpr int NN = 1280; __VA_ARGS__; } break; \
+        default: break;                                             \
     }
 
 void launch_ao_tables(hipStream_t s, const AoGeom& g, const uint8_t* d_mask_rec,
@@ -816,12 +860,12 @@ static void allow_smem(K kernel, size_t bytes) {
 
 void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp,
                        const double* d_aotab, double cfit, void* d_C, const void* d_tw64) {
-    const size_t sm = fft_smem<double>(N);
     DISPATCH_N(N, {
+        constexpr size_t sm = fft_smem<double, NN>(true);
         allow_smem(k_psd_rowfft<NN>, sm);
         dim3 grid(NN / LineCfg<NN>::SLOTS, ntd);
-        hipLaunchKernelGGL(k_psd_rowfft<NN>, grid, dim3(256), sm, s, ndir, d_tp, d_aotab, cfit,
-                           (cx<double>*)d_C, (const cx<double>*)d_tw64);
+        hipLaunchKernelGGL(k_psd_rowfft<NN>, grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir, d_tp,
+                           d_aotab, cfit, (cx<double>*)d_C, (const cx<double>*)d_tw64);
     })
 }
 
@@ -834,18 +878,18 @@ void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00
 
 void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,
                         double scale2, void* d_D0t, bool f64out, const void* d_tw64) {
-    const size_t sm = fft_smem<double>(N);
     DISPATCH_N(N, {
         constexpr int SL = LineCfg<NN>::SLOTS;
+        constexpr size_t sm = fft_smem<double, NN>(true);
         dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntd);
         if (f64out) {
             allow_smem(k_colfft_dphi<NN, double>, sm);
-            hipLaunchKernelGGL((k_colfft_dphi<NN, double>), grid, dim3(256), sm, s,
+            hipLaunchKernelGGL((k_colfft_dphi<NN, double>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
                                (const cx<double>*)d_C, d_s00, scale2, (double*)d_D0t,
                                (const cx<double>*)d_tw64);
         } else {
             allow_smem(k_colfft_dphi<NN, float>, sm);
-            hipLaunchKernelGGL((k_colfft_dphi<NN, float>), grid, dim3(256), sm, s,
+            hipLaunchKernelGGL((k_colfft_dphi<NN, float>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
                                (const cx<double>*)d_C, d_s00, scale2, (float*)d_D0t,
                                (const cx<double>*)d_tw64);
         }
@@ -875,27 +919,38 @@ void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const
                            (float*)d_out);
 }
 
+template <typename R, int NN, int ND>
+static void launch_otf_t(hipStream_t s, int ntask, int ndir, int nl, const void* d_D0t,
+                         const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
+                         const void* d_samp_a, void* d_Tq, const void* d_tw64, bool fast_exp) {
+    constexpr int SL = LineCfg<NN>::SLOTS;
+    constexpr size_t sm = fft_smem<R, NN>(!use_reg_twiddles<NN>());
+    allow_smem(k_otf_rowfft<R, NN, ND>, sm);
+    dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntask);
+    hipLaunchKernelGGL((k_otf_rowfft<R, NN, ND>), grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir, nl,
+                       (const R*)d_D0t, (const R*)d_tel, d_lp, d_samp_p, (const R*)d_samp_a,
+                       (cx<R>*)d_Tq, (const cx<double>*)d_tw64, fast_exp ? 1 : 0);
+}
+
 void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
                        const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
-                       const void* d_samp_a, void* d_Tq, const void* d_tw, bool f64,
+                       const void* d_samp_a, void* d_Tq, const void* d_tw64, bool f64,
                        bool fast_exp) {
     DISPATCH_N(N, {
-        constexpr int SL = LineCfg<NN>::SLOTS;
-        dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntask);
         if (f64) {
-            const size_t sm = fft_smem<double>(N);
-            allow_smem(k_otf_rowfft<double, NN>, sm);
-            hipLaunchKernelGGL((k_otf_rowfft<double, NN>), grid, dim3(256), sm, s, ndir, nl,
-                               (const double*)d_D0t, (const double*)d_tel, d_lp, d_samp_p,
-                               (const double*)d_samp_a, (cx<double>*)d_Tq, (const cx<double>*)d_tw,
-                               0);
+            if (ndir == 1)
+                launch_otf_t<double, NN, 1>(s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p,
+                                            d_samp_a, d_Tq, d_tw64, false);
+            else
+                launch_otf_t<double, NN, 0>(s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p,
+                                            d_samp_a, d_Tq, d_tw64, false);
         } else {
-            const size_t sm = fft_smem<float>(N);
-            allow_smem(k_otf_rowfft<float, NN>, sm);
-            hipLaunchKernelGGL((k_otf_rowfft<float, NN>), grid, dim3(256), sm, s, ndir, nl,
-                               (const float*)d_D0t, (const float*)d_tel, d_lp, d_samp_p,
-                               (const float*)d_samp_a, (cx<float>*)d_Tq, (const cx<float>*)d_tw,
-                               fast_exp ? 1 : 0);
+            if (ndir == 1)
+                launch_otf_t<float, NN, 1>(s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p,
+                                           d_samp_a, d_Tq, d_tw64, fast_exp);
+            else
+                launch_otf_t<float, NN, 0>(s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p,
+                                           d_samp_a, d_Tq, d_tw64, fast_exp);
         }
     })
 }

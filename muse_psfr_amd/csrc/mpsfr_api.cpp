@@ -513,7 +513,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         {
             ProfScope ps(c, K_OTF_ROWFFT);
             launch_otf_rowfft(s, N, tc, ndir, nl, c->D0t.p, c->tel.p, (const LamPar*)c->lp.p,
-                              (const int*)c->samp_p.p, c->samp_a.p, c->Tq.p, c->twR.p, c->f64,
+                              (const int*)c->samp_p.p, c->samp_a.p, c->Tq.p, c->tw64.p, c->f64,
                               c->fast_exp);
         }
         {
