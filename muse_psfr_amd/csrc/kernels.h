@@ -74,7 +74,7 @@ void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, c
                     double* d_pre, bool f64);
 void launch_conv(hipStream_t s, int ntask, int nl, const double* d_pre, const void* d_ktt,
                  const void* d_kmuse, double* d_fin, bool f64);
-void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit);
+void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit, bool f64);
 void launch_stamp_sum(hipStream_t s, int ntask, int nl, const double* d_fin, double* d_sum,
                       int accumulate);
 

@@ -597,8 +597,11 @@ k_conv(int nl, const double* __restrict__ pre, const R* __restrict__ ktt,
 // ------------------------------------------------------------------------------------------
 // K_FIT: 5-parameter circular Moffat least-squares fit per stamp (fit_psf_cube psfrec.py:861-871
 // -> mpdaf Image.moffat_fit(circular=True, fit_back=False)): I (1 + ((p-p0)^2+(q-q0)^2)/a^2)^-n,
-// unweighted, all 1600 pixels.  One wavefront per stamp, 25 pixels per lane held in registers,
-// Levenberg-Marquardt in fp64 with wave-shuffle reductions of the 21 normal-equation sums.
+// unweighted, all 1600 pixels.  One wavefront per stamp, 25 pixels per lane held in registers.
+// Levenberg-Marquardt (Marquardt scaling, Nielsen's gain-ratio damping update) iterated in the
+// better-conditioned variables (I, p0, q0, w = FWHM, n) -- the minimum is the same point.
+// Per-lane sums run in the evaluation type RE (float in mixed mode, double in f64 mode); the
+// 21 cross-lane reductions and the 5x5 solves are always fp64.
 // ------------------------------------------------------------------------------------------
 constexpr int NPIX_LANE = NS * NS / 64;   // 25
 
@@ -608,49 +611,67 @@ struct NormEq {
     double chi2;
 };
 
-__device__ __forceinline__ void moffat_accumulate(const double* dpix, int lane, const double* v,
-                                                  NormEq& ne, bool with_jac) {
-    double a[15], g[5], chi2 = 0.0;
+template <typename RE>
+__device__ __forceinline__ RE fit_log(RE x);
+template <>
+__device__ __forceinline__ float fit_log<float>(float x) { return __logf(x); }
+template <>
+__device__ __forceinline__ double fit_log<double>(double x) { return log(x); }
+template <typename RE>
+__device__ __forceinline__ RE fit_exp(RE x);
+template <>
+__device__ __forceinline__ float fit_exp<float>(float x) { return __expf(x); }
+template <>
+__device__ __forceinline__ double fit_exp<double>(double x) { return exp(x); }
+
+// WN = true : v = (I, p0, q0, w, n), 1/a^2 = 4 (2^(1/n) - 1) / w^2
+// WN = false: v = (I, p0, q0, a, n)
+template <typename RE, bool WN, typename DT>
+__device__ __forceinline__ void moffat_accumulate(const DT* dpix, int lane, const double* v,
+                                                  NormEq& ne) {
+    RE a[15], g[5], chi2 = (RE)0;
 #pragma unroll
-    for (int k = 0; k < 15; ++k) a[k] = 0.0;
+    for (int k = 0; k < 15; ++k) a[k] = (RE)0;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) g[k] = 0.0;
-    const double I = v[0], p0 = v[1], q0 = v[2], al = v[3], n = v[4];
-    const double ia2 = 1.0 / (al * al);
+    for (int k = 0; k < 5; ++k) g[k] = (RE)0;
+    const double n_d = v[4];
+    const double s_d = exp2(1.0 / n_d) - 1.0;
+    const double K_d = WN ? 4.0 * s_d / (v[3] * v[3]) : 1.0 / (v[3] * v[3]);
+    // d(1/a^2)/dn / (1/a^2) = s'/s with s' = -2^(1/n) ln2 / n^2   (WN only)
+    const double dKn_d = WN ? -(s_d + 1.0) * 0.69314718055994530942 / (n_d * n_d * s_d) : 0.0;
+    const RE I = (RE)v[0], p0 = (RE)v[1], q0 = (RE)v[2], n = (RE)n_d, K = (RE)K_d;
+    const RE i3 = (RE)(1.0 / v[3]), dKn = (RE)dKn_d;
 #pragma unroll 5
     for (int m = 0; m < NPIX_LANE; ++m) {
         const int o = lane + m * 64;
-        const double dp = (double)(o / NS) - p0, dq = (double)(o % NS) - q0;
-        const double u = dp * dp + dq * dq;
-        const double gg = 1.0 + u * ia2;
-        const double lg = log(gg);
-        const double e = exp(-n * lg);
-        const double r = I * e - dpix[m];
+        const RE dp = (RE)(o / NS) - p0, dq = (RE)(o % NS) - q0;
+        const RE u = dp * dp + dq * dq;
+        const RE gg = (RE)1 + u * K;
+        const RE lg = fit_log<RE>(gg);
+        const RE e = fit_exp<RE>(-n * lg);
+        const RE mo = I * e;
+        const RE r = mo - (RE)dpix[m];
         chi2 += r * r;
-        if (with_jac) {
-            const double cm = I * n * e / gg;
-            double J[5];
-            J[0] = e;
-            J[1] = cm * 2.0 * dp * ia2;
-            J[2] = cm * 2.0 * dq * ia2;
-            J[3] = cm * 2.0 * u * ia2 / al;
-            J[4] = -I * e * lg;
-            int k = 0;
+        const RE cm = mo * n / gg;
+        RE J[5];
+        J[0] = e;
+        J[1] = cm * (RE)2 * K * dp;
+        J[2] = cm * (RE)2 * K * dq;
+        J[3] = cm * (RE)2 * K * u * i3;
+        J[4] = -mo * lg - (WN ? cm * u * K * dKn : (RE)0);
+        int k = 0;
 #pragma unroll
-            for (int x = 0; x < 5; ++x) {
-                g[x] += J[x] * r;
+        for (int x = 0; x < 5; ++x) {
+            g[x] += J[x] * r;
 #pragma unroll
-                for (int y = x; y < 5; ++y) a[k++] += J[x] * J[y];
-            }
+            for (int y = x; y < 5; ++y) a[k++] += J[x] * J[y];
         }
     }
-    ne.chi2 = wave_sum(chi2);
-    if (with_jac) {
+    ne.chi2 = wave_sum((double)chi2);
 #pragma unroll
-        for (int k = 0; k < 15; ++k) ne.a[k] = wave_sum(a[k]);
+    for (int k = 0; k < 15; ++k) ne.a[k] = wave_sum((double)a[k]);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) ne.g[k] = wave_sum(g[k]);
-    }
+    for (int k = 0; k < 5; ++k) ne.g[k] = wave_sum((double)g[k]);
 }
 
 // solve (A + mu diag(A)) x = -g by Cholesky; returns false if not positive definite
@@ -691,7 +712,7 @@ __device__ __forceinline__ bool lm_solve(const NormEq& ne, double mu, double* x)
 }
 
 // inverse of the symmetric 5x5 (Cholesky); false if singular
-__device__ __forceinline__ bool spd_inverse_diag(const NormEq& ne, double cov[5][5]) {
+__device__ __forceinline__ bool spd_inverse(const NormEq& ne, double cov[5][5]) {
     NormEq e = ne;
     for (int c = 0; c < 5; ++c) {
         for (int k = 0; k < 5; ++k) e.g[k] = (k == c) ? -1.0 : 0.0;
@@ -702,19 +723,21 @@ __device__ __forceinline__ bool spd_inverse_diag(const NormEq& ne, double cov[5]
     return true;
 }
 
+template <typename RE>
 __global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restrict__ stamps,
                                              double* __restrict__ fit) {
     const int lane = threadIdx.x & 63;
     const int st = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (st >= nstamp) return;   // whole wave exits together
     const double* src = stamps + (size_t)st * NS * NS;
-    double dpix[NPIX_LANE];
+    RE dpix[NPIX_LANE];
     double best = -1.0e300;
     int besto = 0;
 #pragma unroll
     for (int m = 0; m < NPIX_LANE; ++m) {
-        dpix[m] = src[lane + m * 64];
-        if (dpix[m] > best) { best = dpix[m]; besto = lane + m * 64; }
+        const double d = src[lane + m * 64];
+        dpix[m] = (RE)d;
+        if (d > best) { best = d; besto = lane + m * 64; }
     }
     // argmax over the wave (first maximum in C order, as np.argmax)
 #pragma unroll
@@ -728,68 +751,106 @@ __global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restric
     // iteration count; the oracle starts from fwhm = 4 px, n = 2.)
     int cnt = 0;
 #pragma unroll
-    for (int m = 0; m < NPIX_LANE; ++m) cnt += dpix[m] > 0.5 * best ? 1 : 0;
+    for (int m = 0; m < NPIX_LANE; ++m) cnt += (double)dpix[m] > 0.5 * best ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     double fw0 = 2.0 * sqrt((double)cnt / kPi);
     fw0 = fmin(fmax(fw0, 1.5), (double)NS);
-    double v[5];
-    v[0] = best;
-    v[1] = (double)(besto / NS);
-    v[2] = (double)(besto % NS);
-    v[4] = 2.5;
-    v[3] = fw0 / (2.0 * sqrt(exp2(1.0 / 2.5) - 1.0));
+    double v[5] = {best, (double)(besto / NS), (double)(besto % NS), fw0, 2.5};
+    // float evaluation only has to reach the basin of quadratic convergence: the fp64 polish
+    // below finishes the job
+    const double tol = sizeof(RE) == 4 ? 1.0e-3 : 1.0e-10;
     NormEq ne;
-    moffat_accumulate(dpix, lane, v, ne, true);
-    double mu = 1.0e-3;
+    moffat_accumulate<RE, true, RE>(dpix, lane, v, ne);
+    double mu = 1.0e-2, nu = 2.0;
     int it = 0, status = 1;
     const int maxit = 200;
     while (it < maxit) {
         ++it;
         double dx[5];
         if (!lm_solve(ne, mu, dx)) {
-            mu *= 10.0;
+            mu *= nu;
+            nu *= 2.0;
             if (mu > 1.0e15) { status = 2; break; }
             continue;
         }
-        double vn[5];
+        double vn[5], rel = 0.0;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) vn[k] = v[k] + dx[k];
-        bool ok = vn[3] > 1.0e-3 && vn[4] > 1.0e-2 && vn[4] < 1.0e3;
-        NormEq nn;
-        if (ok) {
-            moffat_accumulate(dpix, lane, vn, nn, true);
-            ok = nn.chi2 <= ne.chi2;     // NaN compares false
+        for (int k = 0; k < 5; ++k) {
+            vn[k] = v[k] + dx[k];
+            rel = fmax(rel, fabs(dx[k]) / (fabs(vn[k]) + 1.0e-300));
         }
-        if (ok) {
-            double rel = 0.0;
+        const bool inside = vn[3] > 1.0e-3 && vn[4] > 1.0e-2 && vn[4] < 1.0e3;
+        if (inside && rel < tol) {       // converged: take the last (tiny) Gauss-Newton step
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const double sc = fabs(vn[k]) + 1.0e-300;
-                rel = fmax(rel, fabs(dx[k]) / sc);
-            }
+            for (int k = 0; k < 5; ++k) v[k] = vn[k];
+            status = 0;
+            break;
+        }
+        NormEq nn;
+        double rho = -1.0;
+        if (inside) {
+            moffat_accumulate<RE, true, RE>(dpix, lane, vn, nn);
+            // predicted decrease of chi2: dx^T (mu D dx - g)
+            double pred = 0.0;
+            const int dg[5] = {0, 5, 9, 12, 14};
+#pragma unroll
+            for (int k = 0; k < 5; ++k) pred += dx[k] * (mu * ne.a[dg[k]] * dx[k] - ne.g[k]);
+            rho = (ne.chi2 - nn.chi2) / pred;    // NaN -> rejected
+        }
+        if (rho > 0.0) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) v[k] = vn[k];
             ne = nn;
-            mu = fmax(mu * 0.1, 1.0e-14);
-            if (rel < 1.0e-10) { status = 0; break; }
+            const double c = 2.0 * rho - 1.0;
+            mu = fmax(mu * fmax(1.0 / 3.0, 1.0 - c * c * c), 1.0e-14);
+            nu = 2.0;
         } else {
-            mu *= 10.0;
-            if (mu > 1.0e15) { status = 0; break; }   // no further descent possible: at the minimum
+            mu *= nu;
+            nu *= 2.0;
+            if (mu > 1.0e15) { status = 0; break; }   // no further descent: at the minimum
         }
     }
+    if constexpr (sizeof(RE) == 4) {
+        // The float evaluation has systematic errors of ~1e-6 in the wings (v_log/v_exp), enough
+        // to move beta by a few 1e-4 on flat-topped stamps.  Polish with fp64 Gauss-Newton steps
+        // from the float solution (quadratic convergence: one or two suffice).
+        double dd[NPIX_LANE];
+#pragma unroll
+        for (int m = 0; m < NPIX_LANE; ++m) dd[m] = src[lane + m * 64];
+        for (int pz = 0; pz < 6 && status != 2; ++pz) {
+            NormEq np;
+            moffat_accumulate<double, true, double>(dd, lane, v, np);
+            double dx[5];
+            if (!lm_solve(np, 1.0e-10, dx)) break;
+            double rel = 0.0;
+            bool inside = true;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) rel = fmax(rel, fabs(dx[k]) / (fabs(v[k] + dx[k]) + 1.0e-300));
+            inside = v[3] + dx[3] > 1.0e-3 && v[4] + dx[4] > 1.0e-2 && v[4] + dx[4] < 1.0e3 &&
+                     rel < 0.1;
+            if (!inside) break;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] += dx[k];
+            ++it;
+            if (rel < 1.0e-5) break;      // error after this step ~ rel^2
+        }
+    }
+    // back to (a, n); normal equations there for chi2 and the covariance
+    const double n = v[4];
+    const double s2 = exp2(1.0 / n) - 1.0, sq = sqrt(s2);
+    const double al = fabs(v[3]) / (2.0 * sq);
+    double va[5] = {v[0], v[1], v[2], al, n};
+    moffat_accumulate<RE, false, RE>(dpix, lane, va, ne);
     if (lane == 0) {
         double* o = fit + (size_t)st * NFIT;
-        const double al = fabs(v[3]), n = v[4];
-        const double s2 = exp2(1.0 / n) - 1.0;
-        const double sq = sqrt(s2);
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = al; o[4] = n;
-        o[5] = 2.0 * al * sq;
+        o[5] = fabs(v[3]);
         o[6] = ne.chi2;
         o[7] = (double)it;
         double cov[5][5];
         const double dof = (double)(NS * NS - 5);
-        if (spd_inverse_diag(ne, cov)) {
+        if (spd_inverse(ne, cov)) {
             const double s = ne.chi2 / dof;
             for (int k = 0; k < 5; ++k) o[8 + k] = sqrt(fmax(cov[k][k] * s, 0.0));
             const double da = 2.0 * sq;
@@ -983,9 +1044,14 @@ void launch_conv(hipStream_t s, int ntask, int nl, const double* d_pre, const vo
     }
 }
 
-void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit) {
+void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit, bool f64) {
     if (nstamp <= 0) return;
-    hipLaunchKernelGGL(k_fit, dim3((nstamp + 3) / 4), dim3(256), 0, s, nstamp, d_stamps, d_fit);
+    if (f64)
+        hipLaunchKernelGGL(k_fit<double>, dim3((nstamp + 3) / 4), dim3(256), 0, s, nstamp,
+                           d_stamps, d_fit);
+    else
+        hipLaunchKernelGGL(k_fit<float>, dim3((nstamp + 3) / 4), dim3(256), 0, s, nstamp, d_stamps,
+                           d_fit);
 }
 
 void launch_stamp_sum(hipStream_t s, int ntask, int nl, const double* d_fin, double* d_sum,

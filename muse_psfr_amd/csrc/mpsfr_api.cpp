@@ -529,7 +529,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         }
         if (fit_out) {
             ProfScope ps(c, K_FIT);
-            launch_fit(s, tc * nl, d_fin, d_fit_all + (size_t)t0 * nl * NFIT);
+            launch_fit(s, tc * nl, d_fin, d_fit_all + (size_t)t0 * nl * NFIT, c->f64);
         }
         if (psf_sum_out) {
             ProfScope ps(c, K_STAMP_SUM);
@@ -565,7 +565,7 @@ int mpsfr_fit_stamps(mpsfr_ctx* c, int nstamp, const double* stamps, double* fit
     const size_t per = (size_t)NS * NS;
     if (on_device) {
         ProfScope ps(c, K_FIT);
-        launch_fit(s, nstamp, stamps, fit_out);
+        launch_fit(s, nstamp, stamps, fit_out, c->f64);
         HIPCHK(hipGetLastError());
         return MPSFR_OK;
     }
@@ -576,7 +576,7 @@ int mpsfr_fit_stamps(mpsfr_ctx* c, int nstamp, const double* stamps, double* fit
     HIPCHK(hipMemcpyAsync(d_st, stamps, (size_t)nstamp * per * sizeof(double), hipMemcpyHostToDevice, s));
     {
         ProfScope ps(c, K_FIT);
-        launch_fit(s, nstamp, d_st, d_ft);
+        launch_fit(s, nstamp, d_st, d_ft, c->f64);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(fit_out, d_ft, (size_t)nstamp * NFIT * sizeof(double), hipMemcpyDeviceToHost, s));
