@@ -105,20 +105,20 @@ def main():
         ctx.set_option('chunk_tasks', a.chunk)
     ctx.set_option('fast_exp', a.fast_exp)
 
+    from muse_psfr_amd.distributed import gather_fit_tables, reduce_psf_sum
     fit = torch.zeros((rows, nl, NFIT), dtype=torch.float64, device=dev)
     psum = torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev)
-    fit_all = torch.zeros((world * rows, nl, NFIT), dtype=torch.float64, device=dev) \
-        if world > 1 else fit
     three = np.zeros(rows, np.uint8)
     h = (100, 10000)
+    state = {}
 
     def step():
         ctx.reconstruct_device(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, None,
                                None, psum.data_ptr(), fit.data_ptr())
         ctx.sync()
-        if world > 1:
-            dist.all_gather_into_tensor(fit_all, fit)
-            dist.reduce(psum, dst=0, op=dist.ReduceOp.SUM)
+        if world > 1:      # FIT_ROWS gather + PSF_MEAN numerator reduce
+            state['fit_all'] = gather_fit_tables(fit, world * rows)
+            reduce_psf_sum(psum, dst=0)
 
     def fence():
         torch.cuda.synchronize()

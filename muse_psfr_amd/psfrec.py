@@ -1,0 +1,388 @@
+"""Drop-in Python API of the reference's PSF-reconstruction path, on the MI355X.
+
+Mirrors ``muse_psfr.psfrec`` (reference psfrec.py) for this path: ``compute_psf`` (:933-978),
+``compute_psf_from_sparta`` (:981-1120), ``create_sparta_table`` (:1123-1141), ``fit_psf_cube``
+(:861-871), ``muse_intrinsic_psf`` (:1144-1171), ``fit_psf_with_polynom`` (:1174-1215) -- same names,
+argument meaning, return structure, log messages and error behaviour.  All numerics run in
+``libmpsfr.so`` (HIP); the reference's joblib fan-out over rows (:1082-1083) becomes one batched
+GPU call.  There is no CPU fallback.
+
+Extra keyword-only arguments (defaults = the reference's hard-coded values, so existing callers see
+no difference): ``dim=1280`` (:955), ``dimpsf=40`` (:658), ``pixscale=0.2`` (:659, :899, :868),
+``precision='mixed'|'f64'``, ``cutoff_masks='host'|'exact'|(rec, res)``, ``device=0``.
+
+astropy is used for tables / FITS when it is importable (then the return types are astropy's, as
+in the reference); otherwise the small NumPy implementations in ``_minifits`` / ``Table`` below.
+"""
+import logging
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _minifits
+from ._lib import Context, MpsfrError, E_GRID
+
+MIN_L0 = 8    # minimum L0 in m (psfrec.py:30)
+MAX_L0 = 30   # maximum L0 in m (psfrec.py:31)
+
+logger = logging.getLogger(__name__)
+
+_FIT_COLS = ('lbda', 'center', 'flux', 'fwhm', 'n', 'peak', 'err_center', 'err_flux', 'err_fwhm',
+             'err_n', 'err_peak')
+
+
+def _astropy():
+    try:
+        from astropy.io import fits
+        from astropy.table import Table as ATable
+        return fits, ATable
+    except Exception:  # noqa: BLE001 - absent or broken astropy: use the NumPy implementations
+        return None, None
+
+
+class Table:
+    """Tiny stand-in for astropy.table.Table (used only when astropy is absent): ordered columns
+    of equal length plus a ``meta`` dict."""
+
+    def __init__(self, columns=None, meta=None):
+        self.columns = OrderedDict((k, np.asarray(v)) for k, v in (columns or {}).items())
+        self.meta = dict(meta or {})
+
+    @property
+    def colnames(self):
+        return list(self.columns)
+
+    def __len__(self):
+        return 0 if not self.columns else len(next(iter(self.columns.values())))
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return self.columns[key]
+        return Table(OrderedDict((k, v[key]) for k, v in self.columns.items()), self.meta)
+
+    def __setitem__(self, key, value):
+        n = len(self)
+        v = np.asarray(value)
+        self.columns[key] = np.full(n, v) if v.ndim == 0 else v
+
+    def __contains__(self, key):
+        return key in self.columns
+
+    @classmethod
+    def read(cls, hdu):
+        d = hdu.data
+        meta = {k: v for k, v in hdu.header.items()
+                if k not in ('XTENSION', 'BITPIX', 'NAXIS', 'NAXIS1', 'NAXIS2', 'PCOUNT', 'GCOUNT',
+                             'TFIELDS', 'EXTNAME') and not k.startswith(('TTYPE', 'TFORM', 'TDIM'))}
+        return cls(OrderedDict((n, np.array(d[n])) for n in d.dtype.names), meta)
+
+
+def host_cutoff_masks():
+    """The cut-off masks of psfrec.py:257 (>=) and :435 (>) evaluated with this host's NumPy in
+    exactly the reference's way: |f cos(arctan(fy/fx))| and |f sin(arctan(fy/fx))| against
+    fc = 1.5.  On the |k| = 24 lines the outcome depends on last-bit libm rounding, so the
+    reference itself is platform dependent there ("cut-off masks"); computing them here
+    keeps a user's results identical to what the reference gives on the same machine."""
+    fx = np.fft.fftfreq(80, 8.0 / 40)[:, np.newaxis]
+    fy = fx.T
+    f = np.sqrt(fx ** 2 + fy ** 2)
+    with np.errstate(all='ignore'):
+        arg = fy / fx
+    arg[0, 0] = 0
+    arg = np.arctan(arg)
+    f_x = f * np.cos(arg)
+    f_y = f * np.sin(arg)
+    fc = 1 / (2 * (8.0 / 24.0))
+    rec = (f != 0) & (np.abs(f_x) >= fc) | (np.abs(f_y) >= fc)
+    res = (f != 0) & (np.abs(f_x) > fc) | (np.abs(f_y) > fc)
+    return rec, res
+
+
+_contexts = {}
+
+
+def get_context(dim=1280, pixscale=0.2, dimpsf=40, precision='mixed', device=0):
+    """Cached GPU context for (dim, pixscale, dimpsf, precision, device)."""
+    key = (int(dim), float(pixscale), int(dimpsf), precision, int(device))
+    if key not in _contexts:
+        _contexts[key] = Context(dim=dim, pixscale=pixscale, dimpsf=dimpsf, precision=precision,
+                                 device=device)
+    return _contexts[key]
+
+
+def _resolve_masks(cutoff_masks):
+    if cutoff_masks is None or (isinstance(cutoff_masks, str) and cutoff_masks == 'exact'):
+        return None
+    if isinstance(cutoff_masks, str):
+        if cutoff_masks != 'host':
+            raise ValueError("cutoff_masks must be 'host', 'exact' or a (rec, res) pair")
+        return host_cutoff_masks()
+    return cutoff_masks
+
+
+def _reconstruct(lbda, tasks, npsflin, h, dim, dimpsf, pixscale, precision, cutoff_masks, device,
+                 want_psf=True):
+    ctx = get_context(dim, pixscale, dimpsf, precision, device)
+    see = np.array([t[0] for t in tasks], dtype=float)
+    gl = np.array([t[1] for t in tasks], dtype=float)
+    l0 = np.array([t[2] for t in tasks], dtype=float)
+    three = np.array([1 if t[3] else 0 for t in tasks], dtype=np.uint8)
+    try:
+        return ctx.reconstruct(lbda, see, gl, l0, three, h, npsflin=npsflin,
+                               masks=_resolve_masks(cutoff_masks), want_psf=want_psf)
+    except MpsfrError as e:
+        if e.code == E_GRID:
+            # the reference fails here with a ValueError from scipy's interpn (psfrec.py:663-683)
+            raise ValueError(str(e)) from None
+        raise
+
+
+def _fit_columns(lbda, fit, pixscale):
+    """fit: (n, NFIT) rows of libmpsfr -> the columns fit_psf_cube keeps (psfrec.py:866-870)."""
+    fit = np.asarray(fit)
+    n = fit.shape[0]
+    cols = OrderedDict()
+    cols['lbda'] = np.asarray(lbda, dtype=float)
+    cols['center'] = fit[:, 1:3].copy()
+    cols['flux'] = fit[:, 15].copy()
+    cols['fwhm'] = np.repeat(fit[:, 5:6] * pixscale, 2, axis=1)
+    cols['n'] = fit[:, 4].copy()
+    cols['peak'] = fit[:, 0].copy()
+    cols['err_center'] = fit[:, 9:11].copy()
+    with np.errstate(all='ignore'):
+        rel = np.sqrt((fit[:, 8] / fit[:, 0]) ** 2 + (2 * fit[:, 11] / fit[:, 3]) ** 2 +
+                      (fit[:, 12] / (fit[:, 4] - 1)) ** 2)
+    cols['err_flux'] = np.abs(fit[:, 15]) * rel
+    cols['err_fwhm'] = np.repeat(fit[:, 13:14] * pixscale, 2, axis=1)
+    cols['err_n'] = fit[:, 12].copy()
+    cols['err_peak'] = fit[:, 8].copy()
+    assert tuple(cols) == _FIT_COLS and all(len(v) == n for v in cols.values())
+    return cols
+
+
+def _make_table(cols, meta=None):
+    _, ATable = _astropy()
+    if ATable is not None:
+        t = ATable(cols)
+        t.meta.update(meta or {})
+        return t
+    return Table(cols, meta)
+
+
+def fit_psf_cube(lbda, psfcube, *, pixscale=0.2, precision='mixed', device=0):
+    """Fit a Moffat PSF on each wavelength plane of the psfcube (psfrec.py:861-871)."""
+    data = np.asarray(getattr(psfcube, 'data', psfcube), dtype=float)
+    ctx = get_context(128, pixscale, data.shape[-1], precision, device)
+    return _make_table(_fit_columns(lbda, ctx.fit_stamps(data), pixscale))
+
+
+def compute_psf(lbda, seeing, GL, L0, npsflin=1, h=(100, 10000), three_lgs_mode=False,
+                verbose=True, *, dim=1280, dimpsf=40, pixscale=0.2, precision='mixed',
+                cutoff_masks='host', device=0):
+    """Reconstruct a PSF from a set of seeing, GL, and L0 values (psfrec.py:933-978).
+
+    Returns ``(table, psf)``: the per-wavelength Moffat fit table (with SEEING, GL, L0 columns and
+    meta) and the (nl, 40, 40) float64 PSF cube."""
+    lbda = np.atleast_1d(np.asarray(lbda, dtype=float))
+    if verbose:
+        logger.info('Compute PSF with seeing=%.2f GL=%.2f L0=%.2f', seeing, GL, L0)
+        if three_lgs_mode:
+            logger.info('Using three lasers mode')
+    r = _reconstruct(lbda, [(seeing, GL, L0, three_lgs_mode)], npsflin, h, dim, dimpsf, pixscale,
+                     precision, cutoff_masks, device)
+    cols = _fit_columns(lbda, r['fit'][0], pixscale)
+    nl = lbda.size
+    cols['SEEING'] = np.full(nl, float(seeing))
+    cols['GL'] = np.full(nl, float(GL))
+    cols['L0'] = np.full(nl, float(L0))
+    res = _make_table(cols, {'SEEING': float(seeing), 'GL': float(GL), 'L0': float(L0)})
+    return res, r['psf'][0]
+
+
+def _table_hdu(cols, meta, name):
+    fits, ATable = _astropy()
+    if fits is not None:
+        t = ATable(cols)
+        t.meta.update(meta)
+        hdu = fits.table_to_hdu(t)
+        hdu.name = name
+        return hdu
+    hdr = _minifits.Header()
+    for k, v in meta.items():
+        hdr[k] = v
+    return _minifits.BinTableHDU.from_columns(cols, hdr, name)
+
+
+def compute_psf_from_sparta(filename, extname='SPARTA_ATM_DATA', npsflin=1, lmin=490, lmax=930,
+                            nl=35, lbda=None, h=(100, 10000), n_jobs=-1, plot=False,
+                            mean_of_lgs=True, verbose=True, *, dim=1280, dimpsf=40, pixscale=0.2,
+                            precision='mixed', cutoff_masks='host', device=0):
+    """Reconstruct a PSF from SPARTA data (psfrec.py:981-1120).
+
+    ``filename`` is a FITS path or an already opened HDUList.  Returns an HDUList with
+    PRIMARY, a copy of the SPARTA extension, FIT_ROWS, FIT_MEAN and PSF_MEAN -- or ``None``
+    (with a 'No valid values' warning) when no row has a valid laser.  ``n_jobs`` is accepted for
+    compatibility; the rows are processed as one GPU batch."""
+    fits, _ = _astropy()
+    io_mod = fits if fits is not None else _minifits
+    opened = False
+    if isinstance(filename, (list, _minifits.HDUList)) or (
+            fits is not None and isinstance(filename, fits.HDUList)):
+        hdul = filename
+    else:
+        hdul = io_mod.open(filename)
+        opened = True
+    try:
+        ext = hdul[extname]
+        data = np.array(ext.data)
+        if fits is not None and isinstance(ext, fits.BinTableHDU):
+            out = fits.HDUList([fits.PrimaryHDU(), ext.copy()])
+        else:
+            out = _minifits.HDUList([_minifits.PrimaryHDU(), ext.copy()])
+    finally:
+        if opened:
+            hdul.close()
+
+    nrows = len(data)
+    if nrows == 1:
+        n_jobs = 1
+    if lbda is None:
+        lbda = np.linspace(lmin, lmax, nl)
+    lbda = np.atleast_1d(np.asarray(lbda, dtype=float))
+    if verbose:
+        logger.info('Processing SPARTA table with %d values, njobs=%d ...', nrows, n_jobs)
+
+    laser_idx = []
+    to_compute = []
+    for irow in range(1, nrows + 1):
+        row = data[irow - 1]
+        values = np.array([[row['LGS%d_%s' % (k, col)] for col in ('SEEING', 'TUR_GND', 'L0')]
+                           for k in range(1, 5)], dtype=float)
+        # outlier rejection, psfrec.py:1049-1051
+        ok = (values[:, 1] > 0) & (values[:, 2] < MAX_L0) & (values[:, 2] > MIN_L0)
+        nb_gs = int(np.sum(ok))
+        three_lgs_mode = nb_gs < 4
+        if nb_gs == 0:
+            if verbose:
+                logger.info('%d/%d : No valid values, skipping this row', irow, nrows)
+            continue
+        elif nb_gs < 4:
+            if verbose:
+                logger.info('%d/%d : Using only %d values out of 4 after outliers rejection',
+                            irow, nrows, nb_gs)
+        if mean_of_lgs:
+            seeing, GL, L0 = values[ok].mean(axis=0)
+            laser_idx.append(-1)
+            to_compute.append((seeing, GL, L0, three_lgs_mode))
+        else:
+            for i in np.where(ok)[0]:
+                seeing, GL, L0 = values[i]
+                laser_idx.append(int(i) + 1)
+                to_compute.append((seeing, GL, L0, three_lgs_mode))
+
+    if len(to_compute) == 0:
+        logger.warning('No valid values')
+        return None
+
+    if verbose:
+        for seeing, GL, L0, three in to_compute:
+            logger.info('Compute PSF with seeing=%.2f GL=%.2f L0=%.2f', seeing, GL, L0)
+            if three:
+                logger.info('Using three lasers mode')
+
+    r = _reconstruct(lbda, to_compute, npsflin, h, dim, dimpsf, pixscale, precision, cutoff_masks,
+                     device, want_psf=False)
+    ntask, nlam = len(to_compute), lbda.size
+
+    # FIT_ROWS: the per-task tables stacked (psfrec.py:1086-1101)
+    cols = _fit_columns(np.tile(lbda, ntask), r['fit'].reshape(ntask * nlam, -1), pixscale)
+    stats = np.array([t[:3] for t in to_compute], dtype=float)
+    cols['SEEING'] = np.repeat(stats[:, 0], nlam)
+    cols['GL'] = np.repeat(stats[:, 1], nlam)
+    cols['L0'] = np.repeat(stats[:, 2], nlam)
+    cols['row_idx'] = np.repeat(np.arange(1, ntask + 1), nlam)
+    cols['lgs_idx'] = np.repeat(np.array(laser_idx), nlam)
+    out.append(_table_hdu(cols, {}, 'FIT_ROWS'))
+
+    # mean PSF over the tasks and its fit (psfrec.py:1104-1113)
+    psftot = r['psf_sum'] / ntask
+    ctx = get_context(dim, pixscale, dimpsf, precision, device)
+    mcols = _fit_columns(lbda, ctx.fit_stamps(psftot), pixscale)
+    seeing, GL, L0 = np.median(stats, axis=0)
+    out.append(_table_hdu(mcols, {'SEEING': float(seeing), 'GL': float(GL), 'L0': float(L0)},
+                          'FIT_MEAN'))
+    if fits is not None and isinstance(out, fits.HDUList):
+        out.append(fits.ImageHDU(data=psftot, name='PSF_MEAN'))
+    else:
+        out.append(_minifits.ImageHDU(data=psftot, name='PSF_MEAN'))
+
+    if plot:
+        import matplotlib.pyplot as plt
+        plot_psf(out, npsflin=npsflin)
+        plt.show()
+    return out
+
+
+def create_sparta_table(nlines=1, seeing=1, L0=25, GL=0.7, bad_l0=False, outfile=None):
+    """Helper to create a SPARTA table with the given seeing, L0, and GL values for the 4 LGS
+    (psfrec.py:1123-1141).  Returns the table HDU named SPARTA_ATM_DATA."""
+    cols = OrderedDict()
+    for k in range(1, 5):
+        for col, v in (('SEEING', seeing), ('TUR_GND', GL), ('L0', L0)):
+            cols['LGS%d_%s' % (k, col)] = np.full(nlines, float(v))
+    if bad_l0:
+        cols['LGS4_L0'] = np.full(nlines, 150.0)
+    hdu = _table_hdu(cols, {}, 'SPARTA_ATM_DATA')
+    if outfile is not None:
+        fits, _ = _astropy()
+        if fits is not None:
+            hdu.writeto(outfile, overwrite=True)
+        else:
+            _minifits.HDUList([_minifits.PrimaryHDU(), hdu]).writeto(outfile, overwrite=True)
+    return hdu
+
+
+def muse_intrinsic_psf(lbda):
+    """MUSE PSF polynomial approximation (psfrec.py:1144-1171): fwhm, beta, fwhm_std, beta_std."""
+    pol_beta = [-0.83704697, 1.1337153, 0.0609222, -1.35581762, 1.15237178, 2.2106042]
+    pol_fwhm = [0.60467385, -1.58905792, 1.75293264, -1.0368302, 0.21487023, 0.34851139]
+    pol_beta_std = [0.18187424, -0.17841793, 0.30962616]
+    pol_fwhm_std = [0.00707504, -0.0303464, 0.04596354]
+    lb = (10 * np.asarray(lbda, dtype=float) - 4750) / (9350 - 4750)
+    return (np.polyval(pol_fwhm, lb), np.polyval(pol_beta, lb), np.polyval(pol_fwhm_std, lb),
+            np.polyval(pol_beta_std, lb))
+
+
+def fit_psf_with_polynom(lbda, fwhm, beta, deg=(5, 5), output=0):
+    """Fit MUSE PSF fwhm and beta with polynoms (psfrec.py:1174-1215)."""
+    def norm(x):
+        return (np.asarray(x, dtype=float) - 475) / (935 - 475) - 0.5
+    fwhm_pol = np.polyfit(norm(lbda), fwhm, deg[0])
+    beta_pol = np.polyfit(norm(lbda), beta, deg[1])
+    res = dict(fwhm_pol=fwhm_pol, beta_pol=beta_pol, lbda=lbda, lbda_lim=(475, 935))
+    if output > 0:
+        lbda_fit = np.linspace(475, 935, 50)
+        res['lbda_fit'] = lbda_fit
+        res['fwhm_fit'] = np.polyval(fwhm_pol, norm(lbda_fit))
+        res['beta_fit'] = np.polyval(beta_pol, norm(lbda_fit))
+    return res
+
+
+def plot_psf(filename, npsflin=1):
+    """Quick-look figure of PSF_MEAN and the FIT_MEAN curves (psfrec.py:826-858, simplified)."""
+    import matplotlib.pyplot as plt
+    from matplotlib.colors import LogNorm
+    hdul = filename if not isinstance(filename, (str, os.PathLike)) else (
+        _astropy()[0] or _minifits).open(filename)
+    psf = hdul['PSF_MEAN'].data
+    fit = hdul['FIT_MEAN'].data
+    fig, axes = plt.subplots(1, 3, figsize=(12, 3.5), tight_layout=True)
+    im = axes[0].imshow(psf[min(1, len(psf) - 1)], origin='lower', norm=LogNorm())
+    fig.colorbar(im, ax=axes[0])
+    axes[0].set_title('PSF')
+    axes[1].plot(fit['lbda'], np.asarray(fit['fwhm'])[:, 0])
+    axes[1].set_title(r'$FWHM(\\lambda)$')
+    axes[2].plot(fit['lbda'], fit['n'])
+    axes[2].set_title(r'$\\beta(\\lambda)$')
+    return fig

@@ -1,0 +1,120 @@
+"""GPU: the drop-in Python API (muse_psfr_amd.compute_psf / compute_psf_from_sparta) replaying the
+reference's own integration tests (muse_psfr/test_psfrec.py) with their known answers."""
+import logging
+import os
+
+import numpy as np
+import pytest
+
+from conftest import H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def api():
+    import muse_psfr_amd
+    return muse_psfr_amd
+
+
+def _hdul(tbl):
+    from muse_psfr_amd import _minifits as mf
+    from muse_psfr_amd.psfrec import _astropy
+    fits, _ = _astropy()
+    if fits is not None:
+        return fits.HDUList([fits.PrimaryHDU(), tbl])
+    return mf.HDUList([mf.PrimaryHDU(), tbl])
+
+
+def test_reconstruction(api, ref_masks):
+    """test_psfrec.py:17-30 (npsflin=3, 5 wavelengths)."""
+    res = api.compute_psf_from_sparta(_hdul(api.create_sparta_table()), npsflin=3, lmin=490,
+                                      lmax=541.76, nl=5, cutoff_masks=ref_masks)
+    assert len(res) == 5
+    fit = res['FIT_ROWS'].data
+    np.testing.assert_allclose(fit['L0'], 25)
+    np.testing.assert_allclose(fit['center'], 20, atol=1e-3)
+    np.testing.assert_allclose(fit[1]['lbda'], 502.9, atol=1e-1)
+    np.testing.assert_allclose(fit[1]['fwhm'], 0.85, atol=1e-2)
+
+
+def test_fit_poly(api, ref_masks):
+    """test_psfrec.py:33-44."""
+    res = api.compute_psf_from_sparta(_hdul(api.create_sparta_table()), lmin=500, lmax=900, nl=9,
+                                      cutoff_masks=ref_masks)
+    fit = res['FIT_ROWS'].data
+    r = api.fit_psf_with_polynom(fit['lbda'], fit['fwhm'][:, 0], fit['n'], deg=(5, 5), output=1)
+    np.testing.assert_allclose(r['fwhm_pol'][0], 0.65, atol=1e-2)
+    np.testing.assert_allclose(r['beta_pol'][0], 0.78, atol=1e-2)
+    np.testing.assert_allclose(r['beta_fit'][8], fit[1]['n'], atol=1e-2)
+    np.testing.assert_allclose(r['fwhm_fit'][8], fit[1]['fwhm'][0], atol=1e-2)
+
+
+def test_reconstruction2(api, ref_masks):
+    """test_psfrec.py:47-69 (mean_of_lgs=False, one rejected laser, npsflin=3)."""
+    tbl = api.create_sparta_table()
+    tbl.data[0]['LGS1_L0'] = 20
+    tbl.data[0]['LGS1_SEEING'] = 0.8
+    tbl.data[0]['LGS1_TUR_GND'] = 0.5
+    tbl.data[0]['LGS3_L0'] = 100
+    res = api.compute_psf_from_sparta(_hdul(tbl), npsflin=3, lmin=500, lmax=700, nl=3,
+                                      mean_of_lgs=False, cutoff_masks=ref_masks)
+    assert len(res) == 5
+    fit = res['FIT_ROWS'].data
+    np.testing.assert_allclose(fit[fit['lgs_idx'] == 1]['L0'], 20)
+    np.testing.assert_allclose(fit[fit['lgs_idx'] != 1]['L0'], 25)
+    np.testing.assert_allclose(fit['center'], 20, atol=1e-3)
+    np.testing.assert_allclose(fit[fit['lbda'] == 500]['fwhm'][:, 0], [0.79, 0.86, 0.86], atol=1e-2)
+
+
+def test_bad_l0(api, ref_masks, tmp_path, caplog):
+    """test_psfrec.py:72-90 (file input, LGS4_L0 = 150 -> three-laser mode, log strings)."""
+    testfile = os.path.join(str(tmp_path), 'sparta.fits')
+    api.create_sparta_table(outfile=testfile, bad_l0=True)
+    with caplog.at_level(logging.INFO, logger='muse_psfr_amd.psfrec'):
+        res = api.compute_psf_from_sparta(testfile, lmin=490, lmax=541.76, nl=5,
+                                          cutoff_masks=ref_masks)
+    assert caplog.records[1].message == '1/1 : Using only 3 values out of 4 after outliers rejection'
+    assert caplog.records[3].message == 'Using three lasers mode'
+    assert len(res) == 5
+    fit = res['FIT_ROWS'].data
+    np.testing.assert_allclose(fit['L0'], 25)
+    np.testing.assert_allclose(fit['center'], 20, atol=1e-3)
+    np.testing.assert_allclose(fit[1]['lbda'], 502.9, atol=1e-1)
+    np.testing.assert_allclose(fit[1]['fwhm'], 0.86, atol=1e-2)
+    out = os.path.join(str(tmp_path), 'out.fits')
+    res.writeto(out, overwrite=True)
+    assert os.path.getsize(out) > 0
+
+
+def test_cli_table_values(api, ref_masks):
+    """test_psfrec.py:121-127: --values 1,0.7,25 -> LBDA 5000 7000 9000 / FWHM 0.85 0.73 0.62 /
+    BETA 2.73 2.55 2.23, read from FIT_MEAN exactly as cli.py:66-69 does."""
+    res = api.compute_psf_from_sparta(_hdul(api.create_sparta_table(seeing=1, GL=0.7, L0=25)),
+                                      lmin=500, lmax=900, nl=3, cutoff_masks=ref_masks)
+    assert [h.name for h in res] == ['PRIMARY', 'SPARTA_ATM_DATA', 'FIT_ROWS', 'FIT_MEAN', 'PSF_MEAN']
+    data = res['FIT_MEAN'].data
+    hdr = res['FIT_MEAN'].header
+    assert (hdr['SEEING'], hdr['GL'], hdr['L0']) == (1.0, 0.7, 25.0)
+    assert 'LBDA %.0f %.0f %.0f' % tuple(data['lbda'] * 10) == 'LBDA 5000 7000 9000'
+    assert 'FWHM %.2f %.2f %.2f' % tuple(data['fwhm'][:, 0]) == 'FWHM 0.85 0.73 0.62'
+    assert 'BETA %.2f %.2f %.2f' % tuple(data['n']) == 'BETA 2.73 2.55 2.23'
+
+
+def test_compute_psf_against_golden(api, golden, ref_masks):
+    g = golden('g2_native1280')
+    tbl, psf = api.compute_psf(g['lbda'], 1.0, 0.7, 25.0, cutoff_masks=ref_masks, verbose=False)
+    assert psf.shape == (5, 40, 40)
+    assert np.abs(psf - g['fin_0']).max() / g['fin_0'].max() < 2e-5
+    assert np.abs(np.asarray(tbl['fwhm'])[:, 0] - g['fit_0'][:, 3]).max() < 1e-4
+    assert np.abs(np.asarray(tbl['n']) - g['fit_0'][:, 4]).max() < 1e-4
+    assert np.all(np.asarray(tbl['SEEING']) == 1.0) and tbl.meta['L0'] == 25.0
+    # the default ('host') masks are those of this machine's NumPy: self-consistent with the oracle
+    import psfr_oracle as O
+    tbl2, psf2 = api.compute_psf([500.0, 900.0], 1.2, 0.6, 18.0, verbose=False)
+    tabs = O.ao_tables(H, False, 1, masks=O.numpy_cutoff_masks())
+    ofit, ofin = O.compute_psf([500.0, 900.0], 1.2, 0.6, 18.0, tables=tabs)
+    assert np.abs(psf2 - ofin).max() / ofin.max() < 2e-5
+    assert np.abs(np.asarray(tbl2['n']) - ofit[:, 4]).max() < 1e-4
+    with pytest.raises(ValueError):                      # psfrec.py:663-683 at the native grid
+        api.compute_psf([465.0], 1.0, 0.7, 25.0, verbose=False)
