@@ -96,10 +96,17 @@ def main():
     import torch
     import torch.distributed as dist
     from muse_psfr_amd import Context, NFIT
+    # one rank per GPU; the modulo only matters when rehearsing N > 1 on a box with fewer GPUs
+    # (MPSFR_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device)
+    local = local % torch.cuda.device_count()
+    backend = os.environ.get('MPSFR_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     ctx = Context(dim=dim, pixscale=ps, precision=a.precision, device=local)
     if a.chunk:
         ctx.set_option('chunk_tasks', a.chunk)
@@ -117,11 +124,16 @@ def main():
                                None, psum.data_ptr(), fit.data_ptr())
         ctx.sync()
         if world > 1:      # FIT_ROWS gather + PSF_MEAN numerator reduce
-            state['fit_all'] = gather_fit_tables(fit, world * rows)
-            reduce_psf_sum(psum, dst=0)
+            if backend == 'nccl':
+                state['fit_all'] = gather_fit_tables(fit, world * rows)
+                reduce_psf_sum(psum, dst=0)
+            else:          # CPU rehearsal of the same exchange
+                state['fit_all'] = gather_fit_tables(fit.cpu(), world * rows)
+                state['psum'] = reduce_psf_sum(psum.cpu(), dst=0)
 
     def fence():
         torch.cuda.synchronize()
+        ctx.sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -136,7 +148,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())

@@ -12,7 +12,8 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmpsfr.so')
 SOURCES = ['kernels.hip', 'mpsfr_api.cpp']
 HEADERS = ['kernels.h', 'fft_lds.h', 'coeff_l0_table.h', os.path.join('..', '..', 'include', 'mpsfr.h')]
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-result']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-result',
+         '-fno-slp-vectorize']
 
 
 def _hipcc():

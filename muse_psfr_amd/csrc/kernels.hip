@@ -507,9 +507,9 @@ k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
 // K_CONV: convolve_final_psf (psfrec.py:874-930): two zero-padded 'same' convolutions with
 // 41x41 Moffat kernels (tip-tilt kernel of the task, instrument kernel of the wavelength).
 // One workgroup per stamp.  The stamp sits at offset 20 inside an 80-row zero frame in LDS, so
-// the tap loops need no bounds checks.  Each thread owns a 1x8 strip of outputs (200 strips,
-// column-block major: consecutive lanes take consecutive rows); the frame pitch of 84 words
-// makes the 16-byte row reads of a wave hit distinct banks.  The kernel is symmetric in its
+// the tap loops need no bounds checks.  Each thread owns a 1x8 strip of outputs (200 strips, 50
+// per wave); the frame pitch of 84 words and the strip map make the 16-byte row reads of a wave
+// conflict-free.  The kernel is symmetric in its
 // row index (K[a][b] = K[40-a][b]), so image rows i-a and i+a are added first and the tap
 // count halves.  The taps K[a][b] are wave-uniform and arrive through scalar loads, so the
 // inner loop is pure FMA with an SGPR operand.  Each 41-tap row sum is accumulated in R and
@@ -541,9 +541,14 @@ k_conv(int nl, const double* __restrict__ pre, const R* __restrict__ ktt,
         const int P = e / PW - HK, Q = e % PW - HK;
         img[e] = (P >= 0 && P < NS && Q >= 0 && Q < NS) ? (R)src[P * NS + Q] : (R)0;
     }
-    const bool active = threadIdx.x < NSTRIP;
-    const int sid = active ? threadIdx.x : 0;
-    const int i = sid % NS, j0 = (sid / NS) * SW;
+    // strip map: wave w owns output rows 10w .. 10w+9, lane l < 50 -> row 10w + l%10, column
+    // block l/10.  With the 84-word pitch every 16-lane group of a ds_read_b128 then touches 16
+    // distinct 4-bank slots (brute-forced against the gfx950 lane groups; the column-block-major
+    // map cost 1.43x, SQ_LDS_BANK_CONFLICT = 53 % of LDS cycles).
+    static_assert(NSTRIP == 200 && NS == 40, "strip map assumes 40x40 stamps");
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const bool active = ln < 50;
+    const int i = 10 * wv + (active ? ln % 10 : 0), j0 = (active ? ln / 10 : 0) * SW;
     double acc[SW];
     for (int pass = 0; pass < 2; ++pass) {
         const R* __restrict__ kg = pass == 0 ? ktt + (size_t)task * KS * KS
@@ -553,8 +558,10 @@ k_conv(int nl, const double* __restrict__ pre, const R* __restrict__ ktt,
         for (int o = 0; o < SW; ++o) acc[o] = 0.0;
         for (int a = 0; a <= HK; ++a) {
             // frame rows i-a+40 and (a < 20) i+a, columns j0 .. j0+47
-            const V4* r1 = reinterpret_cast<const V4*>(img + (i - a + 2 * HK) * PW + j0);
-            const V4* r2 = reinterpret_cast<const V4*>(img + (i + a) * PW + j0);
+            const V4* r1 = reinterpret_cast<const V4*>(
+                __builtin_assume_aligned(img + (i - a + 2 * HK) * PW + j0, sizeof(V4)));
+            const V4* r2 = reinterpret_cast<const V4*>(
+                __builtin_assume_aligned(img + (i + a) * PW + j0, sizeof(V4)));
             R sv[LW];
 #pragma unroll
             for (int c = 0; c < LW / 4; ++c) {
