@@ -188,73 +188,104 @@ struct TwRegs {
     }
 };
 
-// One Stockham autosort pass p of the plan (padded LDS images).  REGTW: `wreg` is the thread's
-// TwRegs array; otherwise it is the table tw[m] = exp(-2 pi i m / N), m in [0, N) (in LDS).
-template <typename R, int N, int P_, bool REGTW>
-__device__ __forceinline__ void fft_pass(const cx<R>* __restrict__ in, cx<R>* __restrict__ out,
-                                         const cx<R>* __restrict__ wreg, int t) {
+// One Stockham autosort pass p of the plan (padded LDS images).
+//  REGTW  : `tw` is the thread's TwRegs array; otherwise the table tw[m] = exp(-2 pi i m / N)
+//           (in LDS).
+//  FROMREG: pass 0 only -- the inputs are the thread's own line elements x[e] = line[t + e*TPR]
+//           (a thread's first-pass butterflies read exactly the elements it owns), so the line
+//           never has to be staged through LDS.
+// All inputs of the thread are gathered before anything is written, so `in` may equal `out`
+// when the slot is a single wavefront (in-order LDS) -- see fft_forward.
+template <typename R, int N, int P_, bool REGTW, bool FROMREG>
+__device__ __forceinline__ void fft_pass(const cx<R>* in, cx<R>* out, const cx<R>* tw, int t) {
     using P = Plan<N>;
     constexpr int RADIX = P::radix[P_];
     constexpr int NS_ = plan_ns(P::radix, P_);
     constexpr int NB = N / RADIX;
     static_assert(NB % P::TPR == 0, "plan must give every thread the same number of butterflies");
+    constexpr int NBT = NB / P::TPR;
+    static_assert(!FROMREG || P_ == 0, "register input only for the first pass");
     constexpr int WOFF = [] {
         int n = 0;
         for (int p = 1; p < P_; ++p) n += (N / P::radix[p] / P::TPR) * (P::radix[p] - 1);
         return n;
     }();
+    cx<R> v[NBT][RADIX];
 #pragma unroll
-    for (int b = 0; b < NB / P::TPR; ++b) {
+    for (int b = 0; b < NBT; ++b) {
+        const int j = t + b * P::TPR;
+#pragma unroll
+        for (int q = 0; q < RADIX; ++q) {
+            if constexpr (FROMREG)
+                v[b][q] = in[b + q * NBT];
+            else
+                v[b][q] = in[lds_pad(j + q * NB)];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NBT; ++b) {
         const int j = t + b * P::TPR;
         const int k = j % NS_;
-        cx<R> v[RADIX];
-#pragma unroll
-        for (int q = 0; q < RADIX; ++q) v[q] = in[lds_pad(j + q * NB)];
         if constexpr (P_ > 0) {
             if constexpr (REGTW) {
 #pragma unroll
                 for (int q = 1; q < RADIX; ++q)
-                    v[q] = cmul(v[q], wreg[WOFF + b * (RADIX - 1) + q - 1]);
+                    v[b][q] = cmul(v[b][q], tw[WOFF + b * (RADIX - 1) + q - 1]);
             } else {
                 constexpr int TS = N / (NS_ * RADIX);
 #pragma unroll
-                for (int q = 1; q < RADIX; ++q) v[q] = cmul(v[q], wreg[q * k * TS]);
+                for (int q = 1; q < RADIX; ++q) v[b][q] = cmul(v[b][q], tw[q * k * TS]);
             }
         }
-        dftr<R, RADIX>(v);
+        dftr<R, RADIX>(v[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < NBT; ++b) {
+        const int j = t + b * P::TPR;
+        const int k = j % NS_;
         const int base = (j - k) * RADIX + k;
 #pragma unroll
-        for (int q = 0; q < RADIX; ++q) out[lds_pad(base + q * NS_)] = v[q];
+        for (int q = 0; q < RADIX; ++q) out[lds_pad(base + q * NS_)] = v[b][q];
     }
 }
 
-// Full forward FFT of one line held in padded LDS buffer `a` (natural order), scratch `b`.
-// Every thread of the slot (of the workgroup if !WSYNC) must call this.  The caller must have
-// made the input visible (fft_sync) before the call; on return the result is visible to the slot.
-// Returns the buffer that holds the result in natural order (padded: index with lds_pad).
-template <typename R, int N, bool REGTW>
-__device__ __forceinline__ cx<R>* fft_forward(cx<R>* a, cx<R>* b, const cx<R>* tw, int t) {
+template <typename R, int N, bool REGTW, int P_>
+__device__ __forceinline__ cx<R>* fft_rest(cx<R>* cur, cx<R>* other, const cx<R>* tw, int t) {
     using P = Plan<N>;
     constexpr bool WS = LineCfg<N>::WSYNC;
-    fft_pass<R, N, 0, REGTW>(a, b, tw, t);
-    fft_sync<WS>();
-    fft_pass<R, N, 1, REGTW>(b, a, tw, t);
-    fft_sync<WS>();
-    fft_pass<R, N, 2, REGTW>(a, b, tw, t);
-    fft_sync<WS>();
-    if constexpr (P::NP == 3) return b;
-    if constexpr (P::NP >= 4) {
-        fft_pass<R, N, 3, REGTW>(b, a, tw, t);
+    if constexpr (P_ >= P::NP) {
+        return cur;
+    } else {
+        cx<R>* dst = WS ? cur : other;       // single wave per slot: in place
+        fft_pass<R, N, P_, REGTW, false>(cur, dst, tw, t);
         fft_sync<WS>();
-        if constexpr (P::NP == 4) return a;
+        return fft_rest<R, N, REGTW, P_ + 1>(dst, WS ? other : cur, tw, t);
     }
-    if constexpr (P::NP == 5) {
-        fft_pass<R, N, 4, REGTW>(a, b, tw, t);
-        fft_sync<WS>();
-        return b;
-    }
-    return a;
 }
+
+// Forward FFT of one line whose elements are in registers: x[e] = line[t + e*TPR].
+// `a` (and `b` when a slot spans two wavefronts) are padded LDS buffers of NPAD elements.
+// Every thread of the slot (of the workgroup if !WSYNC) must call this.  No synchronisation is
+// needed before the call beyond "nobody still reads a"; on return the result (natural order,
+// index with lds_pad) is visible to the slot.  Returns the buffer holding it.
+template <typename R, int N, bool REGTW>
+__device__ __forceinline__ cx<R>* fft_forward_regs(const cx<R>* x, cx<R>* a, cx<R>* b,
+                                                   const cx<R>* tw, int t) {
+    fft_pass<R, N, 0, REGTW, true>(x, a, tw, t);
+    fft_sync<LineCfg<N>::WSYNC>();
+    return fft_rest<R, N, REGTW, 1>(a, b, tw, t);
+}
+
+// Same with the line staged in LDS buffer `a` (natural order, padded); the caller must have made
+// it visible (fft_sync) before the call.
+template <typename R, int N, bool REGTW>
+__device__ __forceinline__ cx<R>* fft_forward(cx<R>* a, cx<R>* b, const cx<R>* tw, int t) {
+    return fft_rest<R, N, REGTW, 0>(a, b, tw, t);
+}
+
+// LDS buffers per slot: one when a slot is a single wavefront (in-place passes), else two
+template <int N>
+constexpr int fft_nbuf() { return LineCfg<N>::WSYNC ? 1 : 2; }
 
 // whether a kernel that runs many transforms per thread should keep its twiddles in registers
 template <int N>

@@ -132,10 +132,11 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
              double cfit, cx<double>* __restrict__ C, const cx<double>* __restrict__ twg) {
     using L = LineCfg<N>;
     constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
+    constexpr int EPT = N / TPR;
     extern __shared__ __align__(16) unsigned char smem[];
     cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
     cx<double>* bufA = tw + N;
-    cx<double>* bufB = bufA + SLOTS * NPAD;
+    cx<double>* bufB = bufA + SLOTS * NPAD;    // only used when a slot spans two wavefronts
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
     const int r = blockIdx.x * SLOTS + slot;
     const int td = blockIdx.y;
@@ -143,12 +144,13 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
     for (int i = threadIdx.x; i < N; i += THREADS) tw[i] = twg[i];
     const TaskPar p = tp[task];
     const int su = r < N / 2 ? r : r - N;
-    cx<double>* a = bufA + slot * NPAD;
-    cx<double>* b = bufB + slot * NPAD;
     const double* tb = aotab + ((size_t)(p.geom * ndir + d) * 3) * (NAO * NAO);
     const bool rowin = su >= -NAO / 2 && su < NAO / 2;
     const double fy = su + 0.5;
-    for (int c = t; c < N; c += TPR) {
+    cx<double> x[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int c = t + e * TPR;
         const int sv = c < N / 2 ? c : c - N;
         const double fx = sv + 0.5;
         const double f2 = (fx * fx + fy * fy) * (1.0 / 256.0);      // L = 16 m, psfrec.py:618
@@ -164,10 +166,11 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
                               tb[2 * NAO * NAO + o];
             psd = fmax(psd, ao);                                    // :149
         }
-        a[lds_pad(c)] = {psd, 0.0};
+        x[e] = {psd, 0.0};
     }
-    __syncthreads();
-    const cx<double>* res = fft_forward<double, N, false>(a, b, tw, t);
+    __syncthreads();      // twiddle table
+    const cx<double>* res = fft_forward_regs<double, N, false>(x, bufA + slot * NPAD,
+                                                               bufB + slot * NPAD, tw, t);
     cx<double>* out = C + ((size_t)td * N + r) * (N / 2 + 1);
     for (int y = t; y <= N / 2; y += TPR) out[y] = res[lds_pad(y)];
 }
@@ -339,7 +342,7 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
         __syncthreads();
     }
     cx<R>* a = bufA + slot * NPAD;
-    cx<R>* b = bufB + slot * NPAD;
+    cx<R>* b = bufB + slot * NPAD;     // only used when a slot spans two wavefronts
     R tel[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) tel[e] = telT[(size_t)vv * N + t + e * TPR];
@@ -354,24 +357,23 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
     for (int l = 0; l < nl; l += 2) {
         const bool two = l + 1 < nl;
         const R ca = (R)lp[l].c, cb = (R)lp[two ? l + 1 : l].c;
+        cx<R> x[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int x = t + e * TPR;
             R ra = (R)0, rb = (R)0;
             if constexpr (ND == 1) {
                 ra = exp_sel<R>(ca * dreg[e], fast_exp);
                 rb = exp_sel<R>(cb * dreg[e], fast_exp);
             } else {
                 for (int d = 0; d < ndir; ++d) {
-                    const R dv = dline[d * dstride + x];
+                    const R dv = dline[d * dstride + t + e * TPR];
                     ra += exp_sel<R>(ca * dv, fast_exp);
                     rb += exp_sel<R>(cb * dv, fast_exp);
                 }
             }
-            a[lds_pad(x)] = {tel[e] * ra, two ? tel[e] * rb : (R)0};
+            x[e] = {tel[e] * ra, two ? tel[e] * rb : (R)0};
         }
-        fft_sync<WS>();
-        const cx<R>* res = fft_forward<R, N, REGTW>(a, b, twp, t);
+        const cx<R>* res = fft_forward_regs<R, N, REGTW>(x, a, b, twp, t);
         if (valid) {
             // F_a[p] = (Z[p] + conj Z[-p]) / 2,  F_b[p] = (Z[p] - conj Z[-p]) / 2i
             for (int idx = t; idx < 2 * NS; idx += TPR) {
@@ -397,7 +399,7 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
                     ((R)1 - w) * f0.x + w * f1.x, ((R)1 - w) * f0.y + w * f1.y};
             }
         }
-        fft_sync<WS>();
+        fft_sync<WS>();     // extraction reads done before the next transform overwrites
     }
 }
 
@@ -886,8 +888,9 @@ __global__ void __launch_bounds__(256) k_stamp_sum(int ntask, int nl, const doub
 }
 
 template <typename T, int N>
-constexpr size_t fft_smem(bool with_table) {
-    return (size_t)((with_table ? N : 0) + 2 * LineCfg<N>::SLOTS * LineCfg<N>::NPAD) * sizeof(T) * 2;
+constexpr size_t fft_smem(bool with_table, int nbuf) {
+    return (size_t)((with_table ? N : 0) + nbuf * LineCfg<N>::SLOTS * LineCfg<N>::NPAD) *
+           sizeof(T) * 2;
 }
 
 }  // namespace
@@ -929,7 +932,7 @@ static void allow_smem(K kernel, size_t bytes) {
 void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp,
                        const double* d_aotab, double cfit, void* d_C, const void* d_tw64) {
     DISPATCH_N(N, {
-        constexpr size_t sm = fft_smem<double, NN>(true);
+        constexpr size_t sm = fft_smem<double, NN>(true, fft_nbuf<NN>());
         allow_smem(k_psd_rowfft<NN>, sm);
         dim3 grid(NN / LineCfg<NN>::SLOTS, ntd);
         hipLaunchKernelGGL(k_psd_rowfft<NN>, grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir, d_tp,
@@ -948,7 +951,7 @@ void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const do
                         double scale2, void* d_D0t, bool f64out, const void* d_tw64) {
     DISPATCH_N(N, {
         constexpr int SL = LineCfg<NN>::SLOTS;
-        constexpr size_t sm = fft_smem<double, NN>(true);
+        constexpr size_t sm = fft_smem<double, NN>(true, fft_nbuf<NN>());
         dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntd);
         if (f64out) {
             allow_smem(k_colfft_dphi<NN, double>, sm);
@@ -992,7 +995,7 @@ static void launch_otf_t(hipStream_t s, int ntask, int ndir, int nl, const void*
                          const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
                          const void* d_samp_a, void* d_Tq, const void* d_tw64, bool fast_exp) {
     constexpr int SL = LineCfg<NN>::SLOTS;
-    constexpr size_t sm = fft_smem<R, NN>(!use_reg_twiddles<NN>());
+    constexpr size_t sm = fft_smem<R, NN>(!use_reg_twiddles<NN>(), fft_nbuf<NN>());
     allow_smem(k_otf_rowfft<R, NN, ND>, sm);
     dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntask);
     hipLaunchKernelGGL((k_otf_rowfft<R, NN, ND>), grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir, nl,
