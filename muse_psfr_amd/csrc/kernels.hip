@@ -614,11 +614,19 @@ k_conv(int nl, const double* __restrict__ pre, const R* __restrict__ ktt,
 // ------------------------------------------------------------------------------------------
 constexpr int NPIX_LANE = NS * NS / 64;   // 25
 
-struct NormEq {
-    double a[15];   // upper triangle of J^T J, row-major: (0,0)(0,1)..(0,4)(1,1)..(4,4)
-    double g[5];    // J^T r
-    double chi2;
+template <typename T>
+struct NormEqT {
+    T a[15];   // upper triangle of J^T J, row-major: (0,0)(0,1)..(0,4)(1,1)..(4,4)
+    T g[5];    // J^T r
+    T chi2;
 };
+using NormEq = NormEqT<double>;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 
 template <typename RE>
 __device__ __forceinline__ RE fit_log(RE x);
@@ -635,9 +643,11 @@ __device__ __forceinline__ double fit_exp<double>(double x) { return exp(x); }
 
 // WN = true : v = (I, p0, q0, w, n), 1/a^2 = 4 (2^(1/n) - 1) / w^2
 // WN = false: v = (I, p0, q0, a, n)
-template <typename RE, bool WN, typename DT>
+// dpix: the lane's 25 pixels in registers (STRIDE = 1) or the stamp in memory (STRIDE = 64,
+// dpix already offset by the lane)
+template <typename RE, bool WN, typename DT, int STRIDE = 1>
 __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int lane, const double* v,
-                                                  NormEq& ne) {
+                                                  NormEqT<RE>& ne) {
     RE a[15], g[5], chi2 = (RE)0;
 #pragma unroll
     for (int k = 0; k < 15; ++k) a[k] = (RE)0;
@@ -650,7 +660,8 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int lane, cons
     const double dKn_d = WN ? -(s_d + 1.0) * 0.69314718055994530942 / (n_d * n_d * s_d) : 0.0;
     const RE I = (RE)v[0], p0 = (RE)v[1], q0 = (RE)v[2], n = (RE)n_d, K = (RE)K_d;
     const RE i3 = (RE)(1.0 / v[3]), dKn = (RE)dKn_d;
-#pragma unroll 5
+    constexpr int UF = STRIDE == 1 ? 5 : 1;
+#pragma unroll UF
     for (int m = 0; m < NPIX_LANE; ++m) {
         const int o = lane + m * 64;
         const RE dp = (RE)(o / NS) - p0, dq = (RE)(o % NS) - q0;
@@ -659,7 +670,7 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int lane, cons
         const RE lg = fit_log<RE>(gg);
         const RE e = fit_exp<RE>(-n * lg);
         const RE mo = I * e;
-        const RE r = mo - (RE)dpix[m];
+        const RE r = mo - (RE)dpix[m * STRIDE];
         chi2 += r * r;
         const RE cm = mo * n / gg;
         RE J[5];
@@ -676,44 +687,64 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int lane, cons
             for (int y = x; y < 5; ++y) a[k++] += J[x] * J[y];
         }
     }
-    ne.chi2 = wave_sum((double)chi2);
+    // cross-lane sums in the evaluation type: the float phase only has to reach the basin of
+    // convergence (tol 1e-3), the polish and the f64 mode reduce in double
+    ne.chi2 = wave_sum(chi2);
 #pragma unroll
-    for (int k = 0; k < 15; ++k) ne.a[k] = wave_sum((double)a[k]);
+    for (int k = 0; k < 15; ++k) ne.a[k] = wave_sum(a[k]);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) ne.g[k] = wave_sum((double)g[k]);
+    for (int k = 0; k < 5; ++k) ne.g[k] = wave_sum(g[k]);
 }
 
-// solve (A + mu diag(A)) x = -g by Cholesky; returns false if not positive definite
-__device__ __forceinline__ bool lm_solve(const NormEq& ne, double mu, double* x) {
+// solve (A + mu diag(A)) x = -g by Cholesky; returns false if not positive definite.
+// Fully unrolled so that the 5x5 factor lives in registers (dynamic indexing put it in scratch).
+template <typename T>
+__device__ __forceinline__ bool lm_solve(const NormEqT<T>& ne, double mu, double* x) {
     double L[5][5];
-    int k = 0;
-    for (int i = 0; i < 5; ++i)
-        for (int j = i; j < 5; ++j) {
-            L[i][j] = ne.a[k];
-            L[j][i] = ne.a[k];
-            ++k;
-        }
+    {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = i; j < 5; ++j) {
+                L[i][j] = (double)ne.a[k];
+                L[j][i] = (double)ne.a[k];
+                ++k;
+            }
+    }
+#pragma unroll
     for (int i = 0; i < 5; ++i) L[i][i] *= (1.0 + mu);
+    bool ok = true;
+#pragma unroll
     for (int j = 0; j < 5; ++j) {
         double s = L[j][j];
+#pragma unroll
         for (int q = 0; q < j; ++q) s -= L[j][q] * L[j][q];
-        if (!(s > 0.0)) return false;
+        ok = ok && (s > 0.0);
         const double dj = sqrt(s);
+        const double idj = 1.0 / dj;
         L[j][j] = dj;
+#pragma unroll
         for (int i = j + 1; i < 5; ++i) {
             double t = L[i][j];
+#pragma unroll
             for (int q = 0; q < j; ++q) t -= L[i][q] * L[j][q];
-            L[i][j] = t / dj;
+            L[i][j] = t * idj;
         }
     }
+    if (!ok) return false;
     double y[5];
+#pragma unroll
     for (int i = 0; i < 5; ++i) {
-        double t = -ne.g[i];
+        double t = -(double)ne.g[i];
+#pragma unroll
         for (int q = 0; q < i; ++q) t -= L[i][q] * y[q];
         y[i] = t / L[i][i];
     }
+#pragma unroll
     for (int i = 4; i >= 0; --i) {
         double t = y[i];
+#pragma unroll
         for (int q = i + 1; q < 5; ++q) t -= L[q][i] * x[q];
         x[i] = t / L[i][i];
     }
@@ -721,15 +752,20 @@ __device__ __forceinline__ bool lm_solve(const NormEq& ne, double mu, double* x)
 }
 
 // inverse of the symmetric 5x5 (Cholesky); false if singular
-__device__ __forceinline__ bool spd_inverse(const NormEq& ne, double cov[5][5]) {
-    NormEq e = ne;
+template <typename T>
+__device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][5]) {
+    NormEqT<T> e = ne;
+    bool ok = true;
+#pragma unroll
     for (int c = 0; c < 5; ++c) {
-        for (int k = 0; k < 5; ++k) e.g[k] = (k == c) ? -1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) e.g[k] = (k == c) ? (T)-1 : (T)0;
         double x[5];
-        if (!lm_solve(e, 0.0, x)) return false;
+        ok = lm_solve(e, 0.0, x) && ok;
+#pragma unroll
         for (int k = 0; k < 5; ++k) cov[k][c] = x[k];
     }
-    return true;
+    return ok;
 }
 
 template <typename RE>
@@ -769,7 +805,7 @@ __global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restric
     // float evaluation only has to reach the basin of quadratic convergence: the fp64 polish
     // below finishes the job
     const double tol = sizeof(RE) == 4 ? 1.0e-3 : 1.0e-10;
-    NormEq ne;
+    NormEqT<RE> ne;
     moffat_accumulate<RE, true, RE>(dpix, lane, v, ne);
     double mu = 1.0e-2, nu = 2.0;
     int it = 0, status = 1;
@@ -796,7 +832,7 @@ __global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restric
             status = 0;
             break;
         }
-        NormEq nn;
+        NormEqT<RE> nn;
         double rho = -1.0;
         if (inside) {
             moffat_accumulate<RE, true, RE>(dpix, lane, vn, nn);
@@ -804,8 +840,9 @@ __global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restric
             double pred = 0.0;
             const int dg[5] = {0, 5, 9, 12, 14};
 #pragma unroll
-            for (int k = 0; k < 5; ++k) pred += dx[k] * (mu * ne.a[dg[k]] * dx[k] - ne.g[k]);
-            rho = (ne.chi2 - nn.chi2) / pred;    // NaN -> rejected
+            for (int k = 0; k < 5; ++k)
+                pred += dx[k] * (mu * (double)ne.a[dg[k]] * dx[k] - (double)ne.g[k]);
+            rho = ((double)ne.chi2 - (double)nn.chi2) / pred;    // NaN -> rejected
         }
         if (rho > 0.0) {
 #pragma unroll
@@ -824,12 +861,9 @@ __global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restric
         // The float evaluation has systematic errors of ~1e-6 in the wings (v_log/v_exp), enough
         // to move beta by a few 1e-4 on flat-topped stamps.  Polish with fp64 Gauss-Newton steps
         // from the float solution (quadratic convergence: one or two suffice).
-        double dd[NPIX_LANE];
-#pragma unroll
-        for (int m = 0; m < NPIX_LANE; ++m) dd[m] = src[lane + m * 64];
         for (int pz = 0; pz < 6 && status != 2; ++pz) {
             NormEq np;
-            moffat_accumulate<double, true, double>(dd, lane, v, np);
+            moffat_accumulate<double, true, double, 64>(src + lane, lane, v, np);
             double dx[5];
             if (!lm_solve(np, 1.0e-10, dx)) break;
             double rel = 0.0;
@@ -855,12 +889,13 @@ __global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restric
         double* o = fit + (size_t)st * NFIT;
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = al; o[4] = n;
         o[5] = fabs(v[3]);
-        o[6] = ne.chi2;
+        o[6] = (double)ne.chi2;
         o[7] = (double)it;
         double cov[5][5];
         const double dof = (double)(NS * NS - 5);
         if (spd_inverse(ne, cov)) {
-            const double s = ne.chi2 / dof;
+            const double s = (double)ne.chi2 / dof;
+#pragma unroll
             for (int k = 0; k < 5; ++k) o[8 + k] = sqrt(fmax(cov[k][k] * s, 0.0));
             const double da = 2.0 * sq;
             const double dn = -al * exp2(1.0 / n) * 0.69314718055994530942 / (sq * n * n);
