@@ -100,6 +100,11 @@ __device__ __forceinline__ void dftr(cx<R>* v) {
 template <int N>
 struct Plan;
 template <>
+struct Plan<64> {     // small frames of the FFT convolution (k_conv_fft): 8 threads per line
+    static constexpr int NP = 2, TPR = 8, SLOTS = 32;
+    static constexpr int radix[5] = {8, 8, 1, 1, 1};
+};
+template <>
 struct Plan<128> {
     static constexpr int NP = 3, TPR = 16, SLOTS = 16;
     static constexpr int radix[5] = {8, 4, 4, 1, 1};

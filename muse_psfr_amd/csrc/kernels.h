@@ -10,6 +10,7 @@ constexpr int NS = 40;       // dimpsf, psfrec.py:658
 constexpr int KS = 41;       // Moffat kernel side, psfrec.py:911-916
 constexpr int NAO = 80;      // AO-corrected zone, psfrec.py:103, 138
 constexpr int NFIT = 16;
+constexpr int KHAT = 33 * 64;  // complex entries of one kernel spectrum (k_khat)
 constexpr int MAXLGS = 4;
 
 // per-task scalars of the PSD model
@@ -74,6 +75,10 @@ void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, c
                     double* d_pre, bool f64);
 void launch_conv(hipStream_t s, int ntask, int nl, const double* d_pre, const void* d_ktt,
                  const void* d_kmuse, double* d_fin, bool f64);
+void launch_khat(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
+                 void* d_khat);
+void launch_conv_fft(hipStream_t s, int ntask, int nl, const double* d_pre, const void* d_khat_tt,
+                     const void* d_khat_muse, double* d_fin);
 void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit, bool f64);
 void launch_stamp_sum(hipStream_t s, int ntask, int nl, const double* d_fin, double* d_sum,
                       int accumulate);

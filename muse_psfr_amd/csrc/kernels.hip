@@ -604,6 +604,252 @@ k_conv(int nl, const double* __restrict__ pre, const R* __restrict__ ktt,
 }
 
 // ------------------------------------------------------------------------------------------
+// K_CONV (mixed mode): the same two 'same' convolutions through 64-point FFTs in LDS.
+// The outputs needed are indices [20, 60) of the 80-long linear convolution, which a circular
+// convolution of length 64 leaves un-aliased, so 64x64 frames suffice (scipy pads to 80,
+// psfrec.py:917).  Per convolution and stamp: 20 row-pair transforms (two real rows per complex
+// FFT), 32 column transforms forth and back with the kernel spectrum multiplied in between (the
+// real DC and Nyquist columns share one complex column), 20 row-pair inverse transforms --
+// ~7x fewer instructions than the direct form.  One workgroup per stamp, 32 lines of 8 threads.
+// khat[k][kx], k in [0, 33), kx in [0, 64): kernel spectrum (1/4096 folded in), from K_KHAT.
+// ------------------------------------------------------------------------------------------
+constexpr int CF = 64;            // frame side
+constexpr int CFH = CF / 2;       // 32
+constexpr int CFP = 36;           // pitch of the half-spectrum frame (bank-conflict free)
+constexpr int CFB = CF + CF / 8;  // padded line buffer
+
+struct Tw64 {
+    cx<float> w[7];
+    __device__ __forceinline__ void init(int t) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            float sn, cs;
+            sincospif(-2.0f * (float)(q * t) / 64.0f, &sn, &cs);
+            w[q - 1] = {cs, sn};
+        }
+    }
+};
+
+__device__ __forceinline__ cx<float> conjf(cx<float> a) { return {a.x, -a.y}; }
+
+// rows ra, rb of the real image `im` (pitch NS, zero beyond NS) -> half spectra in F
+__device__ __forceinline__ void cf_rows_forward(const float* im, int nrow, cx<float> (*F)[CFP],
+                                                cx<float>* buf, const Tw64& tw, int slot, int t) {
+    const int ra = 2 * slot, rb = ra + 1;
+    cx<float> x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = t + 8 * e;
+        x[e] = {(c < NS && ra < nrow) ? im[ra * NS + c] : 0.f,
+                (c < NS && rb < nrow) ? im[rb * NS + c] : 0.f};
+    }
+    const cx<float>* res = fft_forward_regs<float, CF, true>(x, buf, buf, tw.w, t);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = t + 8 * e;
+        const cx<float> zk = res[lds_pad(k)], zm = res[lds_pad((CF - k) % CF)];
+        if (k == 0) {
+            const cx<float> zn = res[lds_pad(CFH)];
+            F[ra][0] = {zk.x, zn.x};      // (DC, Nyquist) of row ra, both real
+            F[rb][0] = {zk.y, zn.y};
+        } else {
+            F[ra][k] = {0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
+            F[rb][k] = {0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};
+        }
+    }
+}
+
+// column `slot` of F (rows < nrow_in non-zero) -> forward transform along the rows, in `buf`
+__device__ __forceinline__ const cx<float>* cf_col_forward(cx<float> (*F)[CFP], int nrow_in,
+                                                           cx<float>* buf, const Tw64& tw,
+                                                           int slot, int t) {
+    cx<float> x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int r = t + 8 * e;
+        x[e] = r < nrow_in ? F[r][slot] : cx<float>{0.f, 0.f};
+    }
+    return fft_forward_regs<float, CF, true>(x, buf, buf, tw.w, t);
+}
+
+// split the packed column 0 spectrum into the DC column and the Nyquist column at kx
+__device__ __forceinline__ void cf_split0(const cx<float>* res, int kx, cx<float>& a0,
+                                          cx<float>& a32) {
+    const cx<float> p = res[lds_pad(kx)], pm = res[lds_pad((CF - kx) % CF)];
+    a0 = {0.5f * (p.x + pm.x), 0.5f * (p.y - pm.y)};
+    a32 = {0.5f * (p.y + pm.y), -0.5f * (p.x - pm.x)};
+}
+
+__global__ void __launch_bounds__(256)
+k_conv_fft(int nl, const double* __restrict__ pre, const cx<float>* __restrict__ khat_tt,
+           const cx<float>* __restrict__ khat_muse, double* __restrict__ fin) {
+    __shared__ float img[NS * NS];
+    __shared__ cx<float> F[CF][CFP];
+    __shared__ cx<float> bufs[CFH][CFB];
+    const int l = blockIdx.x, task = blockIdx.y;
+    const int slot = threadIdx.x >> 3, t = threadIdx.x & 7;
+    Tw64 tw;
+    tw.init(t);
+    const double* src = pre + ((size_t)task * nl + l) * NS * NS;
+    for (int e = threadIdx.x; e < NS * NS; e += 256) img[e] = (float)src[e];
+    cx<float>* buf = bufs[slot];
+    for (int pass = 0; pass < 2; ++pass) {
+        const cx<float>* __restrict__ kh = pass == 0 ? khat_tt + (size_t)task * (CFH + 1) * CF
+                                                     : khat_muse + (size_t)l * (CFH + 1) * CF;
+        __syncthreads();
+        if (slot < NS / 2) cf_rows_forward(img, NS, F, buf, tw, slot, t);
+        __syncthreads();
+        {   // columns: forward, multiply by the kernel spectrum, inverse (conjugation trick)
+            const cx<float>* res = cf_col_forward(F, NS, buf, tw, slot, t);
+            cx<float> y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kx = t + 8 * e;
+                cx<float> v;
+                if (slot == 0) {
+                    cx<float> a0, a32;
+                    cf_split0(res, kx, a0, a32);
+                    const cx<float> b0 = cmul(a0, kh[kx]), b32 = cmul(a32, kh[CFH * CF + kx]);
+                    v = {b0.x - b32.y, b0.y + b32.x};
+                } else {
+                    v = cmul(res[lds_pad(kx)], kh[slot * CF + kx]);
+                }
+                y[e] = conjf(v);
+            }
+            const cx<float>* r2 = fft_forward_regs<float, CF, true>(y, buf, buf, tw.w, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = t + 8 * e;
+                if (r >= KS / 2 && r < KS / 2 + NS) F[r][slot] = conjf(r2[lds_pad(r)]);
+            }
+        }
+        __syncthreads();
+        if (slot < NS / 2) {   // inverse rows, two output rows per complex transform
+            const int ra = KS / 2 + 2 * slot, rb = ra + 1;
+            cx<float> z[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = t + 8 * e;
+                const int kk = k <= CFH ? k : CF - k;
+                cx<float> a, b;
+                if (kk == 0) {
+                    a = {F[ra][0].x, 0.f};
+                    b = {F[rb][0].x, 0.f};
+                } else if (kk == CFH) {
+                    a = {F[ra][0].y, 0.f};
+                    b = {F[rb][0].y, 0.f};
+                } else {
+                    a = F[ra][kk];
+                    b = F[rb][kk];
+                    if (k > CFH) { a = conjf(a); b = conjf(b); }
+                }
+                z[e] = {a.x - b.y, -(a.y + b.x)};      // conj(A + iB)
+            }
+            const cx<float>* res = fft_forward_regs<float, CF, true>(z, buf, buf, tw.w, t);
+            // y_a = Re conj(res) = res.x, y_b = Im conj(res) = -res.y at columns [20, 60)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = t + 8 * e;
+                if (c >= KS / 2 && c < KS / 2 + NS) {
+                    const cx<float> v = res[lds_pad(c)];
+                    const int i = 2 * slot, j = c - KS / 2;
+                    if (pass == 0) {
+                        img[i * NS + j] = v.x;
+                        img[(i + 1) * NS + j] = -v.y;
+                    } else {
+                        double* out = fin + ((size_t)task * nl + l) * NS * NS;
+                        out[i * NS + j] = (double)v.x;
+                        out[(i + 1) * NS + j] = (double)(-v.y);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// K_KHAT: spectrum of astropy's Moffat2DKernel(gamma, alpha, 41, 41) (psfrec.py:916, 927) on the
+// 64x64 frame, transposed half plane khat[k][kx], with the 1/4096 of the inverse folded in.
+__global__ void __launch_bounds__(256)
+k_khat(const double* __restrict__ gam, const double* __restrict__ alp,
+       cx<float>* __restrict__ khat) {
+    __shared__ float ker[KS * NS + KS * (KS - NS) + 64];   // [41][41] stored with pitch KS
+    __shared__ cx<float> F[CF][CFP];
+    __shared__ cx<float> bufs[CFH][CFB];
+    __shared__ double part[4];
+    __shared__ double tot;
+    const int kid = blockIdx.x;
+    const int slot = threadIdx.x >> 3, t = threadIdx.x & 7;
+    Tw64 tw;
+    tw.init(t);
+    const double g2 = gam[kid] * gam[kid], al = alp[kid];
+    constexpr int NV = (KS * KS + 255) / 256;
+    double vals[NV];
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+        const int e = threadIdx.x + m * 256;
+        double v = 0.0;
+        if (e < KS * KS) {
+            const int dy = e / KS - KS / 2, dx = e % KS - KS / 2;
+            v = pow(1.0 + (double)(dx * dx + dy * dy) / g2, -al);
+        }
+        vals[m] = v;
+        s += v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tot = (part[0] + part[1]) + (part[2] + part[3]);
+    __syncthreads();
+    const double inv = 1.0 / (tot * (double)(CF * CF));
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+        const int e = threadIdx.x + m * 256;
+        if (e < KS * KS) ker[e] = (float)(vals[m] * inv);
+    }
+    __syncthreads();
+    // rows (41 of them, pitch 41): reuse the row-pair transform with a 41-wide image
+    if (slot < (KS + 1) / 2) {
+        const int ra = 2 * slot, rb = ra + 1;
+        cx<float> x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = t + 8 * e;
+            x[e] = {(c < KS) ? ker[ra * KS + c] : 0.f, (c < KS && rb < KS) ? ker[rb * KS + c] : 0.f};
+        }
+        const cx<float>* res = fft_forward_regs<float, CF, true>(x, bufs[slot], bufs[slot], tw.w, t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = t + 8 * e;
+            const cx<float> zk = res[lds_pad(k)], zm = res[lds_pad((CF - k) % CF)];
+            if (k == 0) {
+                const cx<float> zn = res[lds_pad(CFH)];
+                F[ra][0] = {zk.x, zn.x};
+                F[rb][0] = {zk.y, zn.y};
+            } else {
+                F[ra][k] = {0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
+                F[rb][k] = {0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};
+            }
+        }
+    }
+    __syncthreads();
+    const cx<float>* res = cf_col_forward(F, KS, bufs[slot], tw, slot, t);
+    cx<float>* out = khat + (size_t)kid * (CFH + 1) * CF;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kx = t + 8 * e;
+        if (slot == 0) {
+            cx<float> a0, a32;
+            cf_split0(res, kx, a0, a32);
+            out[kx] = a0;
+            out[CFH * CF + kx] = a32;
+        } else {
+            out[slot * CF + kx] = res[lds_pad(kx)];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K_FIT: 5-parameter circular Moffat least-squares fit per stamp (fit_psf_cube psfrec.py:861-871
 // -> mpdaf Image.moffat_fit(circular=True, fit_back=False)): I (1 + ((p-p0)^2+(q-q0)^2)/a^2)^-n,
 // unweighted, all 1600 pixels.  One wavefront per stamp, 25 pixels per lane held in registers.
@@ -1087,6 +1333,18 @@ void launch_conv(hipStream_t s, int ntask, int nl, const double* d_pre, const vo
         hipLaunchKernelGGL(k_conv<float>, grid, dim3(256), sm, s, nl, d_pre, (const float*)d_ktt,
                            (const float*)d_kmuse, d_fin);
     }
+}
+
+void launch_khat(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
+                 void* d_khat) {
+    if (nker <= 0) return;
+    hipLaunchKernelGGL(k_khat, dim3(nker), dim3(256), 0, s, d_gamma, d_alpha, (cx<float>*)d_khat);
+}
+
+void launch_conv_fft(hipStream_t s, int ntask, int nl, const double* d_pre, const void* d_khat_tt,
+                     const void* d_khat_muse, double* d_fin) {
+    hipLaunchKernelGGL(k_conv_fft, dim3(nl, ntask), dim3(256), 0, s, nl, d_pre,
+                       (const cx<float>*)d_khat_tt, (const cx<float>*)d_khat_muse, d_fin);
 }
 
 void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit, bool f64) {

@@ -63,6 +63,7 @@ struct mpsfr_ctx {
     int chunk_tasks = 0;   // 0 = automatic
     bool fast_exp = false;
     bool profile = false;
+    bool fft_conv = true;   // mixed mode: convolutions through 64-point FFTs
     // constant tables
     DevBuf tw64, twR, tel, rows;
     // per-call tables
@@ -318,6 +319,8 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         c->chunk_tasks = (int)value;
     } else if (!strcmp(key, "fast_exp")) {
         c->fast_exp = value != 0.0;
+    } else if (!strcmp(key, "fft_conv")) {
+        c->fft_conv = value != 0.0;
     } else if (!strcmp(key, "profile")) {
         c->profile = value != 0.0;
     } else {
@@ -447,7 +450,16 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         launch_gtable(s, N, nl, (const LamPar*)c->lp.p, c->tw64.p, (int*)c->samp_p.p,
                       c->samp_a.p, c->G.p, c->f64);
     }
-    {
+    const bool use_fft_conv = !c->f64 && c->fft_conv;
+    if (use_fft_conv) {
+        // kernel spectra for the FFT convolution: ktt/kmuse hold [n][33][64] complex float
+        if ((rc = ensure(c, c->ktt, (size_t)ntask * KHAT * 2 * sizeof(float)))) return rc;
+        if ((rc = ensure(c, c->kmuse, (size_t)nl * KHAT * 2 * sizeof(float)))) return rc;
+        ProfScope ps(c, K_MOFFAT_KERNELS);
+        launch_khat(s, ntask, (const double*)c->gam.p, (const double*)c->alp.p, c->ktt.p);
+        launch_khat(s, nl, (const double*)c->gam.p + ntask, (const double*)c->alp.p + ntask,
+                    c->kmuse.p);
+    } else {
         ProfScope ps(c, K_MOFFAT_KERNELS);
         launch_moffat_kernels(s, ntask, (const double*)c->gam.p, (const double*)c->alp.p,
                               c->ktt.p, c->f64);
@@ -523,9 +535,15 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         double* d_fin = d_fin_all ? d_fin_all + (size_t)t0 * nl * per_stamp : (double*)c->fin.p;
         {
             ProfScope ps(c, K_CONV);
-            const size_t koff = (size_t)t0 * KS * KS * rsize(c);
-            launch_conv(s, tc, nl, (const double*)c->pre.p, (const char*)c->ktt.p + koff,
-                        c->kmuse.p, d_fin, c->f64);
+            if (use_fft_conv) {
+                const size_t koff = (size_t)t0 * KHAT * 2 * sizeof(float);
+                launch_conv_fft(s, tc, nl, (const double*)c->pre.p, (const char*)c->ktt.p + koff,
+                                c->kmuse.p, d_fin);
+            } else {
+                const size_t koff = (size_t)t0 * KS * KS * rsize(c);
+                launch_conv(s, tc, nl, (const double*)c->pre.p, (const char*)c->ktt.p + koff,
+                            c->kmuse.p, d_fin, c->f64);
+            }
         }
         if (fit_out) {
             ProfScope ps(c, K_FIT);
