@@ -59,7 +59,7 @@ def main():
     ap.add_argument('--npsflin', type=int, default=1)
     ap.add_argument('--precision', default='mixed', choices=['mixed', 'f64'])
     ap.add_argument('--chunk', type=int, default=0)
-    ap.add_argument('--fast-exp', type=int, default=0)
+    ap.add_argument('--fast-exp', type=int, default=1)
     ap.add_argument('--cpu-rows', type=int, default=-1,
                     help='rows of the CPU-baseline sample (-1: two per core, 0: skip)')
     a = ap.parse_args()

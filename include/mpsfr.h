@@ -57,8 +57,10 @@ int mpsfr_create(mpsfr_ctx** out, int device_id, int dim, int dimpsf, double pix
 void mpsfr_destroy(mpsfr_ctx* ctx);
 const char* mpsfr_last_error(void);
 
-/* Tunables: "chunk_tasks" (tasks per pipeline pass, 0 = automatic), "fast_exp" (0/1, mixed mode only),
- * "profile" (0/1: bracket every kernel launch with HIP events on the context's stream). */
+/* Tunables: "chunk_tasks" (tasks per pipeline pass, 0 = automatic); "fast_exp" (mixed mode only,
+ * default 1: hardware exp2 for the OTF); "fft_conv" (mixed mode only, default 1: the two 41x41
+ * convolutions through 64-point FFTs instead of the direct form); "profile" (0/1: bracket every
+ * kernel launch with HIP events on the context's stream). */
 int mpsfr_set_option(mpsfr_ctx* ctx, const char* key, double value);
 
 /* Batched replacement of  Parallel(n_jobs)(delayed(compute_psf)(*args) ...)  (psfrec.py:1082-1083)

@@ -303,21 +303,23 @@ k_moffat_kernels(const double* __restrict__ gam, const double* __restrict__ alp,
 // directions of psfrec.py:674 commutes with the FFT), forward FFT along the line, and the
 // bilinear-weighted extraction of the NS sampled positions -> Tq[task][l][v][i].
 // ------------------------------------------------------------------------------------------
-template <typename R>
-__device__ __forceinline__ R exp_sel(R x, bool fast);
-template <>
-__device__ __forceinline__ float exp_sel<float>(float x, bool fast) {
-    return fast ? __expf(x) : expf(x);
+template <typename R, bool FAST>
+__device__ __forceinline__ R exp_sel(R x) {
+    if constexpr (sizeof(R) == 8) {
+        return exp(x);
+    } else if constexpr (FAST) {
+        return __expf(x);      // v_exp_f32(x log2 e): 2 instructions instead of ~12
+    } else {
+        return expf(x);
+    }
 }
-template <>
-__device__ __forceinline__ double exp_sel<double>(double x, bool) { return exp(x); }
 
-template <typename R, int N, int ND>
+template <typename R, int N, int ND, bool FASTEXP>
 __global__ void __launch_bounds__(LineCfg<N>::THREADS)
 k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ telT,
              const LamPar* __restrict__ lp, const int* __restrict__ samp_p,
              const R* __restrict__ samp_a, cx<R>* __restrict__ Tq,
-             const cx<double>* __restrict__ twg, int fast_exp) {
+             const cx<double>* __restrict__ twg) {
     using L = LineCfg<N>;
     constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
     constexpr int EPT = N / TPR;
@@ -362,13 +364,13 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
         for (int e = 0; e < EPT; ++e) {
             R ra = (R)0, rb = (R)0;
             if constexpr (ND == 1) {
-                ra = exp_sel<R>(ca * dreg[e], fast_exp);
-                rb = exp_sel<R>(cb * dreg[e], fast_exp);
+                ra = exp_sel<R, FASTEXP>(ca * dreg[e]);
+                rb = exp_sel<R, FASTEXP>(cb * dreg[e]);
             } else {
                 for (int d = 0; d < ndir; ++d) {
                     const R dv = dline[d * dstride + t + e * TPR];
-                    ra += exp_sel<R>(ca * dv, fast_exp);
-                    rb += exp_sel<R>(cb * dv, fast_exp);
+                    ra += exp_sel<R, FASTEXP>(ca * dv);
+                    rb += exp_sel<R, FASTEXP>(cb * dv);
                 }
             }
             x[e] = {tel[e] * ra, two ? tel[e] * rb : (R)0};
@@ -1271,41 +1273,38 @@ void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const
                            (float*)d_out);
 }
 
-template <typename R, int NN, int ND>
+template <typename R, int NN, int ND, bool FE>
 static void launch_otf_t(hipStream_t s, int ntask, int ndir, int nl, const void* d_D0t,
                          const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
-                         const void* d_samp_a, void* d_Tq, const void* d_tw64, bool fast_exp) {
+                         const void* d_samp_a, void* d_Tq, const void* d_tw64) {
     constexpr int SL = LineCfg<NN>::SLOTS;
     constexpr size_t sm = fft_smem<R, NN>(!use_reg_twiddles<NN>(), fft_nbuf<NN>());
-    allow_smem(k_otf_rowfft<R, NN, ND>, sm);
+    allow_smem(k_otf_rowfft<R, NN, ND, FE>, sm);
     dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntask);
-    hipLaunchKernelGGL((k_otf_rowfft<R, NN, ND>), grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir, nl,
-                       (const R*)d_D0t, (const R*)d_tel, d_lp, d_samp_p, (const R*)d_samp_a,
-                       (cx<R>*)d_Tq, (const cx<double>*)d_tw64, fast_exp ? 1 : 0);
+    hipLaunchKernelGGL((k_otf_rowfft<R, NN, ND, FE>), grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir,
+                       nl, (const R*)d_D0t, (const R*)d_tel, d_lp, d_samp_p, (const R*)d_samp_a,
+                       (cx<R>*)d_Tq, (const cx<double>*)d_tw64);
 }
 
+#define OTF_ARGS s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p, d_samp_a, d_Tq, d_tw64
 void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
                        const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
                        const void* d_samp_a, void* d_Tq, const void* d_tw64, bool f64,
                        bool fast_exp) {
     DISPATCH_N(N, {
         if (f64) {
-            if (ndir == 1)
-                launch_otf_t<double, NN, 1>(s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p,
-                                            d_samp_a, d_Tq, d_tw64, false);
-            else
-                launch_otf_t<double, NN, 0>(s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p,
-                                            d_samp_a, d_Tq, d_tw64, false);
+            if (ndir == 1) launch_otf_t<double, NN, 1, false>(OTF_ARGS);
+            else launch_otf_t<double, NN, 0, false>(OTF_ARGS);
+        } else if (fast_exp) {
+            if (ndir == 1) launch_otf_t<float, NN, 1, true>(OTF_ARGS);
+            else launch_otf_t<float, NN, 0, true>(OTF_ARGS);
         } else {
-            if (ndir == 1)
-                launch_otf_t<float, NN, 1>(s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p,
-                                           d_samp_a, d_Tq, d_tw64, fast_exp);
-            else
-                launch_otf_t<float, NN, 0>(s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p,
-                                           d_samp_a, d_Tq, d_tw64, fast_exp);
+            if (ndir == 1) launch_otf_t<float, NN, 1, false>(OTF_ARGS);
+            else launch_otf_t<float, NN, 0, false>(OTF_ARGS);
         }
     })
 }
+#undef OTF_ARGS
 
 void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, const void* d_G,
                     double* d_pre, bool f64) {

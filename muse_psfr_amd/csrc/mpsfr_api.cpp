@@ -61,7 +61,7 @@ struct mpsfr_ctx {
     hipStream_t stream = nullptr;
     // options
     int chunk_tasks = 0;   // 0 = automatic
-    bool fast_exp = false;
+    bool fast_exp = true;    // mixed mode: exp(x) = v_exp_f32(x log2 e)
     bool profile = false;
     bool fft_conv = true;   // mixed mode: convolutions through 64-point FFTs
     // constant tables
