@@ -124,65 +124,99 @@ __global__ void __launch_bounds__(256) k_tel_otf(int N, const uint64_t* __restri
 // ------------------------------------------------------------------------------------------
 // K_PSD_ROWFFT: residual phase PSD (simul_psd_wfm psfrec.py:36-151: psd_fit :616-626 outside /
 // max(fit, AO) inside the 80x80 corrected zone :148-149) generated on the fly in FFT-native
-// layout, row r, and its forward FFT along the row.  C[td][r][y], y in [0, N/2].
+// layout, and its forward FFT along the row.
+//
+// Only N/2 + 40 of the N rows are distinct: outside the corrected zone the PSD depends on the row
+// only through (su + 1/2)^2 (half-pixel grid of psfrec.py:618), so rows su and -1-su are equal.
+// The distinct rows are su in [-40, N/2), stored compactly as C[td][su + 40][y], y in [0, N/2];
+// K_COLFFT_DPHI mirrors them back.  Two real rows share one complex transform
+// (z = row_a + i row_b; C_a = (Z[y] + conj Z[-y])/2, C_b = (Z[y] - conj Z[-y])/2i).
 // ------------------------------------------------------------------------------------------
+template <int N>
+constexpr int psd_rows() { return N / 2 + NAO / 2; }
+
+__device__ __forceinline__ int psd_row_slot(int r, int N) {   // native row -> compact row
+    int su = r < N / 2 ? r : r - N;
+    if (su < -NAO / 2) su = -1 - su;
+    return su + NAO / 2;
+}
+
+// x^(-11/6) = cbrt(sqrt(x)) / x^2: ~3x cheaper than the generic fp64 pow, same accuracy class
+__device__ __forceinline__ double pow_m11_6(double x) { return cbrt(sqrt(x)) / (x * x); }
+
+template <int N>
+__device__ __forceinline__ double psd_value(int su, int sv, const TaskPar& p, double cfit,
+                                            const double* __restrict__ tb) {
+    const double fx = sv + 0.5, fy = su + 0.5;
+    const double f2 = (fx * fx + fy * fy) * (1.0 / 256.0);          // L = 16 m, psfrec.py:618
+    double psd = 0.0;
+    if (f2 >= 2.25)                                                 // f >= fc = 1.5, :624
+        psd = cfit * p.r0m53 * pow_m11_6(f2 + p.inv_l0sq);
+    if (su >= -NAO / 2 && su < NAO / 2 && sv >= -NAO / 2 && sv < NAO / 2) {
+        const int ia = su < 0 ? su + NAO : su, ib = sv < 0 ? sv + NAO : sv;
+        const double g2 = (double)(su * su + sv * sv) * (1.0 / 256.0);
+        const double vk = 0.0229 * p.r0m53 * pow_m11_6(g2 + p.inv_l0sq);   // :569-571
+        const int o = ia * NAO + ib;
+        const double ao = vk * (p.cn2_0 * tb[o] + p.cn2_1 * tb[NAO * NAO + o]) +
+                          tb[2 * NAO * NAO + o];
+        psd = fmax(psd, ao);                                        // :149
+    }
+    return psd;
+}
+
 template <int N>
 __global__ void __launch_bounds__(LineCfg<N>::THREADS)
 k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict__ aotab,
              double cfit, cx<double>* __restrict__ C, const cx<double>* __restrict__ twg) {
     using L = LineCfg<N>;
     constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
-    constexpr int EPT = N / TPR;
+    constexpr int EPT = N / TPR, NR = psd_rows<N>();
     extern __shared__ __align__(16) unsigned char smem[];
     cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
     cx<double>* bufA = tw + N;
     cx<double>* bufB = bufA + SLOTS * NPAD;    // only used when a slot spans two wavefronts
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
-    const int r = blockIdx.x * SLOTS + slot;
+    const int pair = blockIdx.x * SLOTS + slot;             // rows 2 pair, 2 pair + 1 (compact)
     const int td = blockIdx.y;
     const int task = td / ndir, d = td % ndir;
     for (int i = threadIdx.x; i < N; i += THREADS) tw[i] = twg[i];
     const TaskPar p = tp[task];
-    const int su = r < N / 2 ? r : r - N;
+    const bool valid = 2 * pair < NR;
+    const int ca = valid ? 2 * pair : 0, cb = ca + 1;       // NR is even
+    const int sua = ca - NAO / 2, sub = cb - NAO / 2;
     const double* tb = aotab + ((size_t)(p.geom * ndir + d) * 3) * (NAO * NAO);
-    const bool rowin = su >= -NAO / 2 && su < NAO / 2;
-    const double fy = su + 0.5;
     cx<double> x[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int c = t + e * TPR;
         const int sv = c < N / 2 ? c : c - N;
-        const double fx = sv + 0.5;
-        const double f2 = (fx * fx + fy * fy) * (1.0 / 256.0);      // L = 16 m, psfrec.py:618
-        double psd = 0.0;
-        if (f2 >= 2.25)                                             // f >= fc = 1.5, :624
-            psd = cfit * p.r0m53 * pow(f2 + p.inv_l0sq, -11.0 / 6.0);
-        if (rowin && sv >= -NAO / 2 && sv < NAO / 2) {
-            const int ia = su < 0 ? su + NAO : su, ib = sv < 0 ? sv + NAO : sv;
-            const double g2 = (double)(su * su + sv * sv) * (1.0 / 256.0);
-            const double vk = 0.0229 * p.r0m53 * pow(g2 + p.inv_l0sq, -11.0 / 6.0);   // :569-571
-            const int o = ia * NAO + ib;
-            const double ao = vk * (p.cn2_0 * tb[o] + p.cn2_1 * tb[NAO * NAO + o]) +
-                              tb[2 * NAO * NAO + o];
-            psd = fmax(psd, ao);                                    // :149
-        }
-        x[e] = {psd, 0.0};
+        x[e] = {psd_value<N>(sua, sv, p, cfit, tb), psd_value<N>(sub, sv, p, cfit, tb)};
     }
     __syncthreads();      // twiddle table
     const cx<double>* res = fft_forward_regs<double, N, false>(x, bufA + slot * NPAD,
                                                                bufB + slot * NPAD, tw, t);
-    cx<double>* out = C + ((size_t)td * N + r) * (N / 2 + 1);
-    for (int y = t; y <= N / 2; y += TPR) out[y] = res[lds_pad(y)];
+    if (valid) {
+        cx<double>* oa = C + ((size_t)td * NR + ca) * (N / 2 + 1);
+        cx<double>* ob = oa + (N / 2 + 1);
+        for (int y = t; y <= N / 2; y += TPR) {
+            const cx<double> z = res[lds_pad(y)], zm = res[lds_pad(y == 0 ? 0 : N - y)];
+            oa[y] = {0.5 * (z.x + zm.x), 0.5 * (z.y - zm.y)};
+            ob[y] = {0.5 * (z.y + zm.y), -0.5 * (z.x - zm.x)};
+        }
+    }
 }
 
-// K_DC_SUM: S00[td] = Re sum_r C[td][r][0] = sum of the PSD (bg[0,0], psfrec.py:721)
+// K_DC_SUM: S00[td] = Re sum_r C[td][r][0] = sum of the PSD (bg[0,0], psfrec.py:721); compact rows
+// with su >= 40 stand for two rows.
 template <int N>
 __global__ void __launch_bounds__(256) k_dc_sum(const cx<double>* __restrict__ C,
                                                 double* __restrict__ s00) {
+    constexpr int NR = psd_rows<N>();
     __shared__ double part[4];
     const int td = blockIdx.x;
     double s = 0.0;
-    for (int r = threadIdx.x; r < N; r += 256) s += C[((size_t)td * N + r) * (N / 2 + 1)].x;
+    for (int r = threadIdx.x; r < NR; r += 256)
+        s += (r >= NAO ? 2.0 : 1.0) * C[((size_t)td * NR + r) * (N / 2 + 1)].x;
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -207,13 +241,13 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
     const int y0 = blockIdx.x * SLOTS;
     const int td = blockIdx.y;
     for (int i = threadIdx.x; i < N; i += THREADS) tw[i] = twg[i];
-    const cx<double>* Ct = C + (size_t)td * N * (N / 2 + 1);
+    const cx<double>* Ct = C + (size_t)td * psd_rows<N>() * (N / 2 + 1);
     // SLOTS adjacent columns: consecutive lanes read consecutive columns of one row
     for (int idx = threadIdx.x; idx < N * SLOTS; idx += THREADS) {
         const int r = idx / SLOTS, sl = idx % SLOTS;
         const int y = y0 + sl;
         cx<double> v = {0.0, 0.0};
-        if (y <= N / 2) v = Ct[(size_t)r * (N / 2 + 1) + y];
+        if (y <= N / 2) v = Ct[(size_t)psd_row_slot(r, N) * (N / 2 + 1) + y];
         bufA[sl * NPAD + lds_pad(r)] = v;
     }
     __syncthreads();
@@ -1217,7 +1251,8 @@ void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d
     DISPATCH_N(N, {
         constexpr size_t sm = fft_smem<double, NN>(true, fft_nbuf<NN>());
         allow_smem(k_psd_rowfft<NN>, sm);
-        dim3 grid(NN / LineCfg<NN>::SLOTS, ntd);
+        constexpr int NPAIR = psd_rows<NN>() / 2, SL = LineCfg<NN>::SLOTS;
+        dim3 grid((NPAIR + SL - 1) / SL, ntd);
         hipLaunchKernelGGL(k_psd_rowfft<NN>, grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir, d_tp,
                            d_aotab, cfit, (cx<double>*)d_C, (const cx<double>*)d_tw64);
     })

@@ -475,13 +475,14 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         TC = (4096 + nl - 1) / nl;
         if (TC < 8) TC = 8;
         if (TC > 256) TC = 256;
-        const double per_task = (double)ndir * N * H1 * 16.0;
+        const double per_task = (double)ndir * (N / 2 + NAO / 2) * H1 * 16.0;
         const int cap = (int)(4.0 * 1024 * 1024 * 1024 / per_task);
         if (TC > cap) TC = cap < 1 ? 1 : cap;
     }
     if (TC > ntask) TC = ntask;
     const size_t per_stamp = (size_t)NS * NS;
-    if ((rc = ensure(c, c->C, (size_t)TC * ndir * N * H1 * 2 * sizeof(double)))) return rc;
+    // row FFTs of the PSD: only the N/2 + 40 distinct rows are stored (K_PSD_ROWFFT)
+    if ((rc = ensure(c, c->C, (size_t)TC * ndir * (N / 2 + NAO / 2) * H1 * 2 * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->s00, (size_t)TC * ndir * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->D0t, (size_t)TC * ndir * H1 * N * rsize(c)))) return rc;
     if ((rc = ensure(c, c->Tq, (size_t)TC * nl * H1 * NS * 2 * rsize(c)))) return rc;
