@@ -119,11 +119,18 @@ def main():
     h = (100, 10000)
     state = {}
 
+    # The library runs on its own HIP stream; torch orders its collectives against it on the GPU
+    # (no host sync inside a step): torch stream waits for the library stream before the
+    # exchange, the library stream waits for the exchange before it overwrites fit/psum again.
+    lib_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
+
     def step():
+        if world > 1:
+            lib_stream.wait_stream(torch.cuda.current_stream())
         ctx.reconstruct_device(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, None,
                                None, psum.data_ptr(), fit.data_ptr())
-        ctx.sync()
         if world > 1:      # FIT_ROWS gather + PSF_MEAN numerator reduce
+            torch.cuda.current_stream().wait_stream(lib_stream)
             if backend == 'nccl':
                 state['fit_all'] = gather_fit_tables(fit, world * rows)
                 reduce_psf_sum(psum, dst=0)

@@ -100,6 +100,10 @@ int mpsfr_fit_stamps(mpsfr_ctx* ctx, int nstamp, const double* stamps, double* f
 /* Block until everything queued on the context's stream has finished. */
 int mpsfr_sync(mpsfr_ctx* ctx);
 
+/* The context's hipStream_t (as void*), so that a caller can order its own GPU work against the
+ * asynchronous (on_device = 1) calls without a host sync, e.g. torch.cuda.ExternalStream. */
+void* mpsfr_stream(mpsfr_ctx* ctx);
+
 /* Copy an intermediate of the most recent mpsfr_reconstruct pipeline pass (last chunk) to the
  * host as float64 (parity tests, tests/test_stages_gpu.py).  `what`:
  *   "ao_tables"  [2 geometries][ndir][3 (T0,T1,noise)][80][80]   (psfrec.py:531-613)

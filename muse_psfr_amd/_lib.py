@@ -67,6 +67,8 @@ def load():
     lib.mpsfr_fit_stamps.restype = C.c_int
     lib.mpsfr_sync.argtypes = [p]
     lib.mpsfr_sync.restype = C.c_int
+    lib.mpsfr_stream.argtypes = [p]
+    lib.mpsfr_stream.restype = C.c_void_p
     lib.mpsfr_debug_fetch.argtypes = [p, C.c_char_p, dp, C.c_size_t]
     lib.mpsfr_debug_fetch.restype = C.c_long
     lib.mpsfr_profile_count.argtypes = []
@@ -84,7 +86,7 @@ def load():
 
 
 EXPORTS = ['mpsfr_create', 'mpsfr_destroy', 'mpsfr_last_error', 'mpsfr_set_option',
-           'mpsfr_reconstruct', 'mpsfr_fit_stamps', 'mpsfr_sync', 'mpsfr_debug_fetch',
+           'mpsfr_reconstruct', 'mpsfr_fit_stamps', 'mpsfr_sync', 'mpsfr_stream', 'mpsfr_debug_fetch',
            'mpsfr_profile_count', 'mpsfr_profile_name', 'mpsfr_profile_get',
            'mpsfr_profile_reset', 'mpsfr_version']
 
@@ -128,6 +130,10 @@ class Context:
 
     def sync(self):
         _check(self.lib.mpsfr_sync(self._h))
+
+    def stream_handle(self):
+        """hipStream_t of the context as an integer (for torch.cuda.ExternalStream)."""
+        return int(self.lib.mpsfr_stream(self._h) or 0)
 
     def reconstruct(self, lbda, seeing, gl, l0, three_lgs=None, h=(100, 10000), wind_speed=None,
                     npsflin=1, masks=None, want_psf=True, want_sum=True, want_fit=True):

@@ -70,6 +70,19 @@ struct mpsfr_ctx {
     DevBuf aotab, mask_rec, mask_res, tp, lp, samp_p, samp_a, G, gam, alp, ktt, kmuse;
     // chunk workspaces
     DevBuf C, s00, D0t, Tq, pre, fin, fit, sum, stage;
+    // small per-call parameters: one pinned host blob -> one device blob, no stream sync
+    void* stage_h = nullptr;
+    size_t stage_h_cap = 0;
+    DevBuf params;
+    hipEvent_t staged = nullptr;      // recorded after the H2D copy of stage_h
+    bool staged_pending = false;
+    // caches of the per-call tables that only depend on (lbda) / (geometry, masks)
+    std::vector<double> cache_lbda;
+    int cache_lbda_mode = -1;
+    const void* cache_G_ptr = nullptr;
+    const void* cache_kmuse_ptr = nullptr;
+    std::vector<unsigned char> cache_geom;
+    const void* cache_ao_ptr = nullptr;
     // bookkeeping for debug_fetch
     int last_ndir = 0, last_nl = 0, last_chunk_tasks = 0;
     // profiling
@@ -303,10 +316,12 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         (void)hipEventDestroy(p.b);
     }
     for (auto e : c->pool) (void)hipEventDestroy(e);
+    if (c->staged) (void)hipEventDestroy(c->staged);
+    if (c->stage_h) (void)hipHostFree(c->stage_h);
     DevBuf* all[] = {&c->tw64, &c->twR, &c->tel, &c->rows, &c->aotab, &c->mask_rec, &c->mask_res,
                      &c->tp, &c->lp, &c->samp_p, &c->samp_a, &c->G, &c->gam, &c->alp, &c->ktt,
                      &c->kmuse, &c->C, &c->s00, &c->D0t, &c->Tq, &c->pre, &c->fin, &c->fit,
-                     &c->sum, &c->stage};
+                     &c->sum, &c->stage, &c->params};
     for (auto b : all) release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -414,57 +429,95 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         g.dir[1][d] = (double)(d % npsflin - npsflin / 2) * 60 / 2 / 60;
     }
 
-    // ---- uploads (small) + per-call tables
-    if ((rc = ensure(c, c->lp, nl * sizeof(LamPar)))) return rc;
-    if ((rc = ensure(c, c->tp, ntask * sizeof(TaskPar)))) return rc;
-    if ((rc = ensure(c, c->gam, gam.size() * sizeof(double)))) return rc;
-    if ((rc = ensure(c, c->alp, alp.size() * sizeof(double)))) return rc;
+    // ---- uploads: one pinned blob [LamPar nl][TaskPar ntask][gam][alp][mask_rec][mask_res]
+    auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_lp = 0;
+    const size_t o_tp = al16(o_lp + nl * sizeof(LamPar));
+    const size_t o_gam = al16(o_tp + ntask * sizeof(TaskPar));
+    const size_t o_alp = al16(o_gam + gam.size() * sizeof(double));
+    const size_t o_mr = al16(o_alp + alp.size() * sizeof(double));
+    const size_t o_ms = al16(o_mr + NAO * NAO);
+    const size_t blob = al16(o_ms + NAO * NAO);
+    if (c->staged_pending) {            // previous call's copy must have left the pinned buffer
+        HIPCHK(hipEventSynchronize(c->staged));
+        c->staged_pending = false;
+    }
+    if (blob > c->stage_h_cap) {
+        if (c->stage_h) HIPCHK(hipHostFree(c->stage_h));
+        c->stage_h = nullptr;
+        HIPCHK(hipHostMalloc(&c->stage_h, blob * 2, hipHostMallocDefault));
+        c->stage_h_cap = blob * 2;
+    }
+    if (!c->staged) HIPCHK(hipEventCreateWithFlags(&c->staged, hipEventDisableTiming));
+    if ((rc = ensure(c, c->params, blob))) return rc;
+    char* hb = (char*)c->stage_h;
+    memcpy(hb + o_lp, lp.data(), nl * sizeof(LamPar));
+    memcpy(hb + o_tp, tp.data(), ntask * sizeof(TaskPar));
+    memcpy(hb + o_gam, gam.data(), gam.size() * sizeof(double));
+    memcpy(hb + o_alp, alp.data(), alp.size() * sizeof(double));
+    if (mask_rec) {
+        memcpy(hb + o_mr, mask_rec, NAO * NAO);
+        memcpy(hb + o_ms, mask_res, NAO * NAO);
+    }
+    HIPCHK(hipMemcpyAsync(c->params.p, hb, blob, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(c->staged, s));
+    c->staged_pending = true;
+    const char* db = (const char*)c->params.p;
+    const LamPar* d_lp = (const LamPar*)(db + o_lp);
+    const TaskPar* d_tp = (const TaskPar*)(db + o_tp);
+    const double* d_gam = (const double*)(db + o_gam);
+    const double* d_alp = (const double*)(db + o_alp);
+    const uint8_t* d_mrec = mask_rec ? (const uint8_t*)(db + o_mr) : nullptr;
+    const uint8_t* d_mres = mask_rec ? (const uint8_t*)(db + o_ms) : nullptr;
+
+    // ---- per-call tables, cached on their inputs
     if ((rc = ensure(c, c->aotab, (size_t)2 * ndir * 3 * NAO * NAO * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->samp_p, (size_t)nl * NS * sizeof(int)))) return rc;
     if ((rc = ensure(c, c->samp_a, (size_t)nl * NS * rsize(c)))) return rc;
     if ((rc = ensure(c, c->G, (size_t)nl * H1 * NS * 2 * rsize(c)))) return rc;
-    if ((rc = ensure(c, c->ktt, (size_t)ntask * KS * KS * rsize(c)))) return rc;
-    if ((rc = ensure(c, c->kmuse, (size_t)nl * KS * KS * rsize(c)))) return rc;
-    HIPCHK(hipMemcpyAsync(c->lp.p, lp.data(), nl * sizeof(LamPar), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->tp.p, tp.data(), ntask * sizeof(TaskPar), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->gam.p, gam.data(), gam.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->alp.p, alp.data(), alp.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    const uint8_t* d_mrec = nullptr;
-    const uint8_t* d_mres = nullptr;
-    if (mask_rec) {
-        if ((rc = ensure(c, c->mask_rec, NAO * NAO))) return rc;
-        if ((rc = ensure(c, c->mask_res, NAO * NAO))) return rc;
-        HIPCHK(hipMemcpyAsync(c->mask_rec.p, mask_rec, NAO * NAO, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(c->mask_res.p, mask_res, NAO * NAO, hipMemcpyHostToDevice, s));
-        d_mrec = (const uint8_t*)c->mask_rec.p;
-        d_mres = (const uint8_t*)c->mask_res.p;
-    }
-    // the host vectors above must outlive the async copies
-    HIPCHK(hipStreamSynchronize(s));
-    {
-        ProfScope ps(c, K_AO_TABLES);
-        launch_ao_tables(s, g, d_mrec, d_mres, (double*)c->aotab.p);
-    }
-    {
-        ProfScope ps(c, K_GTABLE);
-        launch_gtable(s, N, nl, (const LamPar*)c->lp.p, c->tw64.p, (int*)c->samp_p.p,
-                      c->samp_a.p, c->G.p, c->f64);
-    }
     const bool use_fft_conv = !c->f64 && c->fft_conv;
-    if (use_fft_conv) {
-        // kernel spectra for the FFT convolution: ktt/kmuse hold [n][33][64] complex float
-        if ((rc = ensure(c, c->ktt, (size_t)ntask * KHAT * 2 * sizeof(float)))) return rc;
-        if ((rc = ensure(c, c->kmuse, (size_t)nl * KHAT * 2 * sizeof(float)))) return rc;
+    const size_t ksz = use_fft_conv ? (size_t)KHAT * 2 * sizeof(float) : (size_t)KS * KS * rsize(c);
+    if ((rc = ensure(c, c->ktt, (size_t)ntask * ksz))) return rc;
+    if ((rc = ensure(c, c->kmuse, (size_t)nl * ksz))) return rc;
+    {
+        std::vector<unsigned char> key(sizeof(AoGeom) + 1 + (mask_rec ? 2 * NAO * NAO : 0));
+        memcpy(key.data(), &g, sizeof(AoGeom));
+        key[sizeof(AoGeom)] = mask_rec ? 1 : 0;
+        if (mask_rec) {
+            memcpy(key.data() + sizeof(AoGeom) + 1, mask_rec, NAO * NAO);
+            memcpy(key.data() + sizeof(AoGeom) + 1 + NAO * NAO, mask_res, NAO * NAO);
+        }
+        if (key != c->cache_geom || c->cache_ao_ptr != c->aotab.p) {
+            ProfScope ps(c, K_AO_TABLES);
+            launch_ao_tables(s, g, d_mrec, d_mres, (double*)c->aotab.p);
+            c->cache_geom.swap(key);
+            c->cache_ao_ptr = c->aotab.p;
+        }
+    }
+    const std::vector<double> lb_key(lbda_nm, lbda_nm + nl);
+    const bool lam_cached = lb_key == c->cache_lbda && c->cache_lbda_mode == (use_fft_conv ? 1 : 0) &&
+                            c->cache_G_ptr == c->G.p && c->cache_kmuse_ptr == c->kmuse.p;
+    if (!lam_cached) {
+        ProfScope ps(c, K_GTABLE);
+        launch_gtable(s, N, nl, d_lp, c->tw64.p, (int*)c->samp_p.p, c->samp_a.p, c->G.p, c->f64);
+    }
+    {
         ProfScope ps(c, K_MOFFAT_KERNELS);
-        launch_khat(s, ntask, (const double*)c->gam.p, (const double*)c->alp.p, c->ktt.p);
-        launch_khat(s, nl, (const double*)c->gam.p + ntask, (const double*)c->alp.p + ntask,
-                    c->kmuse.p);
-    } else {
-        ProfScope ps(c, K_MOFFAT_KERNELS);
-        launch_moffat_kernels(s, ntask, (const double*)c->gam.p, (const double*)c->alp.p,
-                              c->ktt.p, c->f64);
-        launch_moffat_kernels(s, nl, (const double*)c->gam.p + ntask,
-                              (const double*)c->alp.p + ntask, c->kmuse.p, c->f64);
+        if (use_fft_conv) {
+            // kernel spectra for the FFT convolution: [n][33][64] complex float
+            launch_khat(s, ntask, d_gam, d_alp, c->ktt.p);
+            if (!lam_cached) launch_khat(s, nl, d_gam + ntask, d_alp + ntask, c->kmuse.p);
+        } else {
+            launch_moffat_kernels(s, ntask, d_gam, d_alp, c->ktt.p, c->f64);
+            if (!lam_cached)
+                launch_moffat_kernels(s, nl, d_gam + ntask, d_alp + ntask, c->kmuse.p, c->f64);
+        }
+    }
+    if (!lam_cached) {
+        c->cache_lbda = lb_key;
+        c->cache_lbda_mode = use_fft_conv ? 1 : 0;
+        c->cache_G_ptr = c->G.p;
+        c->cache_kmuse_ptr = c->kmuse.p;
     }
 
     // ---- chunk workspaces
@@ -511,7 +564,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         const int ntd = tc * ndir;
         {
             ProfScope ps(c, K_PSD_ROWFFT);
-            launch_psd_rowfft(s, N, ntd, ndir, (const TaskPar*)c->tp.p + t0,
+            launch_psd_rowfft(s, N, ntd, ndir, d_tp + t0,
                               (const double*)c->aotab.p, cfit, c->C.p, c->tw64.p);
         }
         {
@@ -525,7 +578,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         }
         {
             ProfScope ps(c, K_OTF_ROWFFT);
-            launch_otf_rowfft(s, N, tc, ndir, nl, c->D0t.p, c->tel.p, (const LamPar*)c->lp.p,
+            launch_otf_rowfft(s, N, tc, ndir, nl, c->D0t.p, c->tel.p, d_lp,
                               (const int*)c->samp_p.p, c->samp_a.p, c->Tq.p, c->tw64.p, c->f64,
                               c->fast_exp);
         }
@@ -537,11 +590,11 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         {
             ProfScope ps(c, K_CONV);
             if (use_fft_conv) {
-                const size_t koff = (size_t)t0 * KHAT * 2 * sizeof(float);
+                const size_t koff = (size_t)t0 * ksz;
                 launch_conv_fft(s, tc, nl, (const double*)c->pre.p, (const char*)c->ktt.p + koff,
                                 c->kmuse.p, d_fin);
             } else {
-                const size_t koff = (size_t)t0 * KS * KS * rsize(c);
+                const size_t koff = (size_t)t0 * ksz;
                 launch_conv(s, tc, nl, (const double*)c->pre.p, (const char*)c->ktt.p + koff,
                             c->kmuse.p, d_fin, c->f64);
             }
@@ -639,6 +692,8 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
     }
     return (long)n;
 }
+
+void* mpsfr_stream(mpsfr_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int mpsfr_profile_count(void) { return K_COUNT; }
 
