@@ -177,6 +177,14 @@ def main():
         achieved = alg_bytes / avg_s / 1e9
         bytes_per_psf = ndir * dim * dim * (3 * p + (5 * 8 + p) / nl)
         pipe = (npsf / dt) * bytes_per_psf / 1e9
+        # HBM traffic of the dominant kernel from the committed PMC pass (profiles/), if it was
+        # taken on this workload: (FETCH_SIZE + WRITE_SIZE) KiB per launch, no width correction
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if os.path.exists(tfile) and (dim, nl, rows, a.npsflin, a.precision) == (512, 35, 100, 1, 'mixed'):
+            k = json.load(open(tfile))['kernels'].get('k_otf_rowfft', {})
+            if k.get('fetch_kib') and k.get('write_kib'):
+                traffic = (k['fetch_kib'] + k['write_kib']) * 1024.0
         fitg = fit.cpu().numpy()
         out = {
             'metric': 'PSFs/sec (row x lambda) on %d^2 grid, %d lambda' % (dim, nl),
@@ -193,7 +201,7 @@ def main():
                        'chunk_tasks': chunk, 'parallelism': 'rows sharded x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'otf_rowfft',
                          'achieved': round(achieved, 1), 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': round(achieved / 8000.0, 4), 'traffic': None,
+                         'frac': round(achieved / 8000.0, 4), 'traffic': traffic,
                          'avg_launch_ms': round(avg_s * 1e3, 4), 'launches': nlaunch,
                          'algorithmic_bytes_per_launch': alg_bytes},
             'roofline_pipeline': {'bytes_per_psf': bytes_per_psf,
