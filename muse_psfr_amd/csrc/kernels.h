@@ -7,6 +7,7 @@
 namespace mpsfr {
 
 constexpr int NS = 40;       // dimpsf, psfrec.py:658
+constexpr int NSH = NS / 2 + 1;  // samples 0..20 of a line; sample 40-i is the conjugate of i
 constexpr int KS = 41;       // Moffat kernel side, psfrec.py:911-916
 constexpr int NAO = 80;      // AO-corrected zone, psfrec.py:103, 138
 constexpr int NFIT = 16;

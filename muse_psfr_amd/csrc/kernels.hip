@@ -411,9 +411,12 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
         }
         const cx<R>* res = fft_forward_regs<R, N, REGTW>(x, a, b, twp, t);
         if (valid) {
-            // F_a[p] = (Z[p] + conj Z[-p]) / 2,  F_b[p] = (Z[p] - conj Z[-p]) / 2i
-            for (int idx = t; idx < 2 * NS; idx += TPR) {
-                const int which = idx / NS, i = idx - which * NS;
+            // F_a[p] = (Z[p] + conj Z[-p]) / 2,  F_b[p] = (Z[p] - conj Z[-p]) / 2i.
+            // Only samples i = 0..20: the OTF is real, so A[v][-p] = conj A[v][p], and the sample
+            // positions are symmetric about the centre (p_(40-i) + 1 = -p_i, weights swapped),
+            // hence Tq[v][40-i] = conj Tq[v][i].
+            for (int idx = t; idx < 2 * NSH; idx += TPR) {
+                const int which = idx / NSH, i = idx - which * NSH;
                 if (which == 1 && !two) continue;
                 const int ll = l + which;
                 const int p = samp_p[ll * NS + i];
@@ -431,7 +434,7 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
                     f0 = {h * (zp.y + zmp.y), -h * (zp.x - zmp.x)};
                     f1 = {h * (zq.y + zmq.y), -h * (zq.x - zmq.x)};
                 }
-                Tq[(((size_t)task * nl + ll) * (N / 2 + 1) + v) * NS + i] = {
+                Tq[(((size_t)task * nl + ll) * (N / 2 + 1) + v) * NSH + i] = {
                     ((R)1 - w) * f0.x + w * f1.x, ((R)1 - w) * f0.y + w * f1.y};
             }
         }
@@ -441,77 +444,93 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
 
 // ------------------------------------------------------------------------------------------
 // K_COLPASS: second (column) pass restricted to the sampled positions,
-// stamp[i][j] = sum_v Re(G[l][v][j] * conj(A[v][i])) = sum_v (Gx Ax + Gy Ay), a real
-// (40 x 2(N/2+1)) x (2(N/2+1) x 40) product per stamp, then clamp >= 0 (psfrec.py:680) and
-// normalise to sum 1 (:685).  One workgroup per stamp; every lane holds a 5x5 register tile and
-// the four waves split the v range (32 lines staged in LDS per step, 8 per wave), the partial
-// tiles being summed through LDS at the end.
+// stamp[i][j] = sum_v Re(G[l][v][j] * conj(Tq[v][i])), then clamp >= 0 (psfrec.py:680) and
+// normalise to sum 1 (:685).  With Tq[v][40-i] = conj Tq[v][i] only i = 0..20 is stored and
+//   P[i][j] = sum_v Gx Tx,  Q[i][j] = sum_v Gy Ty,  stamp[i][j] = P + Q,  stamp[40-i][j] = P - Q,
+// i.e. half the products of the plain form.  One workgroup per stamp; a lane holds a 3x5 tile
+// of (P, Q) pairs (7 x 8 tiles = 56 lanes), the four waves split the v range (32 lines staged
+// in LDS per step, 8 per wave) and the partial tiles are summed through LDS at the end.
 // ------------------------------------------------------------------------------------------
 template <typename R, int N>
 __global__ void __launch_bounds__(256)
 k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
           double* __restrict__ pre) {
-    constexpr int VW = 8, VB = 4 * VW, TL = 5, NV = N / 2 + 1;
-    constexpr int NE = VB * NS / 256;    // staged elements per thread and array (5)
-    // one raw buffer: staging [2][VB][NS] complex during the loop, then [4][NS*NS] partial tiles
-    static_assert(4 * NS * NS * sizeof(R) >= 2 * VB * NS * sizeof(cx<R>), "overlay");
-    __shared__ __align__(16) unsigned char raw[4 * NS * NS * sizeof(R)];
-    cx<R>(*sT)[NS] = reinterpret_cast<cx<R>(*)[NS]>(raw);
-    cx<R>(*sG)[NS] = reinterpret_cast<cx<R>(*)[NS]>(raw + VB * NS * sizeof(cx<R>));
+    constexpr int VW = 8, VB = 4 * VW, TI = 3, TJ = 5, NV = N / 2 + 1;
+    constexpr int NPQ = NSH * NS;                 // 840 (P, Q) pairs
+    static_assert(NSH == 7 * TI && NS == 8 * TJ, "tile map");
+    // one raw buffer: staging {T [VB][NSH], G [VB][NS]} complex during the loop, then the
+    // partial tiles [4][NPQ] complex (P, Q)
+    constexpr size_t STAGE = (size_t)VB * (NSH + NS) * sizeof(cx<R>);
+    constexpr size_t RED = (size_t)4 * NPQ * sizeof(cx<R>);
+    __shared__ __align__(16) unsigned char raw[RED > STAGE ? RED : STAGE];
+    cx<R>(*sT)[NSH] = reinterpret_cast<cx<R>(*)[NSH]>(raw);
+    cx<R>(*sG)[NS] = reinterpret_cast<cx<R>(*)[NS]>(raw + VB * NSH * sizeof(cx<R>));
     __shared__ double part[4];
     __shared__ double tot;
     const int l = blockIdx.x, task = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i0 = TL * (lane >> 3), j0 = TL * (lane & 7);
-    const cx<R>* Tp = Tq + ((size_t)task * nl + l) * NV * NS;
+    const bool act = lane < 56;
+    const int i0 = TI * (act ? lane >> 3 : 0), j0 = TJ * (lane & 7);
+    const cx<R>* Tp = Tq + ((size_t)task * nl + l) * NV * NSH;
     const cx<R>* Gp = G + (size_t)l * NV * NS;
-    R acc[TL][TL];
+    R accP[TI][TJ], accQ[TI][TJ];
 #pragma unroll
-    for (int a = 0; a < TL; ++a)
+    for (int a = 0; a < TI; ++a)
 #pragma unroll
-        for (int b = 0; b < TL; ++b) acc[a][b] = (R)0;
-    cx<R> rt[NE], rg[NE];
+        for (int b = 0; b < TJ; ++b) { accP[a][b] = (R)0; accQ[a][b] = (R)0; }
+    constexpr int NET = (VB * NSH + 255) / 256, NEG = VB * NS / 256;
+    cx<R> rt[NET], rg[NEG];
     auto fetch = [&](int v0) {
 #pragma unroll
-        for (int k = 0; k < NE; ++k) {
+        for (int k = 0; k < NET; ++k) {
             const int e = threadIdx.x + k * 256;
-            const bool in = v0 * NS + e < NV * NS;
-            rt[k] = in ? Tp[(size_t)v0 * NS + e] : cx<R>{(R)0, (R)0};
-            rg[k] = in ? Gp[(size_t)v0 * NS + e] : cx<R>{(R)0, (R)0};
+            rt[k] = (e < VB * NSH && v0 * NSH + e < NV * NSH) ? Tp[(size_t)v0 * NSH + e]
+                                                            : cx<R>{(R)0, (R)0};
+        }
+#pragma unroll
+        for (int k = 0; k < NEG; ++k) {
+            const int e = threadIdx.x + k * 256;
+            rg[k] = v0 * NS + e < NV * NS ? Gp[(size_t)v0 * NS + e] : cx<R>{(R)0, (R)0};
         }
     };
     fetch(0);
     for (int v0 = 0; v0 < NV; v0 += VB) {
 #pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            (&sT[0][0])[threadIdx.x + k * 256] = rt[k];
-            (&sG[0][0])[threadIdx.x + k * 256] = rg[k];
+        for (int k = 0; k < NET; ++k) {
+            const int e = threadIdx.x + k * 256;
+            if (e < VB * NSH) (&sT[0][0])[e] = rt[k];
         }
+#pragma unroll
+        for (int k = 0; k < NEG; ++k) (&sG[0][0])[threadIdx.x + k * 256] = rg[k];
         __syncthreads();
         if (v0 + VB < NV) fetch(v0 + VB);      // prefetch the next block behind the FMAs
 #pragma unroll
         for (int vb = 0; vb < VW; ++vb) {
             const int vr = wave * VW + vb;
-            cx<R> t[TL], g[TL];
+            cx<R> t[TI], g[TJ];
 #pragma unroll
-            for (int k = 0; k < TL; ++k) {
-                t[k] = sT[vr][i0 + k];
-                g[k] = sG[vr][j0 + k];
-            }
+            for (int k = 0; k < TI; ++k) t[k] = sT[vr][i0 + k];
 #pragma unroll
-            for (int a = 0; a < TL; ++a)
+            for (int k = 0; k < TJ; ++k) g[k] = sG[vr][j0 + k];
 #pragma unroll
-                for (int b = 0; b < TL; ++b) acc[a][b] += g[b].x * t[a].x + g[b].y * t[a].y;
+            for (int a = 0; a < TI; ++a)
+#pragma unroll
+                for (int b = 0; b < TJ; ++b) {
+                    accP[a][b] += g[b].x * t[a].x;
+                    accQ[a][b] += g[b].y * t[a].y;
+                }
         }
         __syncthreads();
     }
     // sum the four partial tiles
-    R* red = reinterpret_cast<R*>(raw);
-    R* dst = red + wave * NS * NS;
+    cx<R>* red = reinterpret_cast<cx<R>*>(raw);
+    if (act) {
 #pragma unroll
-    for (int a = 0; a < TL; ++a)
+        for (int a = 0; a < TI; ++a)
 #pragma unroll
-        for (int b = 0; b < TL; ++b) dst[(i0 + a) * NS + j0 + b] = acc[a][b];
+            for (int b = 0; b < TJ; ++b)
+                red[wave * NPQ + (i0 + a) * NS + j0 + b] = {accP[a][b], accQ[a][b]};
+    }
     __syncthreads();
     constexpr int NO = (NS * NS + 255) / 256;
     R val[NO];
@@ -521,7 +540,11 @@ k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
         const int o = threadIdx.x + m * 256;
         R x = (R)0;
         if (o < NS * NS) {
-            x = (red[o] + red[NS * NS + o]) + (red[2 * NS * NS + o] + red[3 * NS * NS + o]);
+            const int i = o / NS, j = o - i * NS;
+            const int e = (i < NSH ? i : NS - i) * NS + j;
+            const cx<R> a = red[e], b = red[NPQ + e], c = red[2 * NPQ + e], d = red[3 * NPQ + e];
+            const R P = (a.x + b.x) + (c.x + d.x), Q = (a.y + b.y) + (c.y + d.y);
+            x = i < NSH ? P + Q : P - Q;
             if (x < (R)0) x = (R)0;
             s += (double)x;
         }

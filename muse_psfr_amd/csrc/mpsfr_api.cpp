@@ -538,7 +538,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     if ((rc = ensure(c, c->C, (size_t)TC * ndir * (N / 2 + NAO / 2) * H1 * 2 * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->s00, (size_t)TC * ndir * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->D0t, (size_t)TC * ndir * H1 * N * rsize(c)))) return rc;
-    if ((rc = ensure(c, c->Tq, (size_t)TC * nl * H1 * NS * 2 * rsize(c)))) return rc;
+    if ((rc = ensure(c, c->Tq, (size_t)TC * nl * H1 * NSH * 2 * rsize(c)))) return rc;
     if ((rc = ensure(c, c->pre, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->sum, (size_t)nl * per_stamp * sizeof(double)))) return rc;
     const bool dev_out = on_device != 0;
