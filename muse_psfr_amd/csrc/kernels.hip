@@ -1074,7 +1074,7 @@ __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][
 }
 
 template <typename RE>
-__global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restrict__ stamps,
+__global__ void __launch_bounds__(256) k_fit_coarse(int nstamp, const double* __restrict__ stamps,
                                              double* __restrict__ fit) {
     const int lane = threadIdx.x & 63;
     const int st = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1162,6 +1162,34 @@ __global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restric
             if (mu > 1.0e15) { status = 0; break; }   // no further descent: at the minimum
         }
     }
+    if (lane == 0) {       // hand the (I, p0, q0, w, n) solution to k_fit_finish
+        double* o = fit + (size_t)st * NFIT;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) o[k] = v[k];
+        o[7] = (double)it;
+        o[14] = (double)status;
+    }
+}
+
+// second half of the fit: fp64 Gauss-Newton polish of the float solution (mixed mode), then the
+// normal equations in (a, n) for chi2 and the covariance.  Separate kernel so that the float LM
+// above keeps a small register footprint (the fused kernel needed 202-256 VGPRs).
+template <typename RE>
+__global__ void __launch_bounds__(256) k_fit_finish(int nstamp, const double* __restrict__ stamps,
+                                                    double* __restrict__ fit) {
+    const int lane = threadIdx.x & 63;
+    const int st = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (st >= nstamp) return;   // whole wave exits together
+    const double* src = stamps + (size_t)st * NS * NS;
+    double* frow = fit + (size_t)st * NFIT;
+    double v[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = frow[k];
+    int it = (int)frow[7], status = (int)frow[14];
+    RE dpix[NPIX_LANE];
+#pragma unroll
+    for (int m = 0; m < NPIX_LANE; ++m) dpix[m] = (RE)src[lane + m * 64];
+    NormEqT<RE> ne;
     if constexpr (sizeof(RE) == 4) {
         // The float evaluation has systematic errors of ~1e-6 in the wings (v_log/v_exp), enough
         // to move beta by a few 1e-4 on flat-topped stamps.  Polish with fp64 Gauss-Newton steps
@@ -1406,12 +1434,14 @@ void launch_conv_fft(hipStream_t s, int ntask, int nl, const double* d_pre, cons
 
 void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit, bool f64) {
     if (nstamp <= 0) return;
-    if (f64)
-        hipLaunchKernelGGL(k_fit<double>, dim3((nstamp + 3) / 4), dim3(256), 0, s, nstamp,
-                           d_stamps, d_fit);
-    else
-        hipLaunchKernelGGL(k_fit<float>, dim3((nstamp + 3) / 4), dim3(256), 0, s, nstamp, d_stamps,
-                           d_fit);
+    const dim3 grid((nstamp + 3) / 4);
+    if (f64) {
+        hipLaunchKernelGGL(k_fit_coarse<double>, grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
+        hipLaunchKernelGGL(k_fit_finish<double>, grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
+    } else {
+        hipLaunchKernelGGL(k_fit_coarse<float>, grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
+        hipLaunchKernelGGL(k_fit_finish<float>, grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
+    }
 }
 
 void launch_stamp_sum(hipStream_t s, int ntask, int nl, const double* d_fin, double* d_sum,
