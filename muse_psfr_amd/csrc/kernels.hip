@@ -128,18 +128,13 @@ __global__ void __launch_bounds__(256) k_tel_otf(int N, const uint64_t* __restri
 //
 // Only N/2 + 40 of the N rows are distinct: outside the corrected zone the PSD depends on the row
 // only through (su + 1/2)^2 (half-pixel grid of psfrec.py:618), so rows su and -1-su are equal.
-// The distinct rows are su in [-40, N/2), stored compactly as C[td][su + 40][y], y in [0, N/2];
+// The distinct rows are su in [-40, N/2), stored compactly and transposed as
+// Ct[td][y][su + 40], y in [0, N/2];
 // K_COLFFT_DPHI mirrors them back.  Two real rows share one complex transform
 // (z = row_a + i row_b; C_a = (Z[y] + conj Z[-y])/2, C_b = (Z[y] - conj Z[-y])/2i).
 // ------------------------------------------------------------------------------------------
 template <int N>
 constexpr int psd_rows() { return N / 2 + NAO / 2; }
-
-__device__ __forceinline__ int psd_row_slot(int r, int N) {   // native row -> compact row
-    int su = r < N / 2 ? r : r - N;
-    if (su < -NAO / 2) su = -1 - su;
-    return su + NAO / 2;
-}
 
 // x^(-11/6) = cbrt(sqrt(x)) / x^2: ~3x cheaper than the generic fp64 pow, same accuracy class
 __device__ __forceinline__ double pow_m11_6(double x) { return cbrt(sqrt(x)) / (x * x); }
@@ -195,14 +190,23 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
     __syncthreads();      // twiddle table
     const cx<double>* res = fft_forward_regs<double, N, false>(x, bufA + slot * NPAD,
                                                                bufB + slot * NPAD, tw, t);
-    if (valid) {
-        cx<double>* oa = C + ((size_t)td * NR + ca) * (N / 2 + 1);
-        cx<double>* ob = oa + (N / 2 + 1);
-        for (int y = t; y <= N / 2; y += TPR) {
-            const cx<double> z = res[lds_pad(y)], zm = res[lds_pad(y == 0 ? 0 : N - y)];
-            oa[y] = {0.5 * (z.x + zm.x), 0.5 * (z.y - zm.y)};
-            ob[y] = {0.5 * (z.y + zm.y), -0.5 * (z.x - zm.x)};
-        }
+    // Store transposed, Ct[td][y][compact row], so that K_COLFFT_DPHI reads whole columns
+    // contiguously: the workgroup's 2*SLOTS rows of one y form a 32*SLOTS-byte segment; lanes run
+    // over (y, row) with the row fastest, each unpacking its value from the slot buffers.
+    __syncthreads();
+    constexpr int RW = 2 * SLOTS;                       // rows per workgroup
+    const int row0 = blockIdx.x * RW;
+    cx<double>* Ct = C + (size_t)td * (N / 2 + 1) * NR;
+    for (int idx = threadIdx.x; idx < (N / 2 + 1) * RW; idx += THREADS) {
+        const int y = idx / RW, rr = idx - y * RW;
+        if (row0 + rr >= NR) continue;
+        const cx<double>* rs = (L::WSYNC ? bufA : (res == bufA + slot * NPAD ? bufA : bufB)) +
+                               (rr >> 1) * NPAD;
+        const cx<double> z = rs[lds_pad(y)], zm = rs[lds_pad(y == 0 ? 0 : N - y)];
+        cx<double> o;
+        if ((rr & 1) == 0) o = {0.5 * (z.x + zm.x), 0.5 * (z.y - zm.y)};
+        else o = {0.5 * (z.y + zm.y), -0.5 * (z.x - zm.x)};
+        Ct[(size_t)y * NR + row0 + rr] = o;
     }
 }
 
@@ -216,7 +220,7 @@ __global__ void __launch_bounds__(256) k_dc_sum(const cx<double>* __restrict__ C
     const int td = blockIdx.x;
     double s = 0.0;
     for (int r = threadIdx.x; r < NR; r += 256)
-        s += (r >= NAO ? 2.0 : 1.0) * C[((size_t)td * NR + r) * (N / 2 + 1)].x;
+        s += (r >= NAO ? 2.0 : 1.0) * C[(size_t)td * (N / 2 + 1) * NR + r].x;
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -241,14 +245,19 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
     const int y0 = blockIdx.x * SLOTS;
     const int td = blockIdx.y;
     for (int i = threadIdx.x; i < N; i += THREADS) tw[i] = twg[i];
-    const cx<double>* Ct = C + (size_t)td * psd_rows<N>() * (N / 2 + 1);
-    // SLOTS adjacent columns: consecutive lanes read consecutive columns of one row
-    for (int idx = threadIdx.x; idx < N * SLOTS; idx += THREADS) {
-        const int r = idx / SLOTS, sl = idx % SLOTS;
-        const int y = y0 + sl;
-        cx<double> v = {0.0, 0.0};
-        if (y <= N / 2) v = Ct[(size_t)psd_row_slot(r, N) * (N / 2 + 1) + y];
-        bufA[sl * NPAD + lds_pad(r)] = v;
+    constexpr int NR = psd_rows<N>();
+    const cx<double>* Ct = C + (size_t)td * (N / 2 + 1) * NR;
+    // column y0+slot: NR contiguous compact rows; rows su >= 40 also stand for row -1-su
+    {
+        const int y = y0 + slot;
+        const cx<double>* col = Ct + (size_t)(y <= N / 2 ? y : 0) * NR;
+        cx<double>* dst = bufA + slot * NPAD;
+        for (int ci = t; ci < NR; ci += TPR) {
+            const cx<double> v = y <= N / 2 ? col[ci] : cx<double>{0.0, 0.0};
+            const int su = ci - NAO / 2;
+            dst[lds_pad(su < 0 ? su + N : su)] = v;
+            if (su >= NAO / 2) dst[lds_pad(N - 1 - su)] = v;
+        }
     }
     __syncthreads();
     const cx<double>* res =
