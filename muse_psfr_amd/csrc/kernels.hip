@@ -1253,15 +1253,23 @@ __global__ void __launch_bounds__(256) k_fit_finish(int nstamp, const double* __
 }
 
 // K_STAMP_SUM: deterministic sum of the final stamps over the tasks of a chunk (PSF_MEAN numerator,
-// psfrec.py:1104)
+// psfrec.py:1104).  64 outputs per workgroup; wave w adds tasks w, w+4, ... and the four partial
+// sums are combined in a fixed order.
 __global__ void __launch_bounds__(256) k_stamp_sum(int ntask, int nl, const double* __restrict__ fin,
                                                    double* __restrict__ sum, int accumulate) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ double part[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t e = (size_t)blockIdx.x * 64 + lane;
     const size_t per = (size_t)nl * NS * NS;
-    if (e >= per) return;
-    double s = accumulate ? sum[e] : 0.0;
-    for (int t = 0; t < ntask; ++t) s += fin[(size_t)t * per + e];
-    sum[e] = s;
+    double s = 0.0;
+    if (e < per)
+        for (int t = wave; t < ntask; t += 4) s += fin[(size_t)t * per + e];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && e < per) {
+        const double tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        sum[e] = accumulate ? sum[e] + tot : tot;
+    }
 }
 
 template <typename T, int N>
@@ -1456,7 +1464,7 @@ void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit
 void launch_stamp_sum(hipStream_t s, int ntask, int nl, const double* d_fin, double* d_sum,
                       int accumulate) {
     const size_t per = (size_t)nl * NS * NS;
-    hipLaunchKernelGGL(k_stamp_sum, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, ntask, nl,
+    hipLaunchKernelGGL(k_stamp_sum, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, ntask, nl,
                        d_fin, d_sum, accumulate);
 }
 
