@@ -60,6 +60,7 @@ def main():
     ap.add_argument('--precision', default='mixed', choices=['mixed', 'f64'])
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--fast-exp', type=int, default=1)
+    ap.add_argument('--streams', type=int, default=0, help='pipeline lanes (0: library default)')
     ap.add_argument('--cpu-rows', type=int, default=-1,
                     help='rows of the CPU-baseline sample (-1: two per core, 0: skip)')
     a = ap.parse_args()
@@ -83,7 +84,9 @@ def main():
     cpu = None
     cpu_fits = None
     if rank == 0 and world == 1 and a.cpu_rows != 0 and a.npsflin == 1:
-        cores = os.cpu_count() or 1
+        # a 1-GPU box has a 16-core CPU share whatever os.cpu_count() says; override with
+        # MPSFR_BENCH_CORES
+        cores = int(os.environ.get('MPSFR_BENCH_CORES', min(os.cpu_count() or 1, 16)))
         ncpu = 2 * cores if a.cpu_rows < 0 else a.cpu_rows
         ncpu = min(ncpu, rows)
         r, cpu_fits = cpu_baseline(lb, see, gl, l0, dim, ps, ncpu, cores)
@@ -111,6 +114,8 @@ def main():
     if a.chunk:
         ctx.set_option('chunk_tasks', a.chunk)
     ctx.set_option('fast_exp', a.fast_exp)
+    if a.streams:
+        ctx.set_option('streams', a.streams)
 
     from muse_psfr_amd.distributed import gather_fit_tables, reduce_psf_sum
     fit = torch.zeros((rows, nl, NFIT), dtype=torch.float64, device=dev)
@@ -182,9 +187,12 @@ def main():
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
         if os.path.exists(tfile) and (dim, nl, rows, a.npsflin, a.precision) == (512, 35, 100, 1, 'mixed'):
-            k = json.load(open(tfile))['kernels'].get('k_otf_rowfft', {})
+            tj = json.load(open(tfile))
+            k = tj['kernels'].get('k_otf_rowfft', {})
             if k.get('fetch_kib') and k.get('write_kib'):
-                traffic = (k['fetch_kib'] + k['write_kib']) * 1024.0
+                # per-launch counters of the profiled run, rescaled to this run's launch size
+                per_unit = (k['fetch_kib'] + k['write_kib']) * 1024.0 / tj['units_per_launch']
+                traffic = per_unit * (rows * nl * ndir * a.steps / max(prof['otf_rowfft'][1], 1))
         fitg = fit.cpu().numpy()
         out = {
             'metric': 'PSFs/sec (row x lambda) on %d^2 grid, %d lambda' % (dim, nl),

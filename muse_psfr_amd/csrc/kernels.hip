@@ -840,7 +840,7 @@ k_conv_fft(int nl, const double* __restrict__ pre, const cx<float>* __restrict__
 __global__ void __launch_bounds__(256)
 k_khat(const double* __restrict__ gam, const double* __restrict__ alp,
        cx<float>* __restrict__ khat) {
-    __shared__ float ker[KS * NS + KS * (KS - NS) + 64];   // [41][41] stored with pitch KS
+    __shared__ float ker[KS * KS];
     __shared__ cx<float> F[CF][CFP];
     __shared__ cx<float> bufs[CFH][CFB];
     __shared__ double part[4];

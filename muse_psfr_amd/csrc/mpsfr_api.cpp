@@ -65,11 +65,21 @@ struct mpsfr_ctx {
     bool profile = false;
     bool fft_conv = true;   // mixed mode: convolutions through 64-point FFTs
     // constant tables
-    DevBuf tw64, twR, tel, rows;
+    DevBuf tw64, tel, rows;
     // per-call tables
-    DevBuf aotab, mask_rec, mask_res, tp, lp, samp_p, samp_a, G, gam, alp, ktt, kmuse;
-    // chunk workspaces
-    DevBuf C, s00, D0t, Tq, pre, fin, fit, sum, stage;
+    DevBuf aotab, samp_p, samp_a, G, ktt, kmuse;
+    // pipeline lanes: each lane owns a HIP stream and a set of chunk workspaces; consecutive chunks
+    // of a call go to alternating lanes so that one chunk's tail overlaps the other's body
+    struct Lane {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        DevBuf C, s00, D0t, Tq, pre, fin, sum;
+    };
+    static constexpr int MAX_LANES = 2;
+    Lane lane[MAX_LANES];
+    int nlanes = 2;
+    hipEvent_t tables_ready = nullptr;
+    DevBuf fit, sum, stage;
     // small per-call parameters: one pinned host blob -> one device blob, no stream sync
     void* stage_h = nullptr;
     size_t stage_h_cap = 0;
@@ -84,7 +94,7 @@ struct mpsfr_ctx {
     std::vector<unsigned char> cache_geom;
     const void* cache_ao_ptr = nullptr;
     // bookkeeping for debug_fetch
-    int last_ndir = 0, last_nl = 0, last_chunk_tasks = 0;
+    int last_ndir = 0, last_nl = 0, last_chunk_tasks = 0, last_lane = 0;
     // profiling
     double prof_ms[K_COUNT] = {0};
     long prof_n[K_COUNT] = {0};
@@ -99,7 +109,7 @@ size_t rsize(const mpsfr_ctx* c) { return c->f64 ? sizeof(double) : sizeof(float
 int ensure(mpsfr_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return MPSFR_OK;
     if (b.p) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -134,16 +144,18 @@ struct ProfScope {
     mpsfr_ctx* c;
     int id;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(mpsfr_ctx* ctx, int kid) : c(ctx), id(kid) {
+    hipStream_t st;
+    ProfScope(mpsfr_ctx* ctx, int kid, hipStream_t stream = nullptr)
+        : c(ctx), id(kid), st(stream ? stream : ctx->stream) {
         if (c->profile) {
             a = get_event(c);
             b = get_event(c);
-            (void)hipEventRecord(a, c->stream);
+            (void)hipEventRecord(a, st);
         }
     }
     ~ProfScope() {
         if (c->profile) {
-            (void)hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, st);
             c->pending.push_back({id, a, b});
         }
     }
@@ -152,6 +164,8 @@ struct ProfScope {
 int resolve_profile(mpsfr_ctx* c) {
     if (c->pending.empty()) return MPSFR_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (int k = 1; k < mpsfr_ctx::MAX_LANES; ++k)
+        if (c->lane[k].stream) HIPCHK(hipStreamSynchronize(c->lane[k].stream));
     for (auto& p : c->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -220,24 +234,14 @@ int build_constant_tables(mpsfr_ctx* c) {
     const int N = c->N;
     // twiddles exp(-2 pi i m / N)
     std::vector<double> tw(2 * (size_t)N);
-    std::vector<float> twf(2 * (size_t)N);
     for (int m = 0; m < N; ++m) {
         const long double ang = -2.0L * 3.141592653589793238462643383279502884L * m / N;
         tw[2 * m] = (double)cosl(ang);
         tw[2 * m + 1] = (double)sinl(ang);
-        twf[2 * m] = (float)tw[2 * m];
-        twf[2 * m + 1] = (float)tw[2 * m + 1];
     }
     int rc;
     if ((rc = ensure(c, c->tw64, tw.size() * sizeof(double)))) return rc;
     HIPCHK(hipMemcpy(c->tw64.p, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
-    if (c->f64) {
-        if ((rc = ensure(c, c->twR, tw.size() * sizeof(double)))) return rc;
-        HIPCHK(hipMemcpy(c->twR.p, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
-    } else {
-        if ((rc = ensure(c, c->twR, twf.size() * sizeof(float)))) return rc;
-        HIPCHK(hipMemcpy(c->twR.p, twf.data(), twf.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
     // pupil mask rows as bit masks: pupil_mask(dim/4, dim/2, oc=0.14), psfrec.py:190-203, 656
     const int H = N / 2, words = (H + 63) / 64, wpad = 2 * words + 1;
     std::vector<uint64_t> rows((size_t)H * wpad, 0);
@@ -298,6 +302,7 @@ int mpsfr_create(mpsfr_ctx** out, int device_id, int dim, int dimpsf, double pix
         delete c;
         return fail(MPSFR_E_HIP, "hipStreamCreate failed");
     }
+    c->lane[0].stream = c->stream;
     const int rc = build_constant_tables(c);
     if (rc) {
         mpsfr_destroy(c);
@@ -317,11 +322,17 @@ void mpsfr_destroy(mpsfr_ctx* c) {
     }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->staged) (void)hipEventDestroy(c->staged);
+    if (c->tables_ready) (void)hipEventDestroy(c->tables_ready);
+    for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k) {
+        mpsfr_ctx::Lane& ln = c->lane[k];
+        if (k > 0 && ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
+        if (ln.done) (void)hipEventDestroy(ln.done);
+        DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.sum};
+        for (auto b : lb) release(*b);
+    }
     if (c->stage_h) (void)hipHostFree(c->stage_h);
-    DevBuf* all[] = {&c->tw64, &c->twR, &c->tel, &c->rows, &c->aotab, &c->mask_rec, &c->mask_res,
-                     &c->tp, &c->lp, &c->samp_p, &c->samp_a, &c->G, &c->gam, &c->alp, &c->ktt,
-                     &c->kmuse, &c->C, &c->s00, &c->D0t, &c->Tq, &c->pre, &c->fin, &c->fit,
-                     &c->sum, &c->stage, &c->params};
+    DevBuf* all[] = {&c->tw64, &c->tel, &c->rows, &c->aotab, &c->samp_p, &c->samp_a, &c->G, &c->ktt,
+                     &c->kmuse, &c->fit, &c->sum, &c->stage, &c->params};
     for (auto b : all) release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -334,6 +345,9 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         c->chunk_tasks = (int)value;
     } else if (!strcmp(key, "fast_exp")) {
         c->fast_exp = value != 0.0;
+    } else if (!strcmp(key, "streams")) {
+        if (value != 1.0 && value != 2.0) return fail(MPSFR_E_INVALID, "streams must be 1 or 2");
+        c->nlanes = (int)value;
     } else if (!strcmp(key, "fft_conv")) {
         c->fft_conv = value != 0.0;
     } else if (!strcmp(key, "profile")) {
@@ -522,7 +536,9 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
 
     // ---- chunk workspaces
     // tasks per pipeline pass: enough stamps (~4096) to fill 256 CUs with several waves each,
-    // bounded so that the fp64 half-plane workspace C stays under 4 GiB
+    // bounded so that the fp64 half-plane workspace C stays under 4 GiB; with two lanes a call
+    // is split into at least two chunks when each still has >= 1024 stamps
+    int NL = c->nlanes;
     int TC = c->chunk_tasks;
     if (TC <= 0) {
         TC = (4096 + nl - 1) / nl;
@@ -531,21 +547,29 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         const double per_task = (double)ndir * (N / 2 + NAO / 2) * H1 * 16.0;
         const int cap = (int)(4.0 * 1024 * 1024 * 1024 / per_task);
         if (TC > cap) TC = cap < 1 ? 1 : cap;
+        if (NL > 1 && ntask <= TC && (size_t)ntask * nl >= 2048) TC = (ntask + 1) / 2;
     }
     if (TC > ntask) TC = ntask;
+    if (ntask <= TC) NL = 1;
     const size_t per_stamp = (size_t)NS * NS;
-    // row FFTs of the PSD: only the N/2 + 40 distinct rows are stored (K_PSD_ROWFFT)
-    if ((rc = ensure(c, c->C, (size_t)TC * ndir * (N / 2 + NAO / 2) * H1 * 2 * sizeof(double)))) return rc;
-    if ((rc = ensure(c, c->s00, (size_t)TC * ndir * sizeof(double)))) return rc;
-    if ((rc = ensure(c, c->D0t, (size_t)TC * ndir * H1 * N * rsize(c)))) return rc;
-    if ((rc = ensure(c, c->Tq, (size_t)TC * nl * H1 * NSH * 2 * rsize(c)))) return rc;
-    if ((rc = ensure(c, c->pre, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
-    if ((rc = ensure(c, c->sum, (size_t)nl * per_stamp * sizeof(double)))) return rc;
     const bool dev_out = on_device != 0;
+    for (int k = 0; k < NL; ++k) {
+        mpsfr_ctx::Lane& ln = c->lane[k];
+        if (!ln.stream) HIPCHK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        if (!ln.done) HIPCHK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+        // row FFTs of the PSD: only the N/2 + 40 distinct rows are stored (K_PSD_ROWFFT)
+        if ((rc = ensure(c, ln.C, (size_t)TC * ndir * (N / 2 + NAO / 2) * H1 * 2 * sizeof(double)))) return rc;
+        if ((rc = ensure(c, ln.s00, (size_t)TC * ndir * sizeof(double)))) return rc;
+        if ((rc = ensure(c, ln.D0t, (size_t)TC * ndir * H1 * N * rsize(c)))) return rc;
+        if ((rc = ensure(c, ln.Tq, (size_t)TC * nl * H1 * NSH * 2 * rsize(c)))) return rc;
+        if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
+        if ((rc = ensure(c, ln.fin, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
+        if ((rc = ensure(c, ln.sum, (size_t)nl * per_stamp * sizeof(double)))) return rc;
+    }
+    if ((rc = ensure(c, c->sum, (size_t)nl * per_stamp * sizeof(double)))) return rc;
     double* d_fin_all = nullptr;   // [ntask][nl][1600] if the caller gave a device buffer
     double* d_fit_all = nullptr;
     if (dev_out && psf_out) d_fin_all = psf_out;
-    if ((rc = ensure(c, c->fin, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
     if (dev_out && fit_out) {
         d_fit_all = fit_out;
     } else {
@@ -559,61 +583,87 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     const double scale2 = 2.0 * (k500 * k500) / 256.0;       // 2 (.)/L^2, L = 16 m (psfrec.py:710, 718)
     double* d_sum = (dev_out && psf_sum_out) ? psf_sum_out : (double*)c->sum.p;
 
-    for (int t0 = 0; t0 < ntask; t0 += TC) {
+    // the per-call tables are produced on the main stream; the other lanes wait for them
+    if (NL > 1) {
+        if (!c->tables_ready) HIPCHK(hipEventCreateWithFlags(&c->tables_ready, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->tables_ready, s));
+        for (int k = 1; k < NL; ++k) HIPCHK(hipStreamWaitEvent(c->lane[k].stream, c->tables_ready, 0));
+    }
+    int nchunk_lane[mpsfr_ctx::MAX_LANES] = {0, 0};
+    int ci = 0;
+    for (int t0 = 0; t0 < ntask; t0 += TC, ++ci) {
         const int tc = (ntask - t0) < TC ? (ntask - t0) : TC;
         const int ntd = tc * ndir;
+        mpsfr_ctx::Lane& ln = c->lane[ci % NL];
+        hipStream_t ls = ln.stream;
         {
-            ProfScope ps(c, K_PSD_ROWFFT);
-            launch_psd_rowfft(s, N, ntd, ndir, d_tp + t0,
-                              (const double*)c->aotab.p, cfit, c->C.p, c->tw64.p);
+            ProfScope ps(c, K_PSD_ROWFFT, ls);
+            launch_psd_rowfft(ls, N, ntd, ndir, d_tp + t0, (const double*)c->aotab.p, cfit, ln.C.p,
+                              c->tw64.p);
         }
         {
-            ProfScope ps(c, K_DC_SUM);
-            launch_dc_sum(s, N, ntd, c->C.p, (double*)c->s00.p);
+            ProfScope ps(c, K_DC_SUM, ls);
+            launch_dc_sum(ls, N, ntd, ln.C.p, (double*)ln.s00.p);
         }
         {
-            ProfScope ps(c, K_COLFFT_DPHI);
-            launch_colfft_dphi(s, N, ntd, c->C.p, (const double*)c->s00.p, scale2, c->D0t.p,
+            ProfScope ps(c, K_COLFFT_DPHI, ls);
+            launch_colfft_dphi(ls, N, ntd, ln.C.p, (const double*)ln.s00.p, scale2, ln.D0t.p,
                                c->f64, c->tw64.p);
         }
         {
-            ProfScope ps(c, K_OTF_ROWFFT);
-            launch_otf_rowfft(s, N, tc, ndir, nl, c->D0t.p, c->tel.p, d_lp,
-                              (const int*)c->samp_p.p, c->samp_a.p, c->Tq.p, c->tw64.p, c->f64,
+            ProfScope ps(c, K_OTF_ROWFFT, ls);
+            launch_otf_rowfft(ls, N, tc, ndir, nl, ln.D0t.p, c->tel.p, d_lp,
+                              (const int*)c->samp_p.p, c->samp_a.p, ln.Tq.p, c->tw64.p, c->f64,
                               c->fast_exp);
         }
         {
-            ProfScope ps(c, K_COLPASS);
-            launch_colpass(s, N, tc, nl, c->Tq.p, c->G.p, (double*)c->pre.p, c->f64);
+            ProfScope ps(c, K_COLPASS, ls);
+            launch_colpass(ls, N, tc, nl, ln.Tq.p, c->G.p, (double*)ln.pre.p, c->f64);
         }
-        double* d_fin = d_fin_all ? d_fin_all + (size_t)t0 * nl * per_stamp : (double*)c->fin.p;
+        double* d_fin = d_fin_all ? d_fin_all + (size_t)t0 * nl * per_stamp : (double*)ln.fin.p;
         {
-            ProfScope ps(c, K_CONV);
-            if (use_fft_conv) {
-                const size_t koff = (size_t)t0 * ksz;
-                launch_conv_fft(s, tc, nl, (const double*)c->pre.p, (const char*)c->ktt.p + koff,
+            ProfScope ps(c, K_CONV, ls);
+            const size_t koff = (size_t)t0 * ksz;
+            if (use_fft_conv)
+                launch_conv_fft(ls, tc, nl, (const double*)ln.pre.p, (const char*)c->ktt.p + koff,
                                 c->kmuse.p, d_fin);
-            } else {
-                const size_t koff = (size_t)t0 * ksz;
-                launch_conv(s, tc, nl, (const double*)c->pre.p, (const char*)c->ktt.p + koff,
+            else
+                launch_conv(ls, tc, nl, (const double*)ln.pre.p, (const char*)c->ktt.p + koff,
                             c->kmuse.p, d_fin, c->f64);
-            }
         }
         if (fit_out) {
-            ProfScope ps(c, K_FIT);
-            launch_fit(s, tc * nl, d_fin, d_fit_all + (size_t)t0 * nl * NFIT, c->f64);
+            ProfScope ps(c, K_FIT, ls);
+            launch_fit(ls, tc * nl, d_fin, d_fit_all + (size_t)t0 * nl * NFIT, c->f64);
         }
         if (psf_sum_out) {
-            ProfScope ps(c, K_STAMP_SUM);
-            launch_stamp_sum(s, tc, nl, d_fin, d_sum, t0 > 0 ? 1 : 0);
+            // per-lane partial sums in chunk order; combined below in lane order (deterministic)
+            ProfScope ps(c, K_STAMP_SUM, ls);
+            double* lsum = NL > 1 ? (double*)ln.sum.p : d_sum;
+            launch_stamp_sum(ls, tc, nl, d_fin, lsum, nchunk_lane[ci % NL] > 0 ? 1 : 0);
         }
         HIPCHK(hipGetLastError());
         if (!dev_out && psf_out) {
             HIPCHK(hipMemcpyAsync(psf_out + (size_t)t0 * nl * per_stamp, d_fin,
                                   (size_t)tc * nl * per_stamp * sizeof(double),
-                                  hipMemcpyDeviceToHost, s));
+                                  hipMemcpyDeviceToHost, ls));
         }
+        ++nchunk_lane[ci % NL];
         c->last_chunk_tasks = tc;
+        c->last_lane = ci % NL;
+    }
+    // join: everything queued on the lanes becomes a dependency of the main stream
+    for (int k = 1; k < NL; ++k) {
+        HIPCHK(hipEventRecord(c->lane[k].done, c->lane[k].stream));
+        HIPCHK(hipStreamWaitEvent(s, c->lane[k].done, 0));
+    }
+    if (psf_sum_out && NL > 1) {
+        // lane sums live in separate buffers: stage them contiguously and add in lane order
+        if ((rc = ensure(c, c->stage, (size_t)NL * nl * per_stamp * sizeof(double)))) return rc;
+        for (int k = 0; k < NL; ++k)
+            HIPCHK(hipMemcpyAsync((double*)c->stage.p + (size_t)k * nl * per_stamp, c->lane[k].sum.p,
+                                  (size_t)nl * per_stamp * sizeof(double), hipMemcpyDeviceToDevice, s));
+        ProfScope ps(c, K_STAMP_SUM);
+        launch_stamp_sum(s, NL, nl, (const double*)c->stage.p, d_sum, 0);
     }
     c->last_ndir = ndir;
     c->last_nl = nl;
@@ -673,11 +723,11 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
         is_real_r = true;
     } else if (!strcmp(what, "dphi0")) {
         n = (size_t)c->last_chunk_tasks * c->last_ndir * H1 * N;
-        src = c->D0t.p;
+        src = c->lane[c->last_lane].D0t.p;
         is_real_r = true;
     } else if (!strcmp(what, "pre")) {
         n = (size_t)c->last_chunk_tasks * c->last_nl * NS * NS;
-        src = c->pre.p;
+        src = c->lane[c->last_lane].pre.p;
     } else {
         return fail(MPSFR_E_INVALID, "unknown buffer '%s'", what);
     }
