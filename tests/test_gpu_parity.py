@@ -183,6 +183,29 @@ def test_chunking_and_repeat_are_bitwise_invariant(api):
     assert np.array_equal(d['psf'], a['psf'][perm])
 
 
+def test_pipeline_lanes_and_kernel_variants_agree(api):
+    """Two HIP-stream lanes vs one; FFT vs direct convolution; hardware exp vs expf."""
+    see, gl, l0 = api.synthetic_rows(64)
+    lb = np.linspace(465, 930, 35)
+    ps = api.grid_pixscale(128)
+    three = (np.arange(64) % 5 == 0).astype(np.uint8)
+    res = {}
+    for key, opts in (('base', {}), ('one_lane', {'streams': 1}), ('direct_conv', {'fft_conv': 0}),
+                      ('expf', {'fast_exp': 0})):
+        ctx = api.Context(dim=128, pixscale=ps, precision='mixed')
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        res[key] = ctx.reconstruct(lb, see, gl, l0, three, H)      # 2240 stamps: split over 2 lanes
+        ctx.close()
+    a, b = res['base'], res['one_lane']
+    assert np.array_equal(a['psf'], b['psf']) and np.array_equal(a['fit'], b['fit'])
+    np.testing.assert_allclose(a['psf_sum'], b['psf_sum'], rtol=1e-13)
+    for key in ('direct_conv', 'expf'):
+        assert rel_err(res[key]['psf'], a['psf']) < 1e-5, key
+    with pytest.raises(api.MpsfrError):
+        api.Context(dim=128, pixscale=ps).set_option('streams', 3)
+
+
 def test_edge_cases_and_errors(api):
     from muse_psfr_amd import MpsfrError
     ps = api.grid_pixscale(128)
