@@ -955,6 +955,19 @@ __device__ __forceinline__ float fit_exp<float>(float x) { return __expf(x); }
 template <>
 __device__ __forceinline__ double fit_exp<double>(double x) { return exp(x); }
 
+template <typename S>
+__device__ __forceinline__ S fit_rcp(S x);
+template <>
+__device__ __forceinline__ float fit_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x); }
+template <>
+__device__ __forceinline__ double fit_rcp<double>(double x) { return 1.0 / x; }
+template <typename S>
+__device__ __forceinline__ S fit_rsqrt(S x);
+template <>
+__device__ __forceinline__ float fit_rsqrt<float>(float x) { return __builtin_amdgcn_rsqf(x); }
+template <>
+__device__ __forceinline__ double fit_rsqrt<double>(double x) { return 1.0 / sqrt(x); }
+
 // WN = true : v = (I, p0, q0, w, n), 1/a^2 = 4 (2^(1/n) - 1) / w^2
 // WN = false: v = (I, p0, q0, a, n)
 // dpix: the lane's 25 pixels in registers (STRIDE = 1) or the stamp in memory (STRIDE = 64,
@@ -986,7 +999,7 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int lane, cons
         const RE mo = I * e;
         const RE r = mo - (RE)dpix[m * STRIDE];
         chi2 += r * r;
-        const RE cm = mo * n / gg;
+        const RE cm = mo * n * fit_rcp<RE>(gg);
         RE J[5];
         J[0] = e;
         J[1] = cm * (RE)2 * K * dp;
@@ -1010,76 +1023,104 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int lane, cons
     for (int k = 0; k < 5; ++k) ne.g[k] = wave_sum(g[k]);
 }
 
-// solve (A + mu diag(A)) x = -g by Cholesky; returns false if not positive definite.
-// Fully unrolled so that the 5x5 factor lives in registers (dynamic indexing put it in scratch).
-template <typename T>
-__device__ __forceinline__ bool lm_solve(const NormEqT<T>& ne, double mu, double* x) {
-    double L[5][5];
+// Cholesky factor of the Marquardt-scaled normal matrix  A'_ij = A_ij / (d_i d_j) + mu delta_ij,
+// d_i = sqrt(A_ii) -- the same system as (A + mu diag A) x = -g, but with a unit diagonal, which
+// is what lets the float phase factor it in float.  Fully unrolled: the factor lives in registers
+// (dynamic indexing put it in scratch).  Li holds 1 / L_ii.  Returns false if not positive definite.
+template <typename S, typename T>
+__device__ __forceinline__ bool chol5(const NormEqT<T>& ne, double mu, S L[5][5], S Li[5], S id[5]) {
+    S A[5][5];
     {
         int k = 0;
 #pragma unroll
         for (int i = 0; i < 5; ++i)
 #pragma unroll
             for (int j = i; j < 5; ++j) {
-                L[i][j] = (double)ne.a[k];
-                L[j][i] = (double)ne.a[k];
+                A[i][j] = (S)ne.a[k];
+                A[j][i] = (S)ne.a[k];
                 ++k;
             }
     }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) L[i][i] *= (1.0 + mu);
     bool ok = true;
 #pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        ok = ok && (A[i][i] > (S)0);
+        id[i] = fit_rsqrt<S>(A[i][i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) L[i][j] = A[i][j] * id[i] * id[j];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) L[i][i] = (S)(1.0 + mu);
+#pragma unroll
     for (int j = 0; j < 5; ++j) {
-        double s = L[j][j];
+        S s = L[j][j];
 #pragma unroll
         for (int q = 0; q < j; ++q) s -= L[j][q] * L[j][q];
-        ok = ok && (s > 0.0);
-        const double dj = sqrt(s);
-        const double idj = 1.0 / dj;
-        L[j][j] = dj;
+        ok = ok && (s > (S)0);
+        Li[j] = fit_rsqrt<S>(s);
+        L[j][j] = s * Li[j];
 #pragma unroll
         for (int i = j + 1; i < 5; ++i) {
-            double t = L[i][j];
+            S t = L[i][j];
 #pragma unroll
             for (int q = 0; q < j; ++q) t -= L[i][q] * L[j][q];
-            L[i][j] = t * idj;
+            L[i][j] = t * Li[j];
         }
     }
-    if (!ok) return false;
-    double y[5];
+    return ok;
+}
+
+// x = A^-1 b through the factor of chol5 (b and x in unscaled units)
+template <typename S>
+__device__ __forceinline__ void chol5_solve(const S L[5][5], const S Li[5], const S id[5],
+                                            const S b[5], double* x) {
+    S y[5], z[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        double t = -(double)ne.g[i];
+        S t = b[i] * id[i];
 #pragma unroll
         for (int q = 0; q < i; ++q) t -= L[i][q] * y[q];
-        y[i] = t / L[i][i];
+        y[i] = t * Li[i];
     }
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
-        double t = y[i];
+        S t = y[i];
 #pragma unroll
-        for (int q = i + 1; q < 5; ++q) t -= L[q][i] * x[q];
-        x[i] = t / L[i][i];
+        for (int q = i + 1; q < 5; ++q) t -= L[q][i] * z[q];
+        z[i] = t * Li[i];
     }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) x[i] = (double)(z[i] * id[i]);
+}
+
+// solve (A + mu diag(A)) x = -g; S = arithmetic type of the factorisation
+template <typename S, typename T>
+__device__ __forceinline__ bool lm_solve(const NormEqT<T>& ne, double mu, double* x) {
+    S L[5][5], Li[5], id[5], b[5];
+    if (!chol5<S, T>(ne, mu, L, Li, id)) return false;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) b[i] = -(S)ne.g[i];
+    chol5_solve<S>(L, Li, id, b, x);
     return true;
 }
 
-// inverse of the symmetric 5x5 (Cholesky); false if singular
+// inverse of the symmetric 5x5: one factorisation, five back-substitutions; false if singular
 template <typename T>
 __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][5]) {
-    NormEqT<T> e = ne;
-    bool ok = true;
+    double L[5][5], Li[5], id[5];
+    if (!chol5<double, T>(ne, 0.0, L, Li, id)) return false;
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
+        double b[5], x[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) e.g[k] = (k == c) ? (T)-1 : (T)0;
-        double x[5];
-        ok = lm_solve(e, 0.0, x) && ok;
+        for (int k = 0; k < 5; ++k) b[k] = (k == c) ? 1.0 : 0.0;
+        chol5_solve<double>(L, Li, id, b, x);
 #pragma unroll
         for (int k = 0; k < 5; ++k) cov[k][c] = x[k];
     }
-    return ok;
+    return true;
 }
 
 template <typename RE>
@@ -1127,7 +1168,7 @@ __global__ void __launch_bounds__(256) k_fit_coarse(int nstamp, const double* __
     while (it < maxit) {
         ++it;
         double dx[5];
-        if (!lm_solve(ne, mu, dx)) {
+        if (!lm_solve<RE, RE>(ne, mu, dx)) {
             mu *= nu;
             nu *= 2.0;
             if (mu > 1.0e15) { status = 2; break; }
@@ -1207,7 +1248,7 @@ __global__ void __launch_bounds__(256) k_fit_finish(int nstamp, const double* __
             NormEq np;
             moffat_accumulate<double, true, double, 64>(src + lane, lane, v, np);
             double dx[5];
-            if (!lm_solve(np, 1.0e-10, dx)) break;
+            if (!lm_solve<double, double>(np, 1.0e-10, dx)) break;
             double rel = 0.0;
             bool inside = true;
 #pragma unroll
