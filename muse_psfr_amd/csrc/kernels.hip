@@ -920,13 +920,12 @@ k_khat(const double* __restrict__ gam, const double* __restrict__ alp,
 // ------------------------------------------------------------------------------------------
 // K_FIT: 5-parameter circular Moffat least-squares fit per stamp (fit_psf_cube psfrec.py:861-871
 // -> mpdaf Image.moffat_fit(circular=True, fit_back=False)): I (1 + ((p-p0)^2+(q-q0)^2)/a^2)^-n,
-// unweighted, all 1600 pixels.  One wavefront per stamp, 25 pixels per lane held in registers.
+// unweighted, all 1600 pixels.  One workgroup (or one wavefront) per stamp, pixels in registers.
 // Levenberg-Marquardt (Marquardt scaling, Nielsen's gain-ratio damping update) iterated in the
 // better-conditioned variables (I, p0, q0, w = FWHM, n) -- the minimum is the same point.
 // Per-lane sums run in the evaluation type RE (float in mixed mode, double in f64 mode); the
-// 21 cross-lane reductions and the 5x5 solves are always fp64.
+// 5x5 solves of the float phase run in float on the Marquardt-scaled matrix.
 // ------------------------------------------------------------------------------------------
-constexpr int NPIX_LANE = NS * NS / 64;   // 25
 
 template <typename T>
 struct NormEqT {
@@ -968,13 +967,18 @@ __device__ __forceinline__ float fit_rsqrt<float>(float x) { return __builtin_am
 template <>
 __device__ __forceinline__ double fit_rsqrt<double>(double x) { return 1.0 / sqrt(x); }
 
-// WN = true : v = (I, p0, q0, w, n), 1/a^2 = 4 (2^(1/n) - 1) / w^2
-// WN = false: v = (I, p0, q0, a, n)
-// dpix: the lane's 25 pixels in registers (STRIDE = 1) or the stamp in memory (STRIDE = 64,
-// dpix already offset by the lane)
-template <typename RE, bool WN, typename DT, int STRIDE = 1>
-__device__ __forceinline__ void moffat_accumulate(const DT* dpix, int lane, const double* v,
-                                                  NormEqT<RE>& ne) {
+// Normal equations of the Moffat model at v over the thread's pixels o = first + m * stride
+// (m < NPX, o < 1600), reduced over the TPS threads that share the stamp.
+//   WN = true : v = (I, p0, q0, w, n), 1/a^2 = 4 (2^(1/n) - 1) / w^2
+//   WN = false: v = (I, p0, q0, a, n)
+// dpix: the thread's pixels in registers (MEM = false) or the stamp in memory (MEM = true).
+// Cross-lane sums run in the evaluation type: the float phase only has to reach the basin of
+// convergence (tol 1e-3); the polish and the f64 mode reduce in double.  With more than one wave
+// per stamp the wave sums meet in LDS (fixed order); every thread ends up with the same totals.
+template <typename RE, bool WN, bool MEM, int NPX, int WPS, typename DT>
+__device__ __forceinline__ void moffat_accumulate(const DT* dpix, int first, const double* v,
+                                                  NormEqT<RE>& ne, double (*red)[24]) {
+    constexpr int STRIDE = 64 * WPS;
     RE a[15], g[5], chi2 = (RE)0;
 #pragma unroll
     for (int k = 0; k < 15; ++k) a[k] = (RE)0;
@@ -987,17 +991,18 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int lane, cons
     const double dKn_d = WN ? -(s_d + 1.0) * 0.69314718055994530942 / (n_d * n_d * s_d) : 0.0;
     const RE I = (RE)v[0], p0 = (RE)v[1], q0 = (RE)v[2], n = (RE)n_d, K = (RE)K_d;
     const RE i3 = (RE)(1.0 / v[3]), dKn = (RE)dKn_d;
-    constexpr int UF = STRIDE == 1 ? 5 : 1;
+    constexpr int UF = MEM ? 1 : (NPX > 5 ? (NPX % 5 == 0 ? 5 : NPX) : NPX);
 #pragma unroll UF
-    for (int m = 0; m < NPIX_LANE; ++m) {
-        const int o = lane + m * 64;
+    for (int m = 0; m < NPX; ++m) {
+        const int o = first + m * STRIDE;
+        if (NPX * STRIDE != NS * NS && o >= NS * NS) break;
         const RE dp = (RE)(o / NS) - p0, dq = (RE)(o % NS) - q0;
         const RE u = dp * dp + dq * dq;
         const RE gg = (RE)1 + u * K;
         const RE lg = fit_log<RE>(gg);
         const RE e = fit_exp<RE>(-n * lg);
         const RE mo = I * e;
-        const RE r = mo - (RE)dpix[m * STRIDE];
+        const RE r = mo - (RE)(MEM ? dpix[o] : dpix[m]);
         chi2 += r * r;
         const RE cm = mo * n * fit_rcp<RE>(gg);
         RE J[5];
@@ -1014,13 +1019,31 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int lane, cons
             for (int y = x; y < 5; ++y) a[k++] += J[x] * J[y];
         }
     }
-    // cross-lane sums in the evaluation type: the float phase only has to reach the basin of
-    // convergence (tol 1e-3), the polish and the f64 mode reduce in double
     ne.chi2 = wave_sum(chi2);
 #pragma unroll
     for (int k = 0; k < 15; ++k) ne.a[k] = wave_sum(a[k]);
 #pragma unroll
     for (int k = 0; k < 5; ++k) ne.g[k] = wave_sum(g[k]);
+    if constexpr (WPS > 1) {
+        static_assert(WPS == 4, "cross-wave reduction written for 4 waves");
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 15; ++k) red[wave][k] = (double)ne.a[k];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) red[wave][15 + k] = (double)ne.g[k];
+            red[wave][20] = (double)ne.chi2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 15; ++k)
+            ne.a[k] = (RE)((red[0][k] + red[1][k]) + (red[2][k] + red[3][k]));
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            ne.g[k] = (RE)((red[0][15 + k] + red[1][15 + k]) + (red[2][15 + k] + red[3][15 + k]));
+        ne.chi2 = (RE)((red[0][20] + red[1][20]) + (red[2][20] + red[3][20]));
+        __syncthreads();
+    }
 }
 
 // Cholesky factor of the Marquardt-scaled normal matrix  A'_ij = A_ij / (d_i d_j) + mu delta_ij,
@@ -1123,45 +1146,76 @@ __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][
     return true;
 }
 
-template <typename RE>
-__global__ void __launch_bounds__(256) k_fit_coarse(int nstamp, const double* __restrict__ stamps,
+template <typename RE, int WPS>
+__global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restrict__ stamps,
                                              double* __restrict__ fit) {
+    constexpr int TPS = 64 * WPS;                         // threads per stamp
+    constexpr int NPX = (NS * NS + TPS - 1) / TPS;        // pixels per thread: 25 or 7
+    __shared__ double red[4][24];
     const int lane = threadIdx.x & 63;
-    const int st = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (st >= nstamp) return;   // whole wave exits together
+    const int first = WPS == 1 ? lane : (int)threadIdx.x;
+    const int st = WPS == 1 ? blockIdx.x * 4 + (threadIdx.x >> 6) : (int)blockIdx.x;
+    if (st >= nstamp) return;   // WPS == 1: the whole wave exits together; WPS == 4: never taken
     const double* src = stamps + (size_t)st * NS * NS;
-    RE dpix[NPIX_LANE];
+    RE dpix[NPX];
     double best = -1.0e300;
     int besto = 0;
 #pragma unroll
-    for (int m = 0; m < NPIX_LANE; ++m) {
-        const double d = src[lane + m * 64];
-        dpix[m] = (RE)d;
-        if (d > best) { best = d; besto = lane + m * 64; }
+    for (int m = 0; m < NPX; ++m) {
+        const int o = first + m * TPS;
+        const double d = o < NS * NS ? src[o] : -1.0e300;
+        dpix[m] = o < NS * NS ? (RE)d : (RE)0;
+        if (d > best) { best = d; besto = o; }
     }
-    // argmax over the wave (first maximum in C order, as np.argmax)
+    // argmax (first maximum in C order, as np.argmax) and the pixel count above half maximum
+    auto arg_reduce = [&]() {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_xor(best, o, 64);
-        const int oo = __shfl_xor(besto, o, 64);
-        if (ob > best || (ob == best && oo < besto)) { best = ob; besto = oo; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o, 64);
+            const int oo = __shfl_xor(besto, o, 64);
+            if (ob > best || (ob == best && oo < besto)) { best = ob; besto = oo; }
+        }
+        if constexpr (WPS > 1) {
+            const int wave = threadIdx.x >> 6;
+            if (lane == 0) { red[wave][0] = best; red[wave][1] = (double)besto; }
+            __syncthreads();
+            best = red[0][0];
+            besto = (int)red[0][1];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const double ob = red[w][0];
+                const int oo = (int)red[w][1];
+                if (ob > best || (ob == best && oo < besto)) { best = ob; besto = oo; }
+            }
+            __syncthreads();
+        }
+    };
+    arg_reduce();
+    int cnt = 0;
+#pragma unroll
+    for (int m = 0; m < NPX; ++m)
+        cnt += (first + m * TPS < NS * NS && (double)dpix[m] > 0.5 * best) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if constexpr (WPS > 1) {
+        const int wave = threadIdx.x >> 6;
+        if (lane == 0) red[wave][0] = (double)cnt;
+        __syncthreads();
+        cnt = (int)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0]));
+        __syncthreads();
     }
     // start values: peak and its position, FWHM from the area above half maximum, n = 2.5.
     // (The least-squares minimum is unique -- SURVEY.md 8(c) -- so the start only sets the
     // iteration count; the oracle starts from fwhm = 4 px, n = 2.)
-    int cnt = 0;
-#pragma unroll
-    for (int m = 0; m < NPIX_LANE; ++m) cnt += (double)dpix[m] > 0.5 * best ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     double fw0 = 2.0 * sqrt((double)cnt / kPi);
     fw0 = fmin(fmax(fw0, 1.5), (double)NS);
     double v[5] = {best, (double)(besto / NS), (double)(besto % NS), fw0, 2.5};
     // float evaluation only has to reach the basin of quadratic convergence: the fp64 polish
-    // below finishes the job
+    // below finishes the job.  Every thread of the stamp carries the same LM state (the totals of
+    // moffat_accumulate are identical in all of them), so the control flow is uniform.
     const double tol = sizeof(RE) == 4 ? 1.0e-3 : 1.0e-10;
     NormEqT<RE> ne;
-    moffat_accumulate<RE, true, RE>(dpix, lane, v, ne);
+    moffat_accumulate<RE, true, false, NPX, WPS>(dpix, first, v, ne, red);
     double mu = 1.0e-2, nu = 2.0;
     int it = 0, status = 1;
     const int maxit = 200;
@@ -1190,7 +1244,7 @@ __global__ void __launch_bounds__(256) k_fit_coarse(int nstamp, const double* __
         NormEqT<RE> nn;
         double rho = -1.0;
         if (inside) {
-            moffat_accumulate<RE, true, RE>(dpix, lane, vn, nn);
+            moffat_accumulate<RE, true, false, NPX, WPS>(dpix, first, vn, nn, red);
             // predicted decrease of chi2: dx^T (mu D dx - g)
             double pred = 0.0;
             const int dg[5] = {0, 5, 9, 12, 14};
@@ -1212,49 +1266,20 @@ __global__ void __launch_bounds__(256) k_fit_coarse(int nstamp, const double* __
             if (mu > 1.0e15) { status = 0; break; }   // no further descent: at the minimum
         }
     }
-    if (lane == 0) {       // hand the (I, p0, q0, w, n) solution to k_fit_finish
-        double* o = fit + (size_t)st * NFIT;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) o[k] = v[k];
-        o[7] = (double)it;
-        o[14] = (double)status;
-    }
-}
-
-// second half of the fit: fp64 Gauss-Newton polish of the float solution (mixed mode), then the
-// normal equations in (a, n) for chi2 and the covariance.  Separate kernel so that the float LM
-// above keeps a small register footprint (the fused kernel needed 202-256 VGPRs).
-template <typename RE>
-__global__ void __launch_bounds__(256) k_fit_finish(int nstamp, const double* __restrict__ stamps,
-                                                    double* __restrict__ fit) {
-    const int lane = threadIdx.x & 63;
-    const int st = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (st >= nstamp) return;   // whole wave exits together
-    const double* src = stamps + (size_t)st * NS * NS;
-    double* frow = fit + (size_t)st * NFIT;
-    double v[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) v[k] = frow[k];
-    int it = (int)frow[7], status = (int)frow[14];
-    RE dpix[NPIX_LANE];
-#pragma unroll
-    for (int m = 0; m < NPIX_LANE; ++m) dpix[m] = (RE)src[lane + m * 64];
-    NormEqT<RE> ne;
     if constexpr (sizeof(RE) == 4) {
         // The float evaluation has systematic errors of ~1e-6 in the wings (v_log/v_exp), enough
         // to move beta by a few 1e-4 on flat-topped stamps.  Polish with fp64 Gauss-Newton steps
         // from the float solution (quadratic convergence: one or two suffice).
         for (int pz = 0; pz < 6 && status != 2; ++pz) {
             NormEq np;
-            moffat_accumulate<double, true, double, 64>(src + lane, lane, v, np);
+            moffat_accumulate<double, true, true, NPX, WPS>(src, first, v, np, red);
             double dx[5];
             if (!lm_solve<double, double>(np, 1.0e-10, dx)) break;
             double rel = 0.0;
-            bool inside = true;
 #pragma unroll
             for (int k = 0; k < 5; ++k) rel = fmax(rel, fabs(dx[k]) / (fabs(v[k] + dx[k]) + 1.0e-300));
-            inside = v[3] + dx[3] > 1.0e-3 && v[4] + dx[4] > 1.0e-2 && v[4] + dx[4] < 1.0e3 &&
-                     rel < 0.1;
+            const bool inside = v[3] + dx[3] > 1.0e-3 && v[4] + dx[4] > 1.0e-2 &&
+                                v[4] + dx[4] < 1.0e3 && rel < 0.1;
             if (!inside) break;
 #pragma unroll
             for (int k = 0; k < 5; ++k) v[k] += dx[k];
@@ -1267,8 +1292,8 @@ __global__ void __launch_bounds__(256) k_fit_finish(int nstamp, const double* __
     const double s2 = exp2(1.0 / n) - 1.0, sq = sqrt(s2);
     const double al = fabs(v[3]) / (2.0 * sq);
     double va[5] = {v[0], v[1], v[2], al, n};
-    moffat_accumulate<RE, false, RE>(dpix, lane, va, ne);
-    if (lane == 0) {
+    moffat_accumulate<RE, false, false, NPX, WPS>(dpix, first, va, ne, red);
+    if (threadIdx.x == 0 || (WPS == 1 && lane == 0)) {
         double* o = fit + (size_t)st * NFIT;
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = al; o[4] = n;
         o[5] = fabs(v[3]);
@@ -1492,14 +1517,14 @@ void launch_conv_fft(hipStream_t s, int ntask, int nl, const double* d_pre, cons
 
 void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit, bool f64) {
     if (nstamp <= 0) return;
+    // One wavefront per stamp (25 pixels per lane).  The kernel also instantiates with a whole
+    // workgroup per stamp (WPS = 4, 6-7 pixels per thread, wave sums meeting in LDS); measured on
+    // MI355X that is 1.8x slower at 3500 stamps (every wave repeats the 5x5 solves, 2 WGs/CU).
     const dim3 grid((nstamp + 3) / 4);
-    if (f64) {
-        hipLaunchKernelGGL(k_fit_coarse<double>, grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
-        hipLaunchKernelGGL(k_fit_finish<double>, grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
-    } else {
-        hipLaunchKernelGGL(k_fit_coarse<float>, grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
-        hipLaunchKernelGGL(k_fit_finish<float>, grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
-    }
+    if (f64)
+        hipLaunchKernelGGL((k_fit<double, 1>), grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
+    else
+        hipLaunchKernelGGL((k_fit<float, 1>), grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
 }
 
 void launch_stamp_sum(hipStream_t s, int ntask, int nl, const double* d_fin, double* d_sum,
