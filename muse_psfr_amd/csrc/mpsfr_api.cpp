@@ -75,7 +75,7 @@ struct mpsfr_ctx {
         hipEvent_t done = nullptr;
         DevBuf C, s00, D0t, Tq, pre, fin, sum;
     };
-    static constexpr int MAX_LANES = 2;
+    static constexpr int MAX_LANES = 4;
     Lane lane[MAX_LANES];
     int nlanes = 2;
     hipEvent_t tables_ready = nullptr;
@@ -346,7 +346,8 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
     } else if (!strcmp(key, "fast_exp")) {
         c->fast_exp = value != 0.0;
     } else if (!strcmp(key, "streams")) {
-        if (value != 1.0 && value != 2.0) return fail(MPSFR_E_INVALID, "streams must be 1 or 2");
+        if (value < 1.0 || value > 4.0 || value != (int)value)
+            return fail(MPSFR_E_INVALID, "streams must be 1..4");
         c->nlanes = (int)value;
     } else if (!strcmp(key, "fft_conv")) {
         c->fft_conv = value != 0.0;
@@ -547,7 +548,8 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         const double per_task = (double)ndir * (N / 2 + NAO / 2) * H1 * 16.0;
         const int cap = (int)(4.0 * 1024 * 1024 * 1024 / per_task);
         if (TC > cap) TC = cap < 1 ? 1 : cap;
-        if (NL > 1 && ntask <= TC && (size_t)ntask * nl >= 2048) TC = (ntask + 1) / 2;
+        if (NL > 1 && (size_t)ntask * nl >= (size_t)1024 * NL && ntask <= TC * NL)
+            TC = (ntask + NL - 1) / NL;     // one chunk per lane, >= 1024 stamps each
     }
     if (TC > ntask) TC = ntask;
     if (ntask <= TC) NL = 1;
@@ -589,7 +591,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         HIPCHK(hipEventRecord(c->tables_ready, s));
         for (int k = 1; k < NL; ++k) HIPCHK(hipStreamWaitEvent(c->lane[k].stream, c->tables_ready, 0));
     }
-    int nchunk_lane[mpsfr_ctx::MAX_LANES] = {0, 0};
+    int nchunk_lane[mpsfr_ctx::MAX_LANES] = {0, 0, 0, 0};
     int ci = 0;
     for (int t0 = 0; t0 < ntask; t0 += TC, ++ci) {
         const int tc = (ntask - t0) < TC ? (ntask - t0) : TC;

@@ -203,7 +203,7 @@ def test_pipeline_lanes_and_kernel_variants_agree(api):
     for key in ('direct_conv', 'expf'):
         assert rel_err(res[key]['psf'], a['psf']) < 1e-5, key
     with pytest.raises(api.MpsfrError):
-        api.Context(dim=128, pixscale=ps).set_option('streams', 3)
+        api.Context(dim=128, pixscale=ps).set_option('streams', 5)
 
 
 def test_edge_cases_and_errors(api):
