@@ -11,9 +11,13 @@ from conftest import H
 pytestmark = pytest.mark.gpu
 
 
+_REF_MASKS = []
+
+
 @pytest.fixture(scope='module')
-def api():
+def api(ref_masks):
     import muse_psfr_amd
+    _REF_MASKS.append(ref_masks)      # the CLI tests patch the host masks with the golden ones
     return muse_psfr_amd
 
 
@@ -118,3 +122,41 @@ def test_compute_psf_against_golden(api, golden, ref_masks):
     assert np.abs(np.asarray(tbl2['n']) - ofit[:, 4]).max() < 1e-4
     with pytest.raises(ValueError):                      # psfrec.py:663-683 at the native grid
         api.compute_psf([465.0], 1.0, 0.7, 25.0, verbose=False)
+
+
+def test_script(api, tmp_path, caplog, monkeypatch):
+    """test_psfrec.py:103-144: `--values 1,0.7,25` -> the three-wavelength table in the log file
+    and in the log records; `--values 1,0.7,1000` -> 'No results'."""
+    from muse_psfr_amd import cli, psfrec
+    monkeypatch.setattr(psfrec, 'host_cutoff_masks', lambda: _REF_MASKS[0])
+    with pytest.raises(SystemExit, match='No results'):
+        cli.main(['--values', '1,0.7,1000'])
+    caplog.clear()
+    logfile = os.path.join(str(tmp_path), 'muse-psfr2.log')
+    with caplog.at_level(logging.INFO, logger='muse_psfr_amd'):
+        cli.main(['--no-color', '--values', '1,0.7,25', '--logfile', logfile])
+    lines = open(logfile).read().splitlines()
+    assert lines[2:] == ['-' * 68, 'Sparta Seeing: 1.00 arcsec GL: 0.70 L0:25.00 m',
+                         'LBDA 5000 7000 9000', 'FWHM 0.85 0.73 0.62', 'BETA 2.73 2.55 2.23', '-' * 68]
+    records = [r for r in caplog.records if r.levelname != 'DEBUG']
+    assert records[6].message == 'LBDA 5000 7000 9000'
+    assert records[7].message == 'FWHM 0.85 0.73 0.62'
+    assert records[8].message == 'BETA 2.73 2.55 2.23'
+
+
+def test_script_with_file(api, tmp_path, monkeypatch):
+    """test_psfrec.py:147-170: file input, log-file text, output FITS extensions."""
+    from muse_psfr_amd import cli, psfrec, _minifits
+    monkeypatch.setattr(psfrec, 'host_cutoff_masks', lambda: _REF_MASKS[0])
+    testfile = os.path.join(str(tmp_path), 'sparta.fits')
+    api.create_sparta_table(outfile=testfile)
+    logfile = os.path.join(str(tmp_path), 'muse_psfr.log')
+    outfile = os.path.join(str(tmp_path), 'out.fits')
+    cli.main([testfile, '--no-color', '--logfile', logfile, '--outfile', outfile])
+    fits, _ = psfrec._astropy()
+    hdul = (fits or _minifits).open(outfile)
+    assert [h.name for h in hdul] == ['PRIMARY', 'SPARTA_ATM_DATA', 'FIT_ROWS', 'FIT_MEAN', 'PSF_MEAN']
+    lines = open(logfile).read().splitlines()
+    assert lines[2:] == ['OB None None Airmass 0.00-0.00', '-' * 68,
+                         'Sparta Seeing: 1.00 arcsec GL: 0.70 L0:25.00 m', 'LBDA 5000 7000 9000',
+                         'FWHM 0.85 0.73 0.62', 'BETA 2.73 2.55 2.23', '-' * 68]

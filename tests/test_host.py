@@ -165,3 +165,12 @@ def test_shard_bounds():
     assert shard_bounds(1000, 8) == [(i * 125, (i + 1) * 125) for i in range(8)]
     assert shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert shard_bounds(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+
+
+def test_cli_argument_errors():
+    """test_psfrec.py:104-108: the CLI's argument errors (no GPU needed)."""
+    from muse_psfr_amd.cli import main
+    with pytest.raises(SystemExit, match='no input file provided'):
+        main([])
+    with pytest.raises(SystemExit, match='--values must contain a list.*'):
+        main(['--values', '0.1,0.2'])
