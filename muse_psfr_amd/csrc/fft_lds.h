@@ -114,9 +114,12 @@ struct Plan<256> {
     static constexpr int NP = 3, TPR = 32, SLOTS = 8;
     static constexpr int radix[5] = {8, 8, 4, 1, 1};
 };
+#ifndef MPSFR_SLOTS512
+#define MPSFR_SLOTS512 4
+#endif
 template <>
 struct Plan<512> {
-    static constexpr int NP = 3, TPR = 64, SLOTS = 4;
+    static constexpr int NP = 3, TPR = 64, SLOTS = MPSFR_SLOTS512;
     static constexpr int radix[5] = {8, 8, 8, 1, 1};
 };
 template <>

@@ -346,12 +346,19 @@ k_moffat_kernels(const double* __restrict__ gam, const double* __restrict__ alp,
 // directions of psfrec.py:674 commutes with the FFT), forward FFT along the line, and the
 // bilinear-weighted extraction of the NS sampled positions -> Tq[task][l][v][i].
 // ------------------------------------------------------------------------------------------
+// exp(c * d) for the OTF.  FAST (float only): the caller pre-multiplies c by log2(e) and the
+// hardware exp2 is used directly: one multiply + v_exp_f32 per value.
+template <typename R, bool FAST>
+__device__ __forceinline__ R exp_scale(R c) {
+    if constexpr (FAST && sizeof(R) == 4) return c * (R)1.44269504088896340736;
+    else return c;
+}
 template <typename R, bool FAST>
 __device__ __forceinline__ R exp_sel(R x) {
     if constexpr (sizeof(R) == 8) {
         return exp(x);
     } else if constexpr (FAST) {
-        return __expf(x);      // v_exp_f32(x log2 e): 2 instructions instead of ~12
+        return __builtin_amdgcn_exp2f(x);
     } else {
         return expf(x);
     }
@@ -401,7 +408,8 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
     // two wavelengths per complex transform: z = otf(la) + i otf(lb), both real lines
     for (int l = 0; l < nl; l += 2) {
         const bool two = l + 1 < nl;
-        const R ca = (R)lp[l].c, cb = (R)lp[two ? l + 1 : l].c;
+        const R ca = exp_scale<R, FASTEXP>((R)lp[l].c);
+        const R cb = exp_scale<R, FASTEXP>((R)lp[two ? l + 1 : l].c);
         cx<R> x[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
