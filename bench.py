@@ -211,7 +211,12 @@ def main():
                          'achieved': round(achieved, 1), 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': round(achieved / 8000.0, 4), 'traffic': traffic,
                          'avg_launch_ms': round(avg_s * 1e3, 4), 'launches': nlaunch,
-                         'algorithmic_bytes_per_launch': alg_bytes},
+                         'algorithmic_bytes_per_launch': alg_bytes,
+                         'note': 'algorithmic bytes = SURVEY 8(d) figure for this kernel (2 p N^2 per '
+                                 'task x dir x lambda, i.e. full-plane passes); the restructured kernel '
+                                 'never materialises them (traffic = measured FETCH_SIZE + WRITE_SIZE), '
+                                 'so frac > 1; it is LDS-store/VALU bound (profiles/r01_pmc_summary.txt, '
+                                 'DESIGN.md section 5)'},
             'roofline_pipeline': {'bytes_per_psf': bytes_per_psf,
                                   'achieved_GBps': round(pipe, 1),
                                   'frac_of_8TBps': round(pipe / 8000.0, 4),
