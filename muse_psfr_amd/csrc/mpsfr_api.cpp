@@ -73,13 +73,13 @@ struct mpsfr_ctx {
     struct Lane {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
-        DevBuf C, s00, D0t, Tq, pre, fin, sum;
+        DevBuf C, s00, D0t, Tq, pre, fin;
     };
     static constexpr int MAX_LANES = 4;
     Lane lane[MAX_LANES];
     int nlanes = 2;
     hipEvent_t tables_ready = nullptr;
-    DevBuf fit, sum, stage;
+    DevBuf fit, sum, stage, lsum;      // lsum: [lanes][nl][40][40] per-lane partial stamp sums
     // small per-call parameters: one pinned host blob -> one device blob, no stream sync
     void* stage_h = nullptr;
     size_t stage_h_cap = 0;
@@ -327,12 +327,12 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         mpsfr_ctx::Lane& ln = c->lane[k];
         if (k > 0 && ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
         if (ln.done) (void)hipEventDestroy(ln.done);
-        DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.sum};
+        DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin};
         for (auto b : lb) release(*b);
     }
     if (c->stage_h) (void)hipHostFree(c->stage_h);
     DevBuf* all[] = {&c->tw64, &c->tel, &c->rows, &c->aotab, &c->samp_p, &c->samp_a, &c->G, &c->ktt,
-                     &c->kmuse, &c->fit, &c->sum, &c->stage, &c->params};
+                     &c->kmuse, &c->fit, &c->sum, &c->stage, &c->lsum, &c->params};
     for (auto b : all) release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -566,8 +566,8 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         if ((rc = ensure(c, ln.Tq, (size_t)TC * nl * H1 * NSH * 2 * rsize(c)))) return rc;
         if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
         if ((rc = ensure(c, ln.fin, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
-        if ((rc = ensure(c, ln.sum, (size_t)nl * per_stamp * sizeof(double)))) return rc;
     }
+    if (NL > 1 && (rc = ensure(c, c->lsum, (size_t)NL * nl * per_stamp * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->sum, (size_t)nl * per_stamp * sizeof(double)))) return rc;
     double* d_fin_all = nullptr;   // [ntask][nl][1600] if the caller gave a device buffer
     double* d_fit_all = nullptr;
@@ -640,7 +640,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         if (psf_sum_out) {
             // per-lane partial sums in chunk order; combined below in lane order (deterministic)
             ProfScope ps(c, K_STAMP_SUM, ls);
-            double* lsum = NL > 1 ? (double*)ln.sum.p : d_sum;
+            double* lsum = NL > 1 ? (double*)c->lsum.p + (size_t)(ci % NL) * nl * per_stamp : d_sum;
             launch_stamp_sum(ls, tc, nl, d_fin, lsum, nchunk_lane[ci % NL] > 0 ? 1 : 0);
         }
         HIPCHK(hipGetLastError());
@@ -658,14 +658,9 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         HIPCHK(hipEventRecord(c->lane[k].done, c->lane[k].stream));
         HIPCHK(hipStreamWaitEvent(s, c->lane[k].done, 0));
     }
-    if (psf_sum_out && NL > 1) {
-        // lane sums live in separate buffers: stage them contiguously and add in lane order
-        if ((rc = ensure(c, c->stage, (size_t)NL * nl * per_stamp * sizeof(double)))) return rc;
-        for (int k = 0; k < NL; ++k)
-            HIPCHK(hipMemcpyAsync((double*)c->stage.p + (size_t)k * nl * per_stamp, c->lane[k].sum.p,
-                                  (size_t)nl * per_stamp * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (psf_sum_out && NL > 1) {       // add the per-lane sums in lane order
         ProfScope ps(c, K_STAMP_SUM);
-        launch_stamp_sum(s, NL, nl, (const double*)c->stage.p, d_sum, 0);
+        launch_stamp_sum(s, NL, nl, (const double*)c->lsum.p, d_sum, 0);
     }
     c->last_ndir = ndir;
     c->last_nl = nl;
