@@ -10,8 +10,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmpsfr.so')
-SOURCES = ['kernels.hip', 'mpsfr_api.cpp']
-HEADERS = ['kernels.h', 'fft_lds.h', 'coeff_l0_table.h', os.path.join('..', '..', 'include', 'mpsfr.h')]
+SOURCES = ['stage_a.hip', 'per_lambda.hip', 'stamps.hip', 'mpsfr_api.cpp']
+HEADERS = ['kernels.h', 'fft_lds.h', 'device_common.h', 'coeff_l0_table.h',
+           os.path.join('..', '..', 'include', 'mpsfr.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-result',
          '-fno-slp-vectorize']
 
@@ -39,13 +40,17 @@ def build_library(force=False, verbose=True):
     objs = []
     bdir = os.path.join(HERE, 'build')
     os.makedirs(bdir, exist_ok=True)
-    for src in SOURCES:
+    procs = []
+    for src in SOURCES:          # the translation units compile in parallel
         obj = os.path.join(bdir, os.path.splitext(src)[0] + '.o')
         cmd = [hipcc] + FLAGS + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
     if verbose:
         print(' '.join(cmd), flush=True)

@@ -1,4 +1,5 @@
-// Launchers for the HIP kernels of the PSF-reconstruction hot path (implemented in kernels.hip).
+// Launchers for the HIP kernels of the PSF-reconstruction hot path (implemented in stage_a.hip,
+// per_lambda.hip and stamps.hip).
 // Host code (mpsfr_api.cpp) sees only these plain functions.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,0 +1,346 @@
+// HIP kernels of the muse-psfr PSF-reconstruction hot path, written for gfx950 (MI355X, wave64).
+// Reference citations are to /root/reference/muse_psfr/psfrec.py.  See DESIGN.md for the data
+// layout and the derivation of the restructured algorithm.
+//
+// Per-wavelength stage: sampling tables, OTF lines -> sampled first pass, second pass.
+#include "device_common.h"
+
+namespace mpsfr {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// K_GTABLE: per-wavelength sampling tables.  Sample i of the 40-pixel stamp sits at i*npixc/40
+// in the centred crop (psfrec.py:672-683); its left neighbour is native index
+// p_i = (floor(i npixc/40) - npixc/2) mod N with weight 1-a_i, a_i = frac.
+// G[l][v][j] = w_v ((1-a_j) W^-(v p_j) + a_j W^-(v (p_j+1))), W = exp(-2 pi i/N), w_v = 1 for
+// v in {0, N/2} else 2: bilinear interpolation folded into the second (column) pass.
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256)
+k_gtable(int N, const LamPar* __restrict__ lp, const cx<double>* __restrict__ twg,
+         int* __restrict__ samp_p, R* __restrict__ samp_a, cx<R>* __restrict__ G) {
+    const int l = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int npixc = lp[l].npixc;
+    if (idx < NS) {
+        const int q = idx * npixc;
+        samp_p[l * NS + idx] = ((q / NS - npixc / 2) % N + N) % N;
+        samp_a[l * NS + idx] = (R)((double)(q % NS) / NS);
+    }
+    if (idx >= (N / 2 + 1) * NS) return;
+    const int v = idx / NS, j = idx % NS;
+    const int q = j * npixc;
+    const int p = ((q / NS - npixc / 2) % N + N) % N;
+    const double a = (double)(q % NS) / NS;
+    const cx<double> w0 = twg[(int)(((long)v * p) % N)];
+    const cx<double> w1 = twg[(int)(((long)v * (p + 1)) % N)];
+    const double wv = (v == 0 || v == N / 2) ? 1.0 : 2.0;
+    // conj(W^(v p)) = exp(+2 pi i v p / N)
+    G[((size_t)l * (N / 2 + 1) + v) * NS + j] = {(R)(wv * ((1.0 - a) * w0.x + a * w1.x)),
+                                                 (R)(-wv * ((1.0 - a) * w0.y + a * w1.y))};
+}
+
+// ------------------------------------------------------------------------------------------
+// K_OTF_ROWFFT (dominant kernel): for one task and one line v of the transposed half plane, for
+// every wavelength: OTF line = tel * sum_dir exp(c_l * D0)  (psfrec.py:793-797; the mean over
+// directions of psfrec.py:674 commutes with the FFT), forward FFT along the line, and the
+// bilinear-weighted extraction of the NS sampled positions -> Tq[task][l][v][i].
+// ------------------------------------------------------------------------------------------
+// exp(c * d) for the OTF.  FAST (float only): the caller pre-multiplies c by log2(e) and the
+// hardware exp2 is used directly: one multiply + v_exp_f32 per value.
+template <typename R, bool FAST>
+__device__ __forceinline__ R exp_scale(R c) {
+    if constexpr (FAST && sizeof(R) == 4) return c * (R)1.44269504088896340736;
+    else return c;
+}
+template <typename R, bool FAST>
+__device__ __forceinline__ R exp_sel(R x) {
+    if constexpr (sizeof(R) == 8) {
+        return exp(x);
+    } else if constexpr (FAST) {
+        return __builtin_amdgcn_exp2f(x);
+    } else {
+        return expf(x);
+    }
+}
+
+template <typename R, int N, int ND, bool FASTEXP>
+__global__ void __launch_bounds__(LineCfg<N>::THREADS)
+k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ telT,
+             const LamPar* __restrict__ lp, const int* __restrict__ samp_p,
+             const R* __restrict__ samp_a, cx<R>* __restrict__ Tq,
+             const cx<double>* __restrict__ twg) {
+    using L = LineCfg<N>;
+    constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
+    constexpr int EPT = N / TPR;
+    constexpr bool REGTW = use_reg_twiddles<N>(), WS = L::WSYNC;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cx<R>* twl = reinterpret_cast<cx<R>*>(smem);          // only used when !REGTW
+    cx<R>* bufA = twl + (REGTW ? 0 : N);
+    cx<R>* bufB = bufA + SLOTS * NPAD;
+    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
+    const int v = blockIdx.x * SLOTS + slot;
+    const int task = blockIdx.y;
+    const bool valid = v <= N / 2;
+    const int vv = valid ? v : N / 2;
+    TwRegs<R, N> twr;
+    const cx<R>* twp;
+    if constexpr (REGTW) {
+        twr.init(twg, t);
+        twp = twr.w;
+    } else {
+        for (int i = threadIdx.x; i < N; i += THREADS) twl[i] = {(R)twg[i].x, (R)twg[i].y};
+        twp = twl;
+        __syncthreads();
+    }
+    cx<R>* a = bufA + slot * NPAD;
+    cx<R>* b = bufB + slot * NPAD;     // only used when a slot spans two wavefronts
+    R tel[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) tel[e] = telT[(size_t)vv * N + t + e * TPR];
+    const R* dline = D0t + ((size_t)task * ndir * (N / 2 + 1) + vv) * N;
+    const size_t dstride = (size_t)(N / 2 + 1) * N;
+    R dreg[ND == 1 ? EPT : 1];
+    if constexpr (ND == 1) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) dreg[e] = dline[t + e * TPR];
+    }
+    // two wavelengths per complex transform: z = otf(la) + i otf(lb), both real lines
+    for (int l = 0; l < nl; l += 2) {
+        const bool two = l + 1 < nl;
+        const R ca = exp_scale<R, FASTEXP>((R)lp[l].c);
+        const R cb = exp_scale<R, FASTEXP>((R)lp[two ? l + 1 : l].c);
+        cx<R> x[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            R ra = (R)0, rb = (R)0;
+            if constexpr (ND == 1) {
+                ra = exp_sel<R, FASTEXP>(ca * dreg[e]);
+                rb = exp_sel<R, FASTEXP>(cb * dreg[e]);
+            } else {
+                for (int d = 0; d < ndir; ++d) {
+                    const R dv = dline[d * dstride + t + e * TPR];
+                    ra += exp_sel<R, FASTEXP>(ca * dv);
+                    rb += exp_sel<R, FASTEXP>(cb * dv);
+                }
+            }
+            x[e] = {tel[e] * ra, two ? tel[e] * rb : (R)0};
+        }
+        const cx<R>* res = fft_forward_regs<R, N, REGTW>(x, a, b, twp, t);
+        if (valid) {
+            // F_a[p] = (Z[p] + conj Z[-p]) / 2,  F_b[p] = (Z[p] - conj Z[-p]) / 2i.
+            // Only samples i = 0..20: the OTF is real, so A[v][-p] = conj A[v][p], and the sample
+            // positions are symmetric about the centre (p_(40-i) + 1 = -p_i, weights swapped),
+            // hence Tq[v][40-i] = conj Tq[v][i].
+            for (int idx = t; idx < 2 * NSH; idx += TPR) {
+                const int which = idx / NSH, i = idx - which * NSH;
+                if (which == 1 && !two) continue;
+                const int ll = l + which;
+                const int p = samp_p[ll * NS + i];
+                const R w = samp_a[ll * NS + i];
+                const int q = p + 1 == N ? 0 : p + 1;
+                const int mp = p == 0 ? 0 : N - p, mq = q == 0 ? 0 : N - q;
+                const cx<R> zp = res[lds_pad(p)], zmp = res[lds_pad(mp)];
+                const cx<R> zq = res[lds_pad(q)], zmq = res[lds_pad(mq)];
+                cx<R> f0, f1;
+                const R h = (R)0.5;
+                if (which == 0) {
+                    f0 = {h * (zp.x + zmp.x), h * (zp.y - zmp.y)};
+                    f1 = {h * (zq.x + zmq.x), h * (zq.y - zmq.y)};
+                } else {
+                    f0 = {h * (zp.y + zmp.y), -h * (zp.x - zmp.x)};
+                    f1 = {h * (zq.y + zmq.y), -h * (zq.x - zmq.x)};
+                }
+                Tq[(((size_t)task * nl + ll) * (N / 2 + 1) + v) * NSH + i] = {
+                    ((R)1 - w) * f0.x + w * f1.x, ((R)1 - w) * f0.y + w * f1.y};
+            }
+        }
+        fft_sync<WS>();     // extraction reads done before the next transform overwrites
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K_COLPASS: second (column) pass restricted to the sampled positions,
+// stamp[i][j] = sum_v Re(G[l][v][j] * conj(Tq[v][i])), then clamp >= 0 (psfrec.py:680) and
+// normalise to sum 1 (:685).  With Tq[v][40-i] = conj Tq[v][i] only i = 0..20 is stored and
+//   P[i][j] = sum_v Gx Tx,  Q[i][j] = sum_v Gy Ty,  stamp[i][j] = P + Q,  stamp[40-i][j] = P - Q,
+// i.e. half the products of the plain form.  One workgroup per stamp; a lane holds a 3x5 tile
+// of (P, Q) pairs (7 x 8 tiles = 56 lanes), the four waves split the v range (32 lines staged
+// in LDS per step, 8 per wave) and the partial tiles are summed through LDS at the end.
+// ------------------------------------------------------------------------------------------
+template <typename R, int N>
+__global__ void __launch_bounds__(256)
+k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
+          double* __restrict__ pre) {
+    constexpr int VW = 8, VB = 4 * VW, TI = 3, TJ = 5, NV = N / 2 + 1;
+    constexpr int NPQ = NSH * NS;                 // 840 (P, Q) pairs
+    static_assert(NSH == 7 * TI && NS == 8 * TJ, "tile map");
+    // one raw buffer: staging {T [VB][NSH], G [VB][NS]} complex during the loop, then the
+    // partial tiles [4][NPQ] complex (P, Q)
+    constexpr size_t STAGE = (size_t)VB * (NSH + NS) * sizeof(cx<R>);
+    constexpr size_t RED = (size_t)4 * NPQ * sizeof(cx<R>);
+    __shared__ __align__(16) unsigned char raw[RED > STAGE ? RED : STAGE];
+    cx<R>(*sT)[NSH] = reinterpret_cast<cx<R>(*)[NSH]>(raw);
+    cx<R>(*sG)[NS] = reinterpret_cast<cx<R>(*)[NS]>(raw + VB * NSH * sizeof(cx<R>));
+    __shared__ double part[4];
+    __shared__ double tot;
+    const int l = blockIdx.x, task = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool act = lane < 56;
+    const int i0 = TI * (act ? lane >> 3 : 0), j0 = TJ * (lane & 7);
+    const cx<R>* Tp = Tq + ((size_t)task * nl + l) * NV * NSH;
+    const cx<R>* Gp = G + (size_t)l * NV * NS;
+    R accP[TI][TJ], accQ[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) { accP[a][b] = (R)0; accQ[a][b] = (R)0; }
+    constexpr int NET = (VB * NSH + 255) / 256, NEG = VB * NS / 256;
+    cx<R> rt[NET], rg[NEG];
+    auto fetch = [&](int v0) {
+#pragma unroll
+        for (int k = 0; k < NET; ++k) {
+            const int e = threadIdx.x + k * 256;
+            rt[k] = (e < VB * NSH && v0 * NSH + e < NV * NSH) ? Tp[(size_t)v0 * NSH + e]
+                                                            : cx<R>{(R)0, (R)0};
+        }
+#pragma unroll
+        for (int k = 0; k < NEG; ++k) {
+            const int e = threadIdx.x + k * 256;
+            rg[k] = v0 * NS + e < NV * NS ? Gp[(size_t)v0 * NS + e] : cx<R>{(R)0, (R)0};
+        }
+    };
+    fetch(0);
+    for (int v0 = 0; v0 < NV; v0 += VB) {
+#pragma unroll
+        for (int k = 0; k < NET; ++k) {
+            const int e = threadIdx.x + k * 256;
+            if (e < VB * NSH) (&sT[0][0])[e] = rt[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NEG; ++k) (&sG[0][0])[threadIdx.x + k * 256] = rg[k];
+        __syncthreads();
+        if (v0 + VB < NV) fetch(v0 + VB);      // prefetch the next block behind the FMAs
+#pragma unroll
+        for (int vb = 0; vb < VW; ++vb) {
+            const int vr = wave * VW + vb;
+            cx<R> t[TI], g[TJ];
+#pragma unroll
+            for (int k = 0; k < TI; ++k) t[k] = sT[vr][i0 + k];
+#pragma unroll
+            for (int k = 0; k < TJ; ++k) g[k] = sG[vr][j0 + k];
+#pragma unroll
+            for (int a = 0; a < TI; ++a)
+#pragma unroll
+                for (int b = 0; b < TJ; ++b) {
+                    accP[a][b] += g[b].x * t[a].x;
+                    accQ[a][b] += g[b].y * t[a].y;
+                }
+        }
+        __syncthreads();
+    }
+    // sum the four partial tiles
+    cx<R>* red = reinterpret_cast<cx<R>*>(raw);
+    if (act) {
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int b = 0; b < TJ; ++b)
+                red[wave * NPQ + (i0 + a) * NS + j0 + b] = {accP[a][b], accQ[a][b]};
+    }
+    __syncthreads();
+    constexpr int NO = (NS * NS + 255) / 256;
+    R val[NO];
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m < NO; ++m) {
+        const int o = threadIdx.x + m * 256;
+        R x = (R)0;
+        if (o < NS * NS) {
+            const int i = o / NS, j = o - i * NS;
+            const int e = (i < NSH ? i : NS - i) * NS + j;
+            const cx<R> a = red[e], b = red[NPQ + e], c = red[2 * NPQ + e], d = red[3 * NPQ + e];
+            const R P = (a.x + b.x) + (c.x + d.x), Q = (a.y + b.y) + (c.y + d.y);
+            x = i < NSH ? P + Q : P - Q;
+            if (x < (R)0) x = (R)0;
+            s += (double)x;
+        }
+        val[m] = x;
+    }
+    s = wave_sum(s);
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tot = (part[0] + part[1]) + (part[2] + part[3]);
+    __syncthreads();
+    const double inv = 1.0 / tot;
+    double* out = pre + ((size_t)task * nl + l) * NS * NS;
+#pragma unroll
+    for (int m = 0; m < NO; ++m) {
+        const int o = threadIdx.x + m * 256;
+        if (o < NS * NS) out[o] = (double)val[m] * inv;
+    }
+}
+
+}  // namespace
+
+void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void* d_tw64,
+                   int* d_samp_p, void* d_samp_a, void* d_G, bool f64) {
+    dim3 grid(((N / 2 + 1) * NS + 255) / 256, nl);
+    if (f64)
+        hipLaunchKernelGGL(k_gtable<double>, grid, dim3(256), 0, s, N, d_lp,
+                           (const cx<double>*)d_tw64, d_samp_p, (double*)d_samp_a,
+                           (cx<double>*)d_G);
+    else
+        hipLaunchKernelGGL(k_gtable<float>, grid, dim3(256), 0, s, N, d_lp,
+                           (const cx<double>*)d_tw64, d_samp_p, (float*)d_samp_a, (cx<float>*)d_G);
+}
+
+template <typename R, int NN, int ND, bool FE>
+static void launch_otf_t(hipStream_t s, int ntask, int ndir, int nl, const void* d_D0t,
+                         const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
+                         const void* d_samp_a, void* d_Tq, const void* d_tw64) {
+    constexpr int SL = LineCfg<NN>::SLOTS;
+    constexpr size_t sm = fft_smem<R, NN>(!use_reg_twiddles<NN>(), fft_nbuf<NN>());
+    allow_smem(k_otf_rowfft<R, NN, ND, FE>, sm);
+    dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntask);
+    hipLaunchKernelGGL((k_otf_rowfft<R, NN, ND, FE>), grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir,
+                       nl, (const R*)d_D0t, (const R*)d_tel, d_lp, d_samp_p, (const R*)d_samp_a,
+                       (cx<R>*)d_Tq, (const cx<double>*)d_tw64);
+}
+
+#define OTF_ARGS s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p, d_samp_a, d_Tq, d_tw64
+void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
+                       const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
+                       const void* d_samp_a, void* d_Tq, const void* d_tw64, bool f64,
+                       bool fast_exp) {
+    DISPATCH_N(N, {
+        if (f64) {
+            if (ndir == 1) launch_otf_t<double, NN, 1, false>(OTF_ARGS);
+            else launch_otf_t<double, NN, 0, false>(OTF_ARGS);
+        } else if (fast_exp) {
+            if (ndir == 1) launch_otf_t<float, NN, 1, true>(OTF_ARGS);
+            else launch_otf_t<float, NN, 0, true>(OTF_ARGS);
+        } else {
+            if (ndir == 1) launch_otf_t<float, NN, 1, false>(OTF_ARGS);
+            else launch_otf_t<float, NN, 0, false>(OTF_ARGS);
+        }
+    })
+}
+#undef OTF_ARGS
+
+void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, const void* d_G,
+                    double* d_pre, bool f64) {
+    dim3 grid(nl, ntask);
+    DISPATCH_N(N, {
+        if (f64)
+            hipLaunchKernelGGL((k_colpass<double, NN>), grid, dim3(256), 0, s, nl,
+                               (const cx<double>*)d_Tq, (const cx<double>*)d_G, d_pre);
+        else
+            hipLaunchKernelGGL((k_colpass<float, NN>), grid, dim3(256), 0, s, nl,
+                               (const cx<float>*)d_Tq, (const cx<float>*)d_G, d_pre);
+    })
+}
+
+
+}  // namespace mpsfr

@@ -1,0 +1,317 @@
+// HIP kernels of the muse-psfr PSF-reconstruction hot path, written for gfx950 (MI355X, wave64).
+// Reference citations are to /root/reference/muse_psfr/psfrec.py.  See DESIGN.md for the data
+// layout and the derivation of the restructured algorithm.
+//
+// Stage A, once per (task, direction): AO tables, telescope OTF, PSD -> structure function.
+#include "device_common.h"
+
+namespace mpsfr {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// K_AO_TABLES: row-independent tables of the AO-corrected zone (dsp4muse, psfrec.py:531-613 with
+// calc_mat_rec_glao_finale :218-364 (LSE, one DM layer) and calc_dsp_res_glao_finale :367-528).
+// tab[geom][dir][{T0,T1,noise}][a][b] with (a, b) = (fy index, fx index), i.e. already
+// transposed as psfrec.py:613 does, so that  PSD_AO[a][b] = VK * (cn2_0 T0 + cn2_1 T1) + noise.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ao_tables(AoGeom g, const uint8_t* __restrict__ mrec,
+                                                   const uint8_t* __restrict__ mres,
+                                                   double* __restrict__ tab) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= NAO * NAO) return;
+    const int d = blockIdx.y, geom = blockIdx.z;
+    const int i = pix / NAO, j = pix % NAO;              // i <-> fx, j <-> fy (reference layout)
+    const int ki = i < NAO / 2 ? i : i - NAO, kj = j < NAO / 2 ? j : j - NAO;
+    const double fx = ki / 16.0, fy = kj / 16.0;         // fftfreq(80, 0.2), psfrec.py:548
+    const double f = sqrt(fx * fx + fy * fy);
+    // psfrec.py:552-554 + :241-242: arg = arctan(fy/fx) folds the grid onto fx >= 0
+    const double gx = fabs(fx), gy = ki < 0 ? -fy : fy;
+    bool mr, ms;
+    if (mrec != nullptr) {
+        mr = mrec[pix] != 0;
+        ms = mres[pix] != 0;
+    } else {   // exact rule on the integer grid: fc = 1.5 = 24/16 (psfrec.py:254-257, 432-435)
+        const int ai = ki < 0 ? -ki : ki, aj = kj < 0 ? -kj : kj;
+        mr = ai >= 24 || aj >= 24;
+        ms = ai > 24 || aj > 24;
+    }
+    const double pitch = 8.0 / 24.0;
+    const double wamp = 2.0 * kPi * f * sinc_pi(pitch * gx) * sinc_pi(pitch * gy);  // |wfs|, :252
+    const int n = g.nlgs[geom];
+    const bool haveW = !mr && wamp != 0.0 && pix != 0;     // psfrec.py:339, 351-352
+    const double b0 = g.dir[0][d], b1 = g.dir[1][d];
+    const double bf = b0 * gx + b1 * gy;
+    const double theta_dm = 2.0 * kPi * 1.0 * kArcminH * bf;                       // :464
+    double T[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const double ph = 2.0 * kPi * (g.h[l] * kArcminH * bf -
+                                       (g.wind[0][l] * kDeltaT * gx + g.wind[1][l] * kDeltaT * gy));
+        double pr, pi_;
+        sincos(ph, &pi_, &pr);                                                      // :454-457
+        if (haveW && !ms) {
+            // sum_g (PbetaDM W_g) Mv[l,g] = (www/n) sum_g exp(i (theta_dm + psi_lg - phi_g))
+            const double www = sinc_pi(g.wind[0][l] * kTi * gx + g.wind[1][l] * kTi * gy);  // :442
+            double sr = 0.0, si = 0.0;
+            for (int q = 0; q < n; ++q) {
+                const double pf = gx * g.poslgs[geom][0][q] + gy * g.poslgs[geom][1][q];
+                const double phi = 2.0 * kPi * pf * 1.0 * kArcminH;                 // :279-281
+                const double psi = 2.0 * kPi * pf * g.h[l] * kArcminH;              // :440-443
+                double s_, c_;
+                sincos(theta_dm + psi - phi, &s_, &c_);
+                sr += c_;
+                si += s_;
+            }
+            pr -= www / n * sr;
+            pi_ -= www / n * si;
+        }
+        T[l] = pr * pr + pi_ * pi_;                                                 // :489
+    }
+    double noise = haveW ? 1.0 / (n * wamp * wamp) : 0.0;                           // :515
+    if (pix == 0) { T[0] = 0.0; T[1] = 0.0; noise = 0.0; }                          // :490, :516
+    double* o = tab + ((size_t)(geom * g.ndir + d) * 3) * (NAO * NAO) + j * NAO + i;  // transpose :613
+    o[0] = T[0];
+    o[NAO * NAO] = T[1];
+    o[2 * NAO * NAO] = noise;
+}
+
+// ------------------------------------------------------------------------------------------
+// K_TEL_OTF: telescope OTF (psfrec.py:784-790) as the exact integer autocorrelation of the pupil
+// mask: fft2(|ifft2(tab)|^2) = (tab (*) tab) / N^2 for a real 0/1 array, so
+// dlFTO[u][v] * N^2 = count(u, v) / sum(pup).  Rows of the pupil are bit masks.
+// telT[v][u], v in [0, N/2], u in [0, N) (transposed half plane; the OTF is even and symmetric).
+// ------------------------------------------------------------------------------------------
+template <typename RO>
+__global__ void __launch_bounds__(256) k_tel_otf(int N, const uint64_t* __restrict__ rows,
+                                                 int words, double pupsum, RO* __restrict__ telT) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    if (u >= N) return;
+    const int H = N / 2;
+    const int su = u < H ? u : u - N;
+    const int wpad = 2 * words + 1;
+    const int ws = v >> 6, bs = v & 63;
+    long count = 0;
+    const int p0 = su < 0 ? -su : 0, p1 = su < 0 ? H : H - su;
+    for (int p = p0; p < p1; ++p) {
+        const uint64_t* A = rows + (size_t)p * wpad;
+        const uint64_t* B = rows + (size_t)(p + su) * wpad;
+        for (int w = 0; w < words; ++w) {
+            uint64_t sh = B[w + ws] >> bs;
+            if (bs) sh |= B[w + ws + 1] << (64 - bs);
+            count += __popcll(A[w] & sh);
+        }
+    }
+    telT[(size_t)v * N + u] = (RO)((double)count / pupsum);
+}
+
+// ------------------------------------------------------------------------------------------
+// K_PSD_ROWFFT: residual phase PSD (simul_psd_wfm psfrec.py:36-151: psd_fit :616-626 outside /
+// max(fit, AO) inside the 80x80 corrected zone :148-149) generated on the fly in FFT-native
+// layout, and its forward FFT along the row.
+//
+// Only N/2 + 40 of the N rows are distinct: outside the corrected zone the PSD depends on the row
+// only through (su + 1/2)^2 (half-pixel grid of psfrec.py:618), so rows su and -1-su are equal.
+// The distinct rows are su in [-40, N/2), stored compactly and transposed as
+// Ct[td][y][su + 40], y in [0, N/2];
+// K_COLFFT_DPHI mirrors them back.  Two real rows share one complex transform
+// (z = row_a + i row_b; C_a = (Z[y] + conj Z[-y])/2, C_b = (Z[y] - conj Z[-y])/2i).
+// ------------------------------------------------------------------------------------------
+template <int N>
+constexpr int psd_rows() { return N / 2 + NAO / 2; }
+
+// x^(-11/6) = cbrt(sqrt(x)) / x^2: ~3x cheaper than the generic fp64 pow, same accuracy class
+__device__ __forceinline__ double pow_m11_6(double x) { return cbrt(sqrt(x)) / (x * x); }
+
+template <int N>
+__device__ __forceinline__ double psd_value(int su, int sv, const TaskPar& p, double cfit,
+                                            const double* __restrict__ tb) {
+    const double fx = sv + 0.5, fy = su + 0.5;
+    const double f2 = (fx * fx + fy * fy) * (1.0 / 256.0);          // L = 16 m, psfrec.py:618
+    double psd = 0.0;
+    if (f2 >= 2.25)                                                 // f >= fc = 1.5, :624
+        psd = cfit * p.r0m53 * pow_m11_6(f2 + p.inv_l0sq);
+    if (su >= -NAO / 2 && su < NAO / 2 && sv >= -NAO / 2 && sv < NAO / 2) {
+        const int ia = su < 0 ? su + NAO : su, ib = sv < 0 ? sv + NAO : sv;
+        const double g2 = (double)(su * su + sv * sv) * (1.0 / 256.0);
+        const double vk = 0.0229 * p.r0m53 * pow_m11_6(g2 + p.inv_l0sq);   // :569-571
+        const int o = ia * NAO + ib;
+        const double ao = vk * (p.cn2_0 * tb[o] + p.cn2_1 * tb[NAO * NAO + o]) +
+                          tb[2 * NAO * NAO + o];
+        psd = fmax(psd, ao);                                        // :149
+    }
+    return psd;
+}
+
+template <int N>
+__global__ void __launch_bounds__(LineCfg<N>::THREADS)
+k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict__ aotab,
+             double cfit, cx<double>* __restrict__ C, const cx<double>* __restrict__ twg) {
+    using L = LineCfg<N>;
+    constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
+    constexpr int EPT = N / TPR, NR = psd_rows<N>();
+    extern __shared__ __align__(16) unsigned char smem[];
+    cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
+    cx<double>* bufA = tw + N;
+    cx<double>* bufB = bufA + SLOTS * NPAD;    // only used when a slot spans two wavefronts
+    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
+    const int pair = blockIdx.x * SLOTS + slot;             // rows 2 pair, 2 pair + 1 (compact)
+    const int td = blockIdx.y;
+    const int task = td / ndir, d = td % ndir;
+    for (int i = threadIdx.x; i < N; i += THREADS) tw[i] = twg[i];
+    const TaskPar p = tp[task];
+    const bool valid = 2 * pair < NR;
+    const int ca = valid ? 2 * pair : 0, cb = ca + 1;       // NR is even
+    const int sua = ca - NAO / 2, sub = cb - NAO / 2;
+    const double* tb = aotab + ((size_t)(p.geom * ndir + d) * 3) * (NAO * NAO);
+    cx<double> x[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int c = t + e * TPR;
+        const int sv = c < N / 2 ? c : c - N;
+        x[e] = {psd_value<N>(sua, sv, p, cfit, tb), psd_value<N>(sub, sv, p, cfit, tb)};
+    }
+    __syncthreads();      // twiddle table
+    const cx<double>* res = fft_forward_regs<double, N, false>(x, bufA + slot * NPAD,
+                                                               bufB + slot * NPAD, tw, t);
+    // Store transposed, Ct[td][y][compact row], so that K_COLFFT_DPHI reads whole columns
+    // contiguously: the workgroup's 2*SLOTS rows of one y form a 32*SLOTS-byte segment; lanes run
+    // over (y, row) with the row fastest, each unpacking its value from the slot buffers.
+    __syncthreads();
+    constexpr int RW = 2 * SLOTS;                       // rows per workgroup
+    const int row0 = blockIdx.x * RW;
+    cx<double>* Ct = C + (size_t)td * (N / 2 + 1) * NR;
+    for (int idx = threadIdx.x; idx < (N / 2 + 1) * RW; idx += THREADS) {
+        const int y = idx / RW, rr = idx - y * RW;
+        if (row0 + rr >= NR) continue;
+        const cx<double>* rs = (L::WSYNC ? bufA : (res == bufA + slot * NPAD ? bufA : bufB)) +
+                               (rr >> 1) * NPAD;
+        const cx<double> z = rs[lds_pad(y)], zm = rs[lds_pad(y == 0 ? 0 : N - y)];
+        cx<double> o;
+        if ((rr & 1) == 0) o = {0.5 * (z.x + zm.x), 0.5 * (z.y - zm.y)};
+        else o = {0.5 * (z.y + zm.y), -0.5 * (z.x - zm.x)};
+        Ct[(size_t)y * NR + row0 + rr] = o;
+    }
+}
+
+// K_DC_SUM: S00[td] = Re sum_r C[td][r][0] = sum of the PSD (bg[0,0], psfrec.py:721); compact rows
+// with su >= 40 stand for two rows.
+template <int N>
+__global__ void __launch_bounds__(256) k_dc_sum(const cx<double>* __restrict__ C,
+                                                double* __restrict__ s00) {
+    constexpr int NR = psd_rows<N>();
+    __shared__ double part[4];
+    const int td = blockIdx.x;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < NR; r += 256)
+        s += (r >= NAO ? 2.0 : 1.0) * C[(size_t)td * (N / 2 + 1) * NR + r].x;
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) s00[td] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// K_COLFFT_DPHI: column FFTs of C and the structure function (psfrec.py:717-722 without the
+// wavelength factor): D0t[td][y][x] = 2 scale (S00 - Re S[x][y]), y in [0, N/2], x in [0, N).
+// ------------------------------------------------------------------------------------------
+template <int N, typename RO>
+__global__ void __launch_bounds__(LineCfg<N>::THREADS)
+k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, double scale2,
+              RO* __restrict__ D0t, const cx<double>* __restrict__ twg) {
+    using L = LineCfg<N>;
+    constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
+    cx<double>* bufA = tw + N;
+    cx<double>* bufB = bufA + SLOTS * NPAD;
+    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
+    const int y0 = blockIdx.x * SLOTS;
+    const int td = blockIdx.y;
+    for (int i = threadIdx.x; i < N; i += THREADS) tw[i] = twg[i];
+    constexpr int NR = psd_rows<N>();
+    const cx<double>* Ct = C + (size_t)td * (N / 2 + 1) * NR;
+    // column y0+slot: NR contiguous compact rows; rows su >= 40 also stand for row -1-su
+    {
+        const int y = y0 + slot;
+        const cx<double>* col = Ct + (size_t)(y <= N / 2 ? y : 0) * NR;
+        cx<double>* dst = bufA + slot * NPAD;
+        for (int ci = t; ci < NR; ci += TPR) {
+            const cx<double> v = y <= N / 2 ? col[ci] : cx<double>{0.0, 0.0};
+            const int su = ci - NAO / 2;
+            dst[lds_pad(su < 0 ? su + N : su)] = v;
+            if (su >= NAO / 2) dst[lds_pad(N - 1 - su)] = v;
+        }
+    }
+    __syncthreads();
+    const cx<double>* res =
+        fft_forward<double, N, false>(bufA + slot * NPAD, bufB + slot * NPAD, tw, t);
+    const int y = y0 + slot;
+    if (y <= N / 2) {
+        const double dc = s00[td];
+        RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N;
+        for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[lds_pad(x)].x));
+    }
+}
+
+}  // namespace
+
+void launch_ao_tables(hipStream_t s, const AoGeom& g, const uint8_t* d_mask_rec,
+                      const uint8_t* d_mask_res, double* d_tab) {
+    dim3 grid((NAO * NAO + 255) / 256, g.ndir, 2);
+    hipLaunchKernelGGL(k_ao_tables, grid, dim3(256), 0, s, g, d_mask_rec, d_mask_res, d_tab);
+}
+
+void launch_tel_otf(hipStream_t s, int N, const uint64_t* d_rows, int words, double pupsum,
+                    void* d_tel, bool f64out) {
+    dim3 grid((N + 255) / 256, N / 2 + 1);
+    if (f64out)
+        hipLaunchKernelGGL(k_tel_otf<double>, grid, dim3(256), 0, s, N, d_rows, words, pupsum,
+                           (double*)d_tel);
+    else
+        hipLaunchKernelGGL(k_tel_otf<float>, grid, dim3(256), 0, s, N, d_rows, words, pupsum,
+                           (float*)d_tel);
+}
+
+void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp,
+                       const double* d_aotab, double cfit, void* d_C, const void* d_tw64) {
+    DISPATCH_N(N, {
+        constexpr size_t sm = fft_smem<double, NN>(true, fft_nbuf<NN>());
+        allow_smem(k_psd_rowfft<NN>, sm);
+        constexpr int NPAIR = psd_rows<NN>() / 2, SL = LineCfg<NN>::SLOTS;
+        dim3 grid((NPAIR + SL - 1) / SL, ntd);
+        hipLaunchKernelGGL(k_psd_rowfft<NN>, grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir, d_tp,
+                           d_aotab, cfit, (cx<double>*)d_C, (const cx<double>*)d_tw64);
+    })
+}
+
+void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00) {
+    DISPATCH_N(N, {
+        hipLaunchKernelGGL(k_dc_sum<NN>, dim3(ntd), dim3(256), 0, s, (const cx<double>*)d_C,
+                           d_s00);
+    })
+}
+
+void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,
+                        double scale2, void* d_D0t, bool f64out, const void* d_tw64) {
+    DISPATCH_N(N, {
+        constexpr int SL = LineCfg<NN>::SLOTS;
+        constexpr size_t sm = fft_smem<double, NN>(true, fft_nbuf<NN>());
+        dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntd);
+        if (f64out) {
+            allow_smem(k_colfft_dphi<NN, double>, sm);
+            hipLaunchKernelGGL((k_colfft_dphi<NN, double>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
+                               (const cx<double>*)d_C, d_s00, scale2, (double*)d_D0t,
+                               (const cx<double>*)d_tw64);
+        } else {
+            allow_smem(k_colfft_dphi<NN, float>, sm);
+            hipLaunchKernelGGL((k_colfft_dphi<NN, float>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
+                               (const cx<double>*)d_C, d_s00, scale2, (float*)d_D0t,
+                               (const cx<double>*)d_tw64);
+        }
+    })
+}
+
+
+}  // namespace mpsfr

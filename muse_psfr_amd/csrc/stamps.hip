@@ -1,306 +1,13 @@
 // HIP kernels of the muse-psfr PSF-reconstruction hot path, written for gfx950 (MI355X, wave64).
 // Reference citations are to /root/reference/muse_psfr/psfrec.py.  See DESIGN.md for the data
 // layout and the derivation of the restructured algorithm.
-#include "kernels.h"
-
-#include "fft_lds.h"
+//
+// Stamp stage: Moffat kernels, the two convolutions (direct / 64-point FFT), Moffat fit, stamp sum.
+#include "device_common.h"
 
 namespace mpsfr {
 
 namespace {
-
-constexpr double kPi = 3.14159265358979323846;
-constexpr double kArcminH = 60.0 / 206265.0;   // psfrec.py:279, 440
-constexpr double kTi = 1.0e-3;                 // 1/Fsamp, psfrec.py:584
-constexpr double kDeltaT = 1.0e-3 + 2.5e-3;    // ti.max() + td, psfrec.py:449, 585
-
-__device__ __forceinline__ double sinc_pi(double x) {   // np.sinc
-    return x == 0.0 ? 1.0 : sinpi(x) / (kPi * x);
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// ------------------------------------------------------------------------------------------
-// K_AO_TABLES: row-independent tables of the AO-corrected zone (dsp4muse, psfrec.py:531-613 with
-// calc_mat_rec_glao_finale :218-364 (LSE, one DM layer) and calc_dsp_res_glao_finale :367-528).
-// tab[geom][dir][{T0,T1,noise}][a][b] with (a, b) = (fy index, fx index), i.e. already
-// transposed as psfrec.py:613 does, so that  PSD_AO[a][b] = VK * (cn2_0 T0 + cn2_1 T1) + noise.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ao_tables(AoGeom g, const uint8_t* __restrict__ mrec,
-                                                   const uint8_t* __restrict__ mres,
-                                                   double* __restrict__ tab) {
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= NAO * NAO) return;
-    const int d = blockIdx.y, geom = blockIdx.z;
-    const int i = pix / NAO, j = pix % NAO;              // i <-> fx, j <-> fy (reference layout)
-    const int ki = i < NAO / 2 ? i : i - NAO, kj = j < NAO / 2 ? j : j - NAO;
-    const double fx = ki / 16.0, fy = kj / 16.0;         // fftfreq(80, 0.2), psfrec.py:548
-    const double f = sqrt(fx * fx + fy * fy);
-    // psfrec.py:552-554 + :241-242: arg = arctan(fy/fx) folds the grid onto fx >= 0
-    const double gx = fabs(fx), gy = ki < 0 ? -fy : fy;
-    bool mr, ms;
-    if (mrec != nullptr) {
-        mr = mrec[pix] != 0;
-        ms = mres[pix] != 0;
-    } else {   // exact rule on the integer grid: fc = 1.5 = 24/16 (psfrec.py:254-257, 432-435)
-        const int ai = ki < 0 ? -ki : ki, aj = kj < 0 ? -kj : kj;
-        mr = ai >= 24 || aj >= 24;
-        ms = ai > 24 || aj > 24;
-    }
-    const double pitch = 8.0 / 24.0;
-    const double wamp = 2.0 * kPi * f * sinc_pi(pitch * gx) * sinc_pi(pitch * gy);  // |wfs|, :252
-    const int n = g.nlgs[geom];
-    const bool haveW = !mr && wamp != 0.0 && pix != 0;     // psfrec.py:339, 351-352
-    const double b0 = g.dir[0][d], b1 = g.dir[1][d];
-    const double bf = b0 * gx + b1 * gy;
-    const double theta_dm = 2.0 * kPi * 1.0 * kArcminH * bf;                       // :464
-    double T[2];
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-        const double ph = 2.0 * kPi * (g.h[l] * kArcminH * bf -
-                                       (g.wind[0][l] * kDeltaT * gx + g.wind[1][l] * kDeltaT * gy));
-        double pr, pi_;
-        sincos(ph, &pi_, &pr);                                                      // :454-457
-        if (haveW && !ms) {
-            // sum_g (PbetaDM W_g) Mv[l,g] = (www/n) sum_g exp(i (theta_dm + psi_lg - phi_g))
-            const double www = sinc_pi(g.wind[0][l] * kTi * gx + g.wind[1][l] * kTi * gy);  // :442
-            double sr = 0.0, si = 0.0;
-            for (int q = 0; q < n; ++q) {
-                const double pf = gx * g.poslgs[geom][0][q] + gy * g.poslgs[geom][1][q];
-                const double phi = 2.0 * kPi * pf * 1.0 * kArcminH;                 // :279-281
-                const double psi = 2.0 * kPi * pf * g.h[l] * kArcminH;              // :440-443
-                double s_, c_;
-                sincos(theta_dm + psi - phi, &s_, &c_);
-                sr += c_;
-                si += s_;
-            }
-            pr -= www / n * sr;
-            pi_ -= www / n * si;
-        }
-        T[l] = pr * pr + pi_ * pi_;                                                 // :489
-    }
-    double noise = haveW ? 1.0 / (n * wamp * wamp) : 0.0;                           // :515
-    if (pix == 0) { T[0] = 0.0; T[1] = 0.0; noise = 0.0; }                          // :490, :516
-    double* o = tab + ((size_t)(geom * g.ndir + d) * 3) * (NAO * NAO) + j * NAO + i;  // transpose :613
-    o[0] = T[0];
-    o[NAO * NAO] = T[1];
-    o[2 * NAO * NAO] = noise;
-}
-
-// ------------------------------------------------------------------------------------------
-// K_TEL_OTF: telescope OTF (psfrec.py:784-790) as the exact integer autocorrelation of the pupil
-// mask: fft2(|ifft2(tab)|^2) = (tab (*) tab) / N^2 for a real 0/1 array, so
-// dlFTO[u][v] * N^2 = count(u, v) / sum(pup).  Rows of the pupil are bit masks.
-// telT[v][u], v in [0, N/2], u in [0, N) (transposed half plane; the OTF is even and symmetric).
-// ------------------------------------------------------------------------------------------
-template <typename RO>
-__global__ void __launch_bounds__(256) k_tel_otf(int N, const uint64_t* __restrict__ rows,
-                                                 int words, double pupsum, RO* __restrict__ telT) {
-    const int u = blockIdx.x * 256 + threadIdx.x;
-    const int v = blockIdx.y;
-    if (u >= N) return;
-    const int H = N / 2;
-    const int su = u < H ? u : u - N;
-    const int wpad = 2 * words + 1;
-    const int ws = v >> 6, bs = v & 63;
-    long count = 0;
-    const int p0 = su < 0 ? -su : 0, p1 = su < 0 ? H : H - su;
-    for (int p = p0; p < p1; ++p) {
-        const uint64_t* A = rows + (size_t)p * wpad;
-        const uint64_t* B = rows + (size_t)(p + su) * wpad;
-        for (int w = 0; w < words; ++w) {
-            uint64_t sh = B[w + ws] >> bs;
-            if (bs) sh |= B[w + ws + 1] << (64 - bs);
-            count += __popcll(A[w] & sh);
-        }
-    }
-    telT[(size_t)v * N + u] = (RO)((double)count / pupsum);
-}
-
-// ------------------------------------------------------------------------------------------
-// K_PSD_ROWFFT: residual phase PSD (simul_psd_wfm psfrec.py:36-151: psd_fit :616-626 outside /
-// max(fit, AO) inside the 80x80 corrected zone :148-149) generated on the fly in FFT-native
-// layout, and its forward FFT along the row.
-//
-// Only N/2 + 40 of the N rows are distinct: outside the corrected zone the PSD depends on the row
-// only through (su + 1/2)^2 (half-pixel grid of psfrec.py:618), so rows su and -1-su are equal.
-// The distinct rows are su in [-40, N/2), stored compactly and transposed as
-// Ct[td][y][su + 40], y in [0, N/2];
-// K_COLFFT_DPHI mirrors them back.  Two real rows share one complex transform
-// (z = row_a + i row_b; C_a = (Z[y] + conj Z[-y])/2, C_b = (Z[y] - conj Z[-y])/2i).
-// ------------------------------------------------------------------------------------------
-template <int N>
-constexpr int psd_rows() { return N / 2 + NAO / 2; }
-
-// x^(-11/6) = cbrt(sqrt(x)) / x^2: ~3x cheaper than the generic fp64 pow, same accuracy class
-__device__ __forceinline__ double pow_m11_6(double x) { return cbrt(sqrt(x)) / (x * x); }
-
-template <int N>
-__device__ __forceinline__ double psd_value(int su, int sv, const TaskPar& p, double cfit,
-                                            const double* __restrict__ tb) {
-    const double fx = sv + 0.5, fy = su + 0.5;
-    const double f2 = (fx * fx + fy * fy) * (1.0 / 256.0);          // L = 16 m, psfrec.py:618
-    double psd = 0.0;
-    if (f2 >= 2.25)                                                 // f >= fc = 1.5, :624
-        psd = cfit * p.r0m53 * pow_m11_6(f2 + p.inv_l0sq);
-    if (su >= -NAO / 2 && su < NAO / 2 && sv >= -NAO / 2 && sv < NAO / 2) {
-        const int ia = su < 0 ? su + NAO : su, ib = sv < 0 ? sv + NAO : sv;
-        const double g2 = (double)(su * su + sv * sv) * (1.0 / 256.0);
-        const double vk = 0.0229 * p.r0m53 * pow_m11_6(g2 + p.inv_l0sq);   // :569-571
-        const int o = ia * NAO + ib;
-        const double ao = vk * (p.cn2_0 * tb[o] + p.cn2_1 * tb[NAO * NAO + o]) +
-                          tb[2 * NAO * NAO + o];
-        psd = fmax(psd, ao);                                        // :149
-    }
-    return psd;
-}
-
-template <int N>
-__global__ void __launch_bounds__(LineCfg<N>::THREADS)
-k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict__ aotab,
-             double cfit, cx<double>* __restrict__ C, const cx<double>* __restrict__ twg) {
-    using L = LineCfg<N>;
-    constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
-    constexpr int EPT = N / TPR, NR = psd_rows<N>();
-    extern __shared__ __align__(16) unsigned char smem[];
-    cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
-    cx<double>* bufA = tw + N;
-    cx<double>* bufB = bufA + SLOTS * NPAD;    // only used when a slot spans two wavefronts
-    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
-    const int pair = blockIdx.x * SLOTS + slot;             // rows 2 pair, 2 pair + 1 (compact)
-    const int td = blockIdx.y;
-    const int task = td / ndir, d = td % ndir;
-    for (int i = threadIdx.x; i < N; i += THREADS) tw[i] = twg[i];
-    const TaskPar p = tp[task];
-    const bool valid = 2 * pair < NR;
-    const int ca = valid ? 2 * pair : 0, cb = ca + 1;       // NR is even
-    const int sua = ca - NAO / 2, sub = cb - NAO / 2;
-    const double* tb = aotab + ((size_t)(p.geom * ndir + d) * 3) * (NAO * NAO);
-    cx<double> x[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int c = t + e * TPR;
-        const int sv = c < N / 2 ? c : c - N;
-        x[e] = {psd_value<N>(sua, sv, p, cfit, tb), psd_value<N>(sub, sv, p, cfit, tb)};
-    }
-    __syncthreads();      // twiddle table
-    const cx<double>* res = fft_forward_regs<double, N, false>(x, bufA + slot * NPAD,
-                                                               bufB + slot * NPAD, tw, t);
-    // Store transposed, Ct[td][y][compact row], so that K_COLFFT_DPHI reads whole columns
-    // contiguously: the workgroup's 2*SLOTS rows of one y form a 32*SLOTS-byte segment; lanes run
-    // over (y, row) with the row fastest, each unpacking its value from the slot buffers.
-    __syncthreads();
-    constexpr int RW = 2 * SLOTS;                       // rows per workgroup
-    const int row0 = blockIdx.x * RW;
-    cx<double>* Ct = C + (size_t)td * (N / 2 + 1) * NR;
-    for (int idx = threadIdx.x; idx < (N / 2 + 1) * RW; idx += THREADS) {
-        const int y = idx / RW, rr = idx - y * RW;
-        if (row0 + rr >= NR) continue;
-        const cx<double>* rs = (L::WSYNC ? bufA : (res == bufA + slot * NPAD ? bufA : bufB)) +
-                               (rr >> 1) * NPAD;
-        const cx<double> z = rs[lds_pad(y)], zm = rs[lds_pad(y == 0 ? 0 : N - y)];
-        cx<double> o;
-        if ((rr & 1) == 0) o = {0.5 * (z.x + zm.x), 0.5 * (z.y - zm.y)};
-        else o = {0.5 * (z.y + zm.y), -0.5 * (z.x - zm.x)};
-        Ct[(size_t)y * NR + row0 + rr] = o;
-    }
-}
-
-// K_DC_SUM: S00[td] = Re sum_r C[td][r][0] = sum of the PSD (bg[0,0], psfrec.py:721); compact rows
-// with su >= 40 stand for two rows.
-template <int N>
-__global__ void __launch_bounds__(256) k_dc_sum(const cx<double>* __restrict__ C,
-                                                double* __restrict__ s00) {
-    constexpr int NR = psd_rows<N>();
-    __shared__ double part[4];
-    const int td = blockIdx.x;
-    double s = 0.0;
-    for (int r = threadIdx.x; r < NR; r += 256)
-        s += (r >= NAO ? 2.0 : 1.0) * C[(size_t)td * (N / 2 + 1) * NR + r].x;
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) s00[td] = (part[0] + part[1]) + (part[2] + part[3]);
-}
-
-// ------------------------------------------------------------------------------------------
-// K_COLFFT_DPHI: column FFTs of C and the structure function (psfrec.py:717-722 without the
-// wavelength factor): D0t[td][y][x] = 2 scale (S00 - Re S[x][y]), y in [0, N/2], x in [0, N).
-// ------------------------------------------------------------------------------------------
-template <int N, typename RO>
-__global__ void __launch_bounds__(LineCfg<N>::THREADS)
-k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, double scale2,
-              RO* __restrict__ D0t, const cx<double>* __restrict__ twg) {
-    using L = LineCfg<N>;
-    constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
-    extern __shared__ __align__(16) unsigned char smem[];
-    cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
-    cx<double>* bufA = tw + N;
-    cx<double>* bufB = bufA + SLOTS * NPAD;
-    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
-    const int y0 = blockIdx.x * SLOTS;
-    const int td = blockIdx.y;
-    for (int i = threadIdx.x; i < N; i += THREADS) tw[i] = twg[i];
-    constexpr int NR = psd_rows<N>();
-    const cx<double>* Ct = C + (size_t)td * (N / 2 + 1) * NR;
-    // column y0+slot: NR contiguous compact rows; rows su >= 40 also stand for row -1-su
-    {
-        const int y = y0 + slot;
-        const cx<double>* col = Ct + (size_t)(y <= N / 2 ? y : 0) * NR;
-        cx<double>* dst = bufA + slot * NPAD;
-        for (int ci = t; ci < NR; ci += TPR) {
-            const cx<double> v = y <= N / 2 ? col[ci] : cx<double>{0.0, 0.0};
-            const int su = ci - NAO / 2;
-            dst[lds_pad(su < 0 ? su + N : su)] = v;
-            if (su >= NAO / 2) dst[lds_pad(N - 1 - su)] = v;
-        }
-    }
-    __syncthreads();
-    const cx<double>* res =
-        fft_forward<double, N, false>(bufA + slot * NPAD, bufB + slot * NPAD, tw, t);
-    const int y = y0 + slot;
-    if (y <= N / 2) {
-        const double dc = s00[td];
-        RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N;
-        for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[lds_pad(x)].x));
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K_GTABLE: per-wavelength sampling tables.  Sample i of the 40-pixel stamp sits at i*npixc/40
-// in the centred crop (psfrec.py:672-683); its left neighbour is native index
-// p_i = (floor(i npixc/40) - npixc/2) mod N with weight 1-a_i, a_i = frac.
-// G[l][v][j] = w_v ((1-a_j) W^-(v p_j) + a_j W^-(v (p_j+1))), W = exp(-2 pi i/N), w_v = 1 for
-// v in {0, N/2} else 2: bilinear interpolation folded into the second (column) pass.
-// ------------------------------------------------------------------------------------------
-template <typename R>
-__global__ void __launch_bounds__(256)
-k_gtable(int N, const LamPar* __restrict__ lp, const cx<double>* __restrict__ twg,
-         int* __restrict__ samp_p, R* __restrict__ samp_a, cx<R>* __restrict__ G) {
-    const int l = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int npixc = lp[l].npixc;
-    if (idx < NS) {
-        const int q = idx * npixc;
-        samp_p[l * NS + idx] = ((q / NS - npixc / 2) % N + N) % N;
-        samp_a[l * NS + idx] = (R)((double)(q % NS) / NS);
-    }
-    if (idx >= (N / 2 + 1) * NS) return;
-    const int v = idx / NS, j = idx % NS;
-    const int q = j * npixc;
-    const int p = ((q / NS - npixc / 2) % N + N) % N;
-    const double a = (double)(q % NS) / NS;
-    const cx<double> w0 = twg[(int)(((long)v * p) % N)];
-    const cx<double> w1 = twg[(int)(((long)v * (p + 1)) % N)];
-    const double wv = (v == 0 || v == N / 2) ? 1.0 : 2.0;
-    // conj(W^(v p)) = exp(+2 pi i v p / N)
-    G[((size_t)l * (N / 2 + 1) + v) * NS + j] = {(R)(wv * ((1.0 - a) * w0.x + a * w1.x)),
-                                                 (R)(-wv * ((1.0 - a) * w0.y + a * w1.y))};
-}
 
 // ------------------------------------------------------------------------------------------
 // K_MOFFAT_KERNELS: astropy Moffat2DKernel(gamma, alpha, 41, 41) (psfrec.py:916, 927):
@@ -337,247 +44,6 @@ k_moffat_kernels(const double* __restrict__ gam, const double* __restrict__ alp,
     for (int m = 0; m < (KS * KS + 255) / 256; ++m) {
         const int e = threadIdx.x + m * 256;
         if (e < KS * KS) out[(size_t)k * KS * KS + e] = (R)(vals[m] * inv);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K_OTF_ROWFFT (dominant kernel): for one task and one line v of the transposed half plane, for
-// every wavelength: OTF line = tel * sum_dir exp(c_l * D0)  (psfrec.py:793-797; the mean over
-// directions of psfrec.py:674 commutes with the FFT), forward FFT along the line, and the
-// bilinear-weighted extraction of the NS sampled positions -> Tq[task][l][v][i].
-// ------------------------------------------------------------------------------------------
-// exp(c * d) for the OTF.  FAST (float only): the caller pre-multiplies c by log2(e) and the
-// hardware exp2 is used directly: one multiply + v_exp_f32 per value.
-template <typename R, bool FAST>
-__device__ __forceinline__ R exp_scale(R c) {
-    if constexpr (FAST && sizeof(R) == 4) return c * (R)1.44269504088896340736;
-    else return c;
-}
-template <typename R, bool FAST>
-__device__ __forceinline__ R exp_sel(R x) {
-    if constexpr (sizeof(R) == 8) {
-        return exp(x);
-    } else if constexpr (FAST) {
-        return __builtin_amdgcn_exp2f(x);
-    } else {
-        return expf(x);
-    }
-}
-
-template <typename R, int N, int ND, bool FASTEXP>
-__global__ void __launch_bounds__(LineCfg<N>::THREADS)
-k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ telT,
-             const LamPar* __restrict__ lp, const int* __restrict__ samp_p,
-             const R* __restrict__ samp_a, cx<R>* __restrict__ Tq,
-             const cx<double>* __restrict__ twg) {
-    using L = LineCfg<N>;
-    constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
-    constexpr int EPT = N / TPR;
-    constexpr bool REGTW = use_reg_twiddles<N>(), WS = L::WSYNC;
-    extern __shared__ __align__(16) unsigned char smem[];
-    cx<R>* twl = reinterpret_cast<cx<R>*>(smem);          // only used when !REGTW
-    cx<R>* bufA = twl + (REGTW ? 0 : N);
-    cx<R>* bufB = bufA + SLOTS * NPAD;
-    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
-    const int v = blockIdx.x * SLOTS + slot;
-    const int task = blockIdx.y;
-    const bool valid = v <= N / 2;
-    const int vv = valid ? v : N / 2;
-    TwRegs<R, N> twr;
-    const cx<R>* twp;
-    if constexpr (REGTW) {
-        twr.init(twg, t);
-        twp = twr.w;
-    } else {
-        for (int i = threadIdx.x; i < N; i += THREADS) twl[i] = {(R)twg[i].x, (R)twg[i].y};
-        twp = twl;
-        __syncthreads();
-    }
-    cx<R>* a = bufA + slot * NPAD;
-    cx<R>* b = bufB + slot * NPAD;     // only used when a slot spans two wavefronts
-    R tel[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) tel[e] = telT[(size_t)vv * N + t + e * TPR];
-    const R* dline = D0t + ((size_t)task * ndir * (N / 2 + 1) + vv) * N;
-    const size_t dstride = (size_t)(N / 2 + 1) * N;
-    R dreg[ND == 1 ? EPT : 1];
-    if constexpr (ND == 1) {
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) dreg[e] = dline[t + e * TPR];
-    }
-    // two wavelengths per complex transform: z = otf(la) + i otf(lb), both real lines
-    for (int l = 0; l < nl; l += 2) {
-        const bool two = l + 1 < nl;
-        const R ca = exp_scale<R, FASTEXP>((R)lp[l].c);
-        const R cb = exp_scale<R, FASTEXP>((R)lp[two ? l + 1 : l].c);
-        cx<R> x[EPT];
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            R ra = (R)0, rb = (R)0;
-            if constexpr (ND == 1) {
-                ra = exp_sel<R, FASTEXP>(ca * dreg[e]);
-                rb = exp_sel<R, FASTEXP>(cb * dreg[e]);
-            } else {
-                for (int d = 0; d < ndir; ++d) {
-                    const R dv = dline[d * dstride + t + e * TPR];
-                    ra += exp_sel<R, FASTEXP>(ca * dv);
-                    rb += exp_sel<R, FASTEXP>(cb * dv);
-                }
-            }
-            x[e] = {tel[e] * ra, two ? tel[e] * rb : (R)0};
-        }
-        const cx<R>* res = fft_forward_regs<R, N, REGTW>(x, a, b, twp, t);
-        if (valid) {
-            // F_a[p] = (Z[p] + conj Z[-p]) / 2,  F_b[p] = (Z[p] - conj Z[-p]) / 2i.
-            // Only samples i = 0..20: the OTF is real, so A[v][-p] = conj A[v][p], and the sample
-            // positions are symmetric about the centre (p_(40-i) + 1 = -p_i, weights swapped),
-            // hence Tq[v][40-i] = conj Tq[v][i].
-            for (int idx = t; idx < 2 * NSH; idx += TPR) {
-                const int which = idx / NSH, i = idx - which * NSH;
-                if (which == 1 && !two) continue;
-                const int ll = l + which;
-                const int p = samp_p[ll * NS + i];
-                const R w = samp_a[ll * NS + i];
-                const int q = p + 1 == N ? 0 : p + 1;
-                const int mp = p == 0 ? 0 : N - p, mq = q == 0 ? 0 : N - q;
-                const cx<R> zp = res[lds_pad(p)], zmp = res[lds_pad(mp)];
-                const cx<R> zq = res[lds_pad(q)], zmq = res[lds_pad(mq)];
-                cx<R> f0, f1;
-                const R h = (R)0.5;
-                if (which == 0) {
-                    f0 = {h * (zp.x + zmp.x), h * (zp.y - zmp.y)};
-                    f1 = {h * (zq.x + zmq.x), h * (zq.y - zmq.y)};
-                } else {
-                    f0 = {h * (zp.y + zmp.y), -h * (zp.x - zmp.x)};
-                    f1 = {h * (zq.y + zmq.y), -h * (zq.x - zmq.x)};
-                }
-                Tq[(((size_t)task * nl + ll) * (N / 2 + 1) + v) * NSH + i] = {
-                    ((R)1 - w) * f0.x + w * f1.x, ((R)1 - w) * f0.y + w * f1.y};
-            }
-        }
-        fft_sync<WS>();     // extraction reads done before the next transform overwrites
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K_COLPASS: second (column) pass restricted to the sampled positions,
-// stamp[i][j] = sum_v Re(G[l][v][j] * conj(Tq[v][i])), then clamp >= 0 (psfrec.py:680) and
-// normalise to sum 1 (:685).  With Tq[v][40-i] = conj Tq[v][i] only i = 0..20 is stored and
-//   P[i][j] = sum_v Gx Tx,  Q[i][j] = sum_v Gy Ty,  stamp[i][j] = P + Q,  stamp[40-i][j] = P - Q,
-// i.e. half the products of the plain form.  One workgroup per stamp; a lane holds a 3x5 tile
-// of (P, Q) pairs (7 x 8 tiles = 56 lanes), the four waves split the v range (32 lines staged
-// in LDS per step, 8 per wave) and the partial tiles are summed through LDS at the end.
-// ------------------------------------------------------------------------------------------
-template <typename R, int N>
-__global__ void __launch_bounds__(256)
-k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
-          double* __restrict__ pre) {
-    constexpr int VW = 8, VB = 4 * VW, TI = 3, TJ = 5, NV = N / 2 + 1;
-    constexpr int NPQ = NSH * NS;                 // 840 (P, Q) pairs
-    static_assert(NSH == 7 * TI && NS == 8 * TJ, "tile map");
-    // one raw buffer: staging {T [VB][NSH], G [VB][NS]} complex during the loop, then the
-    // partial tiles [4][NPQ] complex (P, Q)
-    constexpr size_t STAGE = (size_t)VB * (NSH + NS) * sizeof(cx<R>);
-    constexpr size_t RED = (size_t)4 * NPQ * sizeof(cx<R>);
-    __shared__ __align__(16) unsigned char raw[RED > STAGE ? RED : STAGE];
-    cx<R>(*sT)[NSH] = reinterpret_cast<cx<R>(*)[NSH]>(raw);
-    cx<R>(*sG)[NS] = reinterpret_cast<cx<R>(*)[NS]>(raw + VB * NSH * sizeof(cx<R>));
-    __shared__ double part[4];
-    __shared__ double tot;
-    const int l = blockIdx.x, task = blockIdx.y;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool act = lane < 56;
-    const int i0 = TI * (act ? lane >> 3 : 0), j0 = TJ * (lane & 7);
-    const cx<R>* Tp = Tq + ((size_t)task * nl + l) * NV * NSH;
-    const cx<R>* Gp = G + (size_t)l * NV * NS;
-    R accP[TI][TJ], accQ[TI][TJ];
-#pragma unroll
-    for (int a = 0; a < TI; ++a)
-#pragma unroll
-        for (int b = 0; b < TJ; ++b) { accP[a][b] = (R)0; accQ[a][b] = (R)0; }
-    constexpr int NET = (VB * NSH + 255) / 256, NEG = VB * NS / 256;
-    cx<R> rt[NET], rg[NEG];
-    auto fetch = [&](int v0) {
-#pragma unroll
-        for (int k = 0; k < NET; ++k) {
-            const int e = threadIdx.x + k * 256;
-            rt[k] = (e < VB * NSH && v0 * NSH + e < NV * NSH) ? Tp[(size_t)v0 * NSH + e]
-                                                            : cx<R>{(R)0, (R)0};
-        }
-#pragma unroll
-        for (int k = 0; k < NEG; ++k) {
-            const int e = threadIdx.x + k * 256;
-            rg[k] = v0 * NS + e < NV * NS ? Gp[(size_t)v0 * NS + e] : cx<R>{(R)0, (R)0};
-        }
-    };
-    fetch(0);
-    for (int v0 = 0; v0 < NV; v0 += VB) {
-#pragma unroll
-        for (int k = 0; k < NET; ++k) {
-            const int e = threadIdx.x + k * 256;
-            if (e < VB * NSH) (&sT[0][0])[e] = rt[k];
-        }
-#pragma unroll
-        for (int k = 0; k < NEG; ++k) (&sG[0][0])[threadIdx.x + k * 256] = rg[k];
-        __syncthreads();
-        if (v0 + VB < NV) fetch(v0 + VB);      // prefetch the next block behind the FMAs
-#pragma unroll
-        for (int vb = 0; vb < VW; ++vb) {
-            const int vr = wave * VW + vb;
-            cx<R> t[TI], g[TJ];
-#pragma unroll
-            for (int k = 0; k < TI; ++k) t[k] = sT[vr][i0 + k];
-#pragma unroll
-            for (int k = 0; k < TJ; ++k) g[k] = sG[vr][j0 + k];
-#pragma unroll
-            for (int a = 0; a < TI; ++a)
-#pragma unroll
-                for (int b = 0; b < TJ; ++b) {
-                    accP[a][b] += g[b].x * t[a].x;
-                    accQ[a][b] += g[b].y * t[a].y;
-                }
-        }
-        __syncthreads();
-    }
-    // sum the four partial tiles
-    cx<R>* red = reinterpret_cast<cx<R>*>(raw);
-    if (act) {
-#pragma unroll
-        for (int a = 0; a < TI; ++a)
-#pragma unroll
-            for (int b = 0; b < TJ; ++b)
-                red[wave * NPQ + (i0 + a) * NS + j0 + b] = {accP[a][b], accQ[a][b]};
-    }
-    __syncthreads();
-    constexpr int NO = (NS * NS + 255) / 256;
-    R val[NO];
-    double s = 0.0;
-#pragma unroll
-    for (int m = 0; m < NO; ++m) {
-        const int o = threadIdx.x + m * 256;
-        R x = (R)0;
-        if (o < NS * NS) {
-            const int i = o / NS, j = o - i * NS;
-            const int e = (i < NSH ? i : NS - i) * NS + j;
-            const cx<R> a = red[e], b = red[NPQ + e], c = red[2 * NPQ + e], d = red[3 * NPQ + e];
-            const R P = (a.x + b.x) + (c.x + d.x), Q = (a.y + b.y) + (c.y + d.y);
-            x = i < NSH ? P + Q : P - Q;
-            if (x < (R)0) x = (R)0;
-            s += (double)x;
-        }
-        val[m] = x;
-    }
-    s = wave_sum(s);
-    if (lane == 0) part[wave] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) tot = (part[0] + part[1]) + (part[2] + part[3]);
-    __syncthreads();
-    const double inv = 1.0 / tot;
-    double* out = pre + ((size_t)task * nl + l) * NS * NS;
-#pragma unroll
-    for (int m = 0; m < NO; ++m) {
-        const int o = threadIdx.x + m * 256;
-        if (o < NS * NS) out[o] = (double)val[m] * inv;
     }
 }
 
@@ -1346,98 +812,7 @@ __global__ void __launch_bounds__(256) k_stamp_sum(int ntask, int nl, const doub
     }
 }
 
-template <typename T, int N>
-constexpr size_t fft_smem(bool with_table, int nbuf) {
-    return (size_t)((with_table ? N : 0) + nbuf * LineCfg<N>::SLOTS * LineCfg<N>::NPAD) *
-           sizeof(T) * 2;
-}
-
 }  // namespace
-
-#define DISPATCH_N(N, ...)                                          \
-    switch (N) {                                                    \
-        case 128: { constexpr int NN = 128; __VA_ARGS__; } break;   \
-        case 256: { constexpr int NN = 256; __VA_ARGS__; } break;   \
-        case 512: { constexpr int NN = 512; __VA_ARGS__; } break;   \
-        case 1024: { constexpr int NN = 1024; __VA_ARGS__; } break; \
-        case 1280: { constexpr int NN = 1280; __VA_ARGS__; } break; \
-        default: break;                                             \
-    }
-
-void launch_ao_tables(hipStream_t s, const AoGeom& g, const uint8_t* d_mask_rec,
-                      const uint8_t* d_mask_res, double* d_tab) {
-    dim3 grid((NAO * NAO + 255) / 256, g.ndir, 2);
-    hipLaunchKernelGGL(k_ao_tables, grid, dim3(256), 0, s, g, d_mask_rec, d_mask_res, d_tab);
-}
-
-void launch_tel_otf(hipStream_t s, int N, const uint64_t* d_rows, int words, double pupsum,
-                    void* d_tel, bool f64out) {
-    dim3 grid((N + 255) / 256, N / 2 + 1);
-    if (f64out)
-        hipLaunchKernelGGL(k_tel_otf<double>, grid, dim3(256), 0, s, N, d_rows, words, pupsum,
-                           (double*)d_tel);
-    else
-        hipLaunchKernelGGL(k_tel_otf<float>, grid, dim3(256), 0, s, N, d_rows, words, pupsum,
-                           (float*)d_tel);
-}
-
-template <typename K>
-static void allow_smem(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)bytes);
-}
-
-void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp,
-                       const double* d_aotab, double cfit, void* d_C, const void* d_tw64) {
-    DISPATCH_N(N, {
-        constexpr size_t sm = fft_smem<double, NN>(true, fft_nbuf<NN>());
-        allow_smem(k_psd_rowfft<NN>, sm);
-        constexpr int NPAIR = psd_rows<NN>() / 2, SL = LineCfg<NN>::SLOTS;
-        dim3 grid((NPAIR + SL - 1) / SL, ntd);
-        hipLaunchKernelGGL(k_psd_rowfft<NN>, grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir, d_tp,
-                           d_aotab, cfit, (cx<double>*)d_C, (const cx<double>*)d_tw64);
-    })
-}
-
-void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00) {
-    DISPATCH_N(N, {
-        hipLaunchKernelGGL(k_dc_sum<NN>, dim3(ntd), dim3(256), 0, s, (const cx<double>*)d_C,
-                           d_s00);
-    })
-}
-
-void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,
-                        double scale2, void* d_D0t, bool f64out, const void* d_tw64) {
-    DISPATCH_N(N, {
-        constexpr int SL = LineCfg<NN>::SLOTS;
-        constexpr size_t sm = fft_smem<double, NN>(true, fft_nbuf<NN>());
-        dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntd);
-        if (f64out) {
-            allow_smem(k_colfft_dphi<NN, double>, sm);
-            hipLaunchKernelGGL((k_colfft_dphi<NN, double>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
-                               (const cx<double>*)d_C, d_s00, scale2, (double*)d_D0t,
-                               (const cx<double>*)d_tw64);
-        } else {
-            allow_smem(k_colfft_dphi<NN, float>, sm);
-            hipLaunchKernelGGL((k_colfft_dphi<NN, float>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
-                               (const cx<double>*)d_C, d_s00, scale2, (float*)d_D0t,
-                               (const cx<double>*)d_tw64);
-        }
-    })
-}
-
-void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void* d_tw64,
-                   int* d_samp_p, void* d_samp_a, void* d_G, bool f64) {
-    dim3 grid(((N / 2 + 1) * NS + 255) / 256, nl);
-    if (f64)
-        hipLaunchKernelGGL(k_gtable<double>, grid, dim3(256), 0, s, N, d_lp,
-                           (const cx<double>*)d_tw64, d_samp_p, (double*)d_samp_a,
-                           (cx<double>*)d_G);
-    else
-        hipLaunchKernelGGL(k_gtable<float>, grid, dim3(256), 0, s, N, d_lp,
-                           (const cx<double>*)d_tw64, d_samp_p, (float*)d_samp_a, (cx<float>*)d_G);
-}
 
 void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
                            void* d_out, bool f64) {
@@ -1448,52 +823,6 @@ void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const
     else
         hipLaunchKernelGGL(k_moffat_kernels<float>, dim3(nker), dim3(256), 0, s, d_gamma, d_alpha,
                            (float*)d_out);
-}
-
-template <typename R, int NN, int ND, bool FE>
-static void launch_otf_t(hipStream_t s, int ntask, int ndir, int nl, const void* d_D0t,
-                         const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
-                         const void* d_samp_a, void* d_Tq, const void* d_tw64) {
-    constexpr int SL = LineCfg<NN>::SLOTS;
-    constexpr size_t sm = fft_smem<R, NN>(!use_reg_twiddles<NN>(), fft_nbuf<NN>());
-    allow_smem(k_otf_rowfft<R, NN, ND, FE>, sm);
-    dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntask);
-    hipLaunchKernelGGL((k_otf_rowfft<R, NN, ND, FE>), grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir,
-                       nl, (const R*)d_D0t, (const R*)d_tel, d_lp, d_samp_p, (const R*)d_samp_a,
-                       (cx<R>*)d_Tq, (const cx<double>*)d_tw64);
-}
-
-#define OTF_ARGS s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p, d_samp_a, d_Tq, d_tw64
-void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
-                       const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
-                       const void* d_samp_a, void* d_Tq, const void* d_tw64, bool f64,
-                       bool fast_exp) {
-    DISPATCH_N(N, {
-        if (f64) {
-            if (ndir == 1) launch_otf_t<double, NN, 1, false>(OTF_ARGS);
-            else launch_otf_t<double, NN, 0, false>(OTF_ARGS);
-        } else if (fast_exp) {
-            if (ndir == 1) launch_otf_t<float, NN, 1, true>(OTF_ARGS);
-            else launch_otf_t<float, NN, 0, true>(OTF_ARGS);
-        } else {
-            if (ndir == 1) launch_otf_t<float, NN, 1, false>(OTF_ARGS);
-            else launch_otf_t<float, NN, 0, false>(OTF_ARGS);
-        }
-    })
-}
-#undef OTF_ARGS
-
-void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, const void* d_G,
-                    double* d_pre, bool f64) {
-    dim3 grid(nl, ntask);
-    DISPATCH_N(N, {
-        if (f64)
-            hipLaunchKernelGGL((k_colpass<double, NN>), grid, dim3(256), 0, s, nl,
-                               (const cx<double>*)d_Tq, (const cx<double>*)d_G, d_pre);
-        else
-            hipLaunchKernelGGL((k_colpass<float, NN>), grid, dim3(256), 0, s, nl,
-                               (const cx<float>*)d_Tq, (const cx<float>*)d_G, d_pre);
-    })
 }
 
 void launch_conv(hipStream_t s, int ntask, int nl, const double* d_pre, const void* d_ktt,
@@ -1541,5 +870,6 @@ void launch_stamp_sum(hipStream_t s, int ntask, int nl, const double* d_fin, dou
     hipLaunchKernelGGL(k_stamp_sum, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, ntask, nl,
                        d_fin, d_sum, accumulate);
 }
+
 
 }  // namespace mpsfr
