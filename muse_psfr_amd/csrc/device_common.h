@@ -27,7 +27,7 @@ constexpr double kDeltaT = 1.0e-3 + 2.5e-3;    // ti.max() + td, psfrec.py:449, 
 // dynamic LDS bytes of a line-FFT kernel: optional twiddle table + nbuf buffers per slot
 template <typename T, int N>
 constexpr size_t fft_smem(bool with_table, int nbuf) {
-    return (size_t)((with_table ? N : 0) + nbuf * LineCfg<N>::SLOTS * LineCfg<N>::NPAD) *
+    return (size_t)((with_table ? LineCfg<N>::NPAD : 0) + nbuf * LineCfg<N>::SLOTS * LineCfg<N>::NPAD) *
            sizeof(T) * 2;
 }
 

@@ -2,7 +2,8 @@
 //
 // One length-N line is transformed by TPR cooperating threads ("slot"); a workgroup carries
 // SLOTS independent lines.  Radix plans: 128 = 8.4.4, 256 = 8.8.4, 512 = 8.8.8, 1024 = 8.8.4.4,
-// 1280 = 4.4.4.4.5 (the reference-native grid of psfrec.py:954-955 needs radix 5).
+// 1280 = 20.4.4.4 (the reference-native grid of psfrec.py:954-955 needs a factor 5; with 64 threads
+// per line only radices 2, 4, 5, 10, 20 divide the butterflies evenly, and 20 first saves a pass).
 //
 // gfx950 specifics:
 //  * LDS images are padded (x -> x + x/8): the autosort writes of a pass have a lane stride of
@@ -88,12 +89,48 @@ __device__ __forceinline__ void dft5(cx<R>* v) {
     v[3] = {m2.x - n2.y, m2.y + n2.x};
 }
 
+// 20 = 4 x 5 (Cooley-Tukey, n = 5 n1 + n2, k = k1 + 4 k2): five radix-4 butterflies over n1,
+// the twiddles W20^(n2 k1), four radix-5 butterflies over n2.
+template <typename R>
+__device__ __forceinline__ void dft20(cx<R>* v) {
+    // W20^m = exp(-2 pi i m / 20), m = 0..12
+    constexpr double C20[13] = {1.0, 0.95105651629515357212, 0.80901699437494742410,
+                                0.58778525229247312917, 0.30901699437494742410, 0.0,
+                                -0.30901699437494742410, -0.58778525229247312917,
+                                -0.80901699437494742410, -0.95105651629515357212, -1.0,
+                                -0.95105651629515357212, -0.80901699437494742410};
+    constexpr double S20[13] = {0.0, -0.30901699437494742410, -0.58778525229247312917,
+                                -0.80901699437494742410, -0.95105651629515357212, -1.0,
+                                -0.95105651629515357212, -0.80901699437494742410,
+                                -0.58778525229247312917, -0.30901699437494742410, 0.0,
+                                0.30901699437494742410, 0.58778525229247312917};
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) dft4(v[n2], v[5 + n2], v[10 + n2], v[15 + n2]);
+#pragma unroll
+    for (int k1 = 1; k1 < 4; ++k1)
+#pragma unroll
+        for (int n2 = 1; n2 < 5; ++n2) {
+            const cx<R> w = {(R)C20[n2 * k1], (R)S20[n2 * k1]};
+            v[5 * k1 + n2] = cmul(v[5 * k1 + n2], w);
+        }
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft5(v + 5 * k1);
+    cx<R> o[20];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 5; ++k2) o[k1 + 4 * k2] = v[5 * k1 + k2];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) v[i] = o[i];
+}
+
 template <typename R, int RADIX>
 __device__ __forceinline__ void dftr(cx<R>* v) {
     if constexpr (RADIX == 2) dft2(v[0], v[1]);
     if constexpr (RADIX == 4) dft4(v[0], v[1], v[2], v[3]);
     if constexpr (RADIX == 8) dft8(v);
     if constexpr (RADIX == 5) dft5(v);
+    if constexpr (RADIX == 20) dft20(v);
 }
 
 // ---- plan ---------------------------------------------------------------------------------
@@ -129,8 +166,8 @@ struct Plan<1024> {
 };
 template <>
 struct Plan<1280> {
-    static constexpr int NP = 5, TPR = 64, SLOTS = 2;
-    static constexpr int radix[5] = {4, 4, 4, 4, 5};
+    static constexpr int NP = 4, TPR = 64, SLOTS = 2;
+    static constexpr int radix[5] = {4, 4, 4, 20, 1};
 };
 
 template <int N>
@@ -197,8 +234,9 @@ struct TwRegs {
 };
 
 // One Stockham autosort pass p of the plan (padded LDS images).
-//  REGTW  : `tw` is the thread's TwRegs array; otherwise the table tw[m] = exp(-2 pi i m / N)
-//           (in LDS).
+//  REGTW  : `tw` is the thread's TwRegs array; otherwise the LDS table
+//           tw[lds_pad(m)] = exp(-2 pi i m / N) (padded like the lines: the lanes of a pass read
+//           it with strides q * TS).
 //  FROMREG: pass 0 only -- the inputs are the thread's own line elements x[e] = line[t + e*TPR]
 //           (a thread's first-pass butterflies read exactly the elements it owns), so the line
 //           never has to be staged through LDS.
@@ -242,7 +280,8 @@ __device__ __forceinline__ void fft_pass(const cx<R>* in, cx<R>* out, const cx<R
             } else {
                 constexpr int TS = N / (NS_ * RADIX);
 #pragma unroll
-                for (int q = 1; q < RADIX; ++q) v[b][q] = cmul(v[b][q], tw[q * k * TS]);
+                for (int q = 1; q < RADIX; ++q)
+                    v[b][q] = cmul(v[b][q], tw[lds_pad(q * k * TS)]);
             }
         }
         dftr<R, RADIX>(v[b]);

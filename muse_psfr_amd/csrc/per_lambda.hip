@@ -77,7 +77,7 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
     constexpr bool REGTW = use_reg_twiddles<N>(), WS = L::WSYNC;
     extern __shared__ __align__(16) unsigned char smem[];
     cx<R>* twl = reinterpret_cast<cx<R>*>(smem);          // only used when !REGTW
-    cx<R>* bufA = twl + (REGTW ? 0 : N);
+    cx<R>* bufA = twl + (REGTW ? 0 : NPAD);
     cx<R>* bufB = bufA + SLOTS * NPAD;
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
     const int v = blockIdx.x * SLOTS + slot;
@@ -90,7 +90,8 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
         twr.init(twg, t);
         twp = twr.w;
     } else {
-        for (int i = threadIdx.x; i < N; i += THREADS) twl[i] = {(R)twg[i].x, (R)twg[i].y};
+        for (int i = threadIdx.x; i < N; i += THREADS)
+            twl[lds_pad(i)] = {(R)twg[i].x, (R)twg[i].y};
         twp = twl;
         __syncthreads();
     }

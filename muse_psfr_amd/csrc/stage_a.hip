@@ -153,13 +153,13 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
     constexpr int EPT = N / TPR, NR = psd_rows<N>();
     extern __shared__ __align__(16) unsigned char smem[];
     cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
-    cx<double>* bufA = tw + N;
+    cx<double>* bufA = tw + NPAD;
     cx<double>* bufB = bufA + SLOTS * NPAD;    // only used when a slot spans two wavefronts
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
     const int pair = blockIdx.x * SLOTS + slot;             // rows 2 pair, 2 pair + 1 (compact)
     const int td = blockIdx.y;
     const int task = td / ndir, d = td % ndir;
-    for (int i = threadIdx.x; i < N; i += THREADS) tw[i] = twg[i];
+    for (int i = threadIdx.x; i < N; i += THREADS) tw[lds_pad(i)] = twg[i];
     const TaskPar p = tp[task];
     const bool valid = 2 * pair < NR;
     const int ca = valid ? 2 * pair : 0, cb = ca + 1;       // NR is even
@@ -224,12 +224,12 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
     constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
     extern __shared__ __align__(16) unsigned char smem[];
     cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
-    cx<double>* bufA = tw + N;
+    cx<double>* bufA = tw + NPAD;
     cx<double>* bufB = bufA + SLOTS * NPAD;
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
     const int y0 = blockIdx.x * SLOTS;
     const int td = blockIdx.y;
-    for (int i = threadIdx.x; i < N; i += THREADS) tw[i] = twg[i];
+    for (int i = threadIdx.x; i < N; i += THREADS) tw[lds_pad(i)] = twg[i];
     constexpr int NR = psd_rows<N>();
     const cx<double>* Ct = C + (size_t)td * (N / 2 + 1) * NR;
     // column y0+slot: NR contiguous compact rows; rows su >= 40 also stand for row -1-su
