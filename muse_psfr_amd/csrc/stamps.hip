@@ -415,6 +415,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// A value every lane of the wave already agrees on, moved to scalar registers: the LM state of a
+// stamp is wave-uniform, and keeping it out of the VGPR file is what buys the third wave per SIMD.
+__device__ __forceinline__ float wave_uniform(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ double wave_uniform(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+
 template <typename RE>
 __device__ __forceinline__ RE fit_log(RE x);
 template <>
@@ -493,11 +505,11 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int first, con
             for (int y = x; y < 5; ++y) a[k++] += J[x] * J[y];
         }
     }
-    ne.chi2 = wave_sum(chi2);
+    ne.chi2 = wave_uniform(wave_sum(chi2));
 #pragma unroll
-    for (int k = 0; k < 15; ++k) ne.a[k] = wave_sum(a[k]);
+    for (int k = 0; k < 15; ++k) ne.a[k] = wave_uniform(wave_sum(a[k]));
 #pragma unroll
-    for (int k = 0; k < 5; ++k) ne.g[k] = wave_sum(g[k]);
+    for (int k = 0; k < 5; ++k) ne.g[k] = wave_uniform(wave_sum(g[k]));
     if constexpr (WPS > 1) {
         static_assert(WPS == 4, "cross-wave reduction written for 4 waves");
         const int wave = threadIdx.x >> 6;
@@ -620,9 +632,14 @@ __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][
     return true;
 }
 
+#ifndef MPSFR_FIT_WAVES
+#define MPSFR_FIT_WAVES 3
+#endif
+// amdgpu_waves_per_eu: the serial LM iterations are latency-bound, so occupancy matters more than
+// the scheduler's appetite for registers (208 VGPRs -> 2 waves/SIMD without the hint).
 template <typename RE, int WPS>
-__global__ void __launch_bounds__(256) k_fit(int nstamp, const double* __restrict__ stamps,
-                                             double* __restrict__ fit) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MPSFR_FIT_WAVES)))
+k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
     constexpr int TPS = 64 * WPS;                         // threads per stamp
     constexpr int NPX = (NS * NS + TPS - 1) / TPS;        // pixels per thread: 25 or 7
     __shared__ double red[4][24];
