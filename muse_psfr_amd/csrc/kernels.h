@@ -73,13 +73,14 @@ void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const
 void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
                        const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
                        const void* d_samp_a, void* d_Tq, const void* d_tw64, bool f64, bool fast_exp);
+// d_pre: stamps before the convolutions, float (mixed) or double (f64)
 void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, const void* d_G,
-                    double* d_pre, bool f64);
-void launch_conv(hipStream_t s, int ntask, int nl, const double* d_pre, const void* d_ktt,
+                    void* d_pre, bool f64);
+void launch_conv(hipStream_t s, int ntask, int nl, const void* d_pre, const void* d_ktt,
                  const void* d_kmuse, double* d_fin, bool f64);
 void launch_khat(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
                  void* d_khat);
-void launch_conv_fft(hipStream_t s, int ntask, int nl, const double* d_pre, const void* d_khat_tt,
+void launch_conv_fft(hipStream_t s, int ntask, int nl, const void* d_pre, const void* d_khat_tt,
                      const void* d_khat_muse, double* d_fin);
 void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit, bool f64);
 void launch_stamp_sum(hipStream_t s, int ntask, int nl, const double* d_fin, double* d_sum,

@@ -564,7 +564,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         if ((rc = ensure(c, ln.s00, (size_t)TC * ndir * sizeof(double)))) return rc;
         if ((rc = ensure(c, ln.D0t, (size_t)TC * ndir * H1 * N * rsize(c)))) return rc;
         if ((rc = ensure(c, ln.Tq, (size_t)TC * nl * H1 * NSH * 2 * rsize(c)))) return rc;
-        if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
+        if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * (c->f64 ? 8 : 4)))) return rc;
         if ((rc = ensure(c, ln.fin, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
     }
     if (NL > 1 && (rc = ensure(c, c->lsum, (size_t)NL * nl * per_stamp * sizeof(double)))) return rc;
@@ -620,17 +620,17 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         }
         {
             ProfScope ps(c, K_COLPASS, ls);
-            launch_colpass(ls, N, tc, nl, ln.Tq.p, c->G.p, (double*)ln.pre.p, c->f64);
+            launch_colpass(ls, N, tc, nl, ln.Tq.p, c->G.p, ln.pre.p, c->f64);
         }
         double* d_fin = d_fin_all ? d_fin_all + (size_t)t0 * nl * per_stamp : (double*)ln.fin.p;
         {
             ProfScope ps(c, K_CONV, ls);
             const size_t koff = (size_t)t0 * ksz;
             if (use_fft_conv)
-                launch_conv_fft(ls, tc, nl, (const double*)ln.pre.p, (const char*)c->ktt.p + koff,
+                launch_conv_fft(ls, tc, nl, ln.pre.p, (const char*)c->ktt.p + koff,
                                 c->kmuse.p, d_fin);
             else
-                launch_conv(ls, tc, nl, (const double*)ln.pre.p, (const char*)c->ktt.p + koff,
+                launch_conv(ls, tc, nl, ln.pre.p, (const char*)c->ktt.p + koff,
                             c->kmuse.p, d_fin, c->f64);
         }
         if (fit_out) {
@@ -725,6 +725,7 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
     } else if (!strcmp(what, "pre")) {
         n = (size_t)c->last_chunk_tasks * c->last_nl * NS * NS;
         src = c->lane[c->last_lane].pre.p;
+        is_real_r = true;
     } else {
         return fail(MPSFR_E_INVALID, "unknown buffer '%s'", what);
     }

@@ -173,7 +173,7 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
 template <typename R, int N>
 __global__ void __launch_bounds__(256)
 k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
-          double* __restrict__ pre) {
+          R* __restrict__ pre) {
     constexpr int VW = 8, VB = 4 * VW, TI = 3, TJ = 5, NV = N / 2 + 1;
     constexpr int NPQ = NSH * NS;                 // 840 (P, Q) pairs
     static_assert(NSH == 7 * TI && NS == 8 * TJ, "tile map");
@@ -275,11 +275,136 @@ k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
     if (threadIdx.x == 0) tot = (part[0] + part[1]) + (part[2] + part[3]);
     __syncthreads();
     const double inv = 1.0 / tot;
-    double* out = pre + ((size_t)task * nl + l) * NS * NS;
+    R* out = pre + ((size_t)task * nl + l) * NS * NS;
 #pragma unroll
     for (int m = 0; m < NO; ++m) {
         const int o = threadIdx.x + m * 256;
-        if (o < NS * NS) out[o] = (double)val[m] * inv;
+        if (o < NS * NS) out[o] = (R)((double)val[m] * inv);
+    }
+}
+
+
+// K_COLPASS, fp32 variant on the matrix cores.  The second pass is a dense contraction over the
+// lines v,  P[(task,i)][j] = sum_v Tx[task][v][i] Gx[v][j]  (Q likewise with the imaginary parts),
+// and what bounded the tiled variant above was not the FMAs but handing every lane its operands
+// (8 ds_read_b64 per 30 FMAs: LDS pipe 67 % busy, VALU 33 %).  v_mfma_f32_16x16x4_f32 runs at the
+// same 64 FLOP/clk/SIMD as v_fma_f32 with exact f32 products (a k-ordered fmaf chain), but takes
+// each operand element from ONE lane: lane l supplies A[row l&15][k l>>4] and B[k l>>4][col l&15],
+// both straight from global memory -- no LDS, no broadcast.
+//   rows : three tasks x 21 samples = 63 of 64 (four 16-row tiles)
+//   cols : 40 of 48 (three 16-column tiles)
+//   k    : four lines per instruction; each of the four waves owns one row tile over all lines,
+//          so there is no cross-wave reduction -- LDS only gathers the finished tiles.
+// 82 % of the multiplies are useful; P and Q share their operand loads (T and G are complex).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int N>
+__global__ void __launch_bounds__(256)
+k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>* __restrict__ G,
+            float* __restrict__ pre) {
+    constexpr int NV = N / 2 + 1, TPG = 3, MT = 4, NT = 3, NCOL = NT * 16;
+    constexpr int KST = (NV + 3) / 4;        // k-steps (four lines each)
+    static_assert(TPG * NSH <= MT * 16 && NS <= NCOL, "tile map");
+    __shared__ float red[2][MT * 16][NCOL];  // P, Q
+    __shared__ double part[4][TPG];
+    const int l = blockIdx.x, tg = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    // wave w owns row tile w (all lines, all columns): no cross-wave reduction
+    const int r = 16 * wave + lr, tl = r / NSH, i = r - tl * NSH;
+    const bool aok = tl < TPG && tg * TPG + tl < ntask;
+    // rows without a task read the group's first task (valid memory); they are never used
+    const cx<float>* ap = Tq + ((size_t)(aok ? tg * TPG + tl : tg * TPG) * nl + l) * NV * NSH +
+                          (aok ? i : 0);
+    const cx<float>* bp[NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+        const int j = 16 * ct + lr;
+        bp[ct] = G + (size_t)l * NV * NS + (j < NS ? j : 0);     // columns 40..47 are dropped
+    }
+    f32x4 accP[NT], accQ[NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+        accP[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        accQ[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int PF = 4;                        // k-steps in flight
+    auto load = [&](int ks, cx<float>& a, cx<float>* b) {
+        const int v = 4 * ks + lk;
+        const bool vok = v < NV;                 // k padding: A = 0
+        const int vc = vok ? v : NV - 1;
+        const cx<float> t = ap[(size_t)vc * NSH];
+        a = vok ? t : cx<float>{0.f, 0.f};
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) b[ct] = bp[ct][(size_t)vc * NS];
+    };
+    // Branch-free ring: steps past the last line load line NV-1 again with A = 0 (load() clamps),
+    // so the loop simply runs to the next multiple of PF -- any branch in here makes the compiler
+    // drain the loads (s_waitcnt vmcnt(0)) at every step.
+    cx<float> ra[PF], rb[PF][NT];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) load(k, ra[k], rb[k]);
+    for (int ks = 0; ks < KST; ks += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const cx<float> a = ra[k];
+            cx<float> b[NT];
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) b[ct] = rb[k][ct];
+            load(ks + k + PF, ra[k], rb[k]);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                accP[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[ct].x, accP[ct], 0, 0, 0);
+                accQ[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[ct].y, accQ[ct], 0, 0, 0);
+            }
+        }
+    }
+    // C layout of the 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            red[0][16 * wave + 4 * lk + r4][16 * ct + lr] = accP[ct][r4];
+            red[1][16 * wave + 4 * lk + r4][16 * ct + lr] = accQ[ct][r4];
+        }
+    __syncthreads();
+    const int ng = min(TPG, ntask - tg * TPG);
+    constexpr int NO = (NS * NS + 255) / 256;
+    float val[TPG][NO];
+    double s[TPG];
+#pragma unroll
+    for (int k = 0; k < TPG; ++k) {
+        s[k] = 0.0;
+#pragma unroll
+        for (int m = 0; m < NO; ++m) {
+            const int o = threadIdx.x + m * 256;
+            float x = 0.f;
+            if (k < ng && o < NS * NS) {
+                const int row = o / NS, j = o - row * NS;
+                const int r = k * NSH + (row < NSH ? row : NS - row);
+                const float P = red[0][r][j], Q = red[1][r][j];
+                x = fmaxf(row < NSH ? P + Q : P - Q, 0.f);        // clamp: psfrec.py:680
+                s[k] += (double)x;
+            }
+            val[k][m] = x;
+        }
+        s[k] = wave_sum(s[k]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) part[wave][k] = s[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TPG; ++k) {
+        if (k >= ng) break;
+        const double inv = 1.0 / ((part[0][k] + part[1][k]) + (part[2][k] + part[3][k]));   // :685
+        float* out = pre + ((size_t)(tg * TPG + k) * nl + l) * NS * NS;
+#pragma unroll
+        for (int m = 0; m < NO; ++m) {
+            const int o = threadIdx.x + m * 256;
+            if (o < NS * NS) out[o] = (float)((double)val[k][m] * inv);
+        }
     }
 }
 
@@ -331,15 +456,15 @@ void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const 
 #undef OTF_ARGS
 
 void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, const void* d_G,
-                    double* d_pre, bool f64) {
+                    void* d_pre, bool f64) {
     dim3 grid(nl, ntask);
     DISPATCH_N(N, {
         if (f64)
             hipLaunchKernelGGL((k_colpass<double, NN>), grid, dim3(256), 0, s, nl,
-                               (const cx<double>*)d_Tq, (const cx<double>*)d_G, d_pre);
+                               (const cx<double>*)d_Tq, (const cx<double>*)d_G, (double*)d_pre);
         else
-            hipLaunchKernelGGL((k_colpass<float, NN>), grid, dim3(256), 0, s, nl,
-                               (const cx<float>*)d_Tq, (const cx<float>*)d_G, d_pre);
+            hipLaunchKernelGGL((k_colpass_m<NN>), dim3(nl, (ntask + 2) / 3), dim3(256), 0, s, ntask,
+                               nl, (const cx<float>*)d_Tq, (const cx<float>*)d_G, (float*)d_pre);
     })
 }
 

@@ -68,7 +68,7 @@ struct Vec4<double> { using type = double4; };
 
 template <typename R>
 __global__ void __launch_bounds__(256)
-k_conv(int nl, const double* __restrict__ pre, const R* __restrict__ ktt,
+k_conv(int nl, const R* __restrict__ pre, const R* __restrict__ ktt,
        const R* __restrict__ kmuse, double* __restrict__ fin) {
     constexpr int PH = NS + KS - 1;   // 80 frame rows
     constexpr int PW = 84;            // frame pitch (80 used)
@@ -80,7 +80,7 @@ k_conv(int nl, const double* __restrict__ pre, const R* __restrict__ ktt,
     extern __shared__ __align__(32) unsigned char smem[];
     R* img = reinterpret_cast<R*>(smem);   // [PH][PW]
     const int l = blockIdx.x, task = blockIdx.y;
-    const double* src = pre + ((size_t)task * nl + l) * NS * NS;
+    const R* src = pre + ((size_t)task * nl + l) * NS * NS;
     for (int e = threadIdx.x; e < PH * PW; e += 256) {
         const int P = e / PW - HK, Q = e % PW - HK;
         img[e] = (P >= 0 && P < NS && Q >= 0 && Q < NS) ? (R)src[P * NS + Q] : (R)0;
@@ -223,7 +223,7 @@ __device__ __forceinline__ void cf_split0(const cx<float>* res, int kx, cx<float
 }
 
 __global__ void __launch_bounds__(256)
-k_conv_fft(int nl, const double* __restrict__ pre, const cx<float>* __restrict__ khat_tt,
+k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ khat_tt,
            const cx<float>* __restrict__ khat_muse, double* __restrict__ fin) {
     __shared__ float img[NS * NS];
     __shared__ cx<float> F[CF][CFP];
@@ -232,8 +232,8 @@ k_conv_fft(int nl, const double* __restrict__ pre, const cx<float>* __restrict__
     const int slot = threadIdx.x >> 3, t = threadIdx.x & 7;
     Tw64 tw;
     tw.init(t);
-    const double* src = pre + ((size_t)task * nl + l) * NS * NS;
-    for (int e = threadIdx.x; e < NS * NS; e += 256) img[e] = (float)src[e];
+    const float* src = pre + ((size_t)task * nl + l) * NS * NS;
+    for (int e = threadIdx.x; e < NS * NS; e += 256) img[e] = src[e];
     cx<float>* buf = bufs[slot];
     for (int pass = 0; pass < 2; ++pass) {
         const cx<float>* __restrict__ kh = pass == 0 ? khat_tt + (size_t)task * (CFH + 1) * CF
@@ -842,17 +842,19 @@ void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const
                            (float*)d_out);
 }
 
-void launch_conv(hipStream_t s, int ntask, int nl, const double* d_pre, const void* d_ktt,
+void launch_conv(hipStream_t s, int ntask, int nl, const void* d_pre, const void* d_ktt,
                  const void* d_kmuse, double* d_fin, bool f64) {
     dim3 grid(nl, ntask);
     constexpr int PH = NS + KS - 1, PW = 84;
     if (f64) {
         const size_t sm = (size_t)(PH * PW) * sizeof(double);
-        hipLaunchKernelGGL(k_conv<double>, grid, dim3(256), sm, s, nl, d_pre, (const double*)d_ktt,
+        hipLaunchKernelGGL(k_conv<double>, grid, dim3(256), sm, s, nl, (const double*)d_pre,
+                           (const double*)d_ktt,
                            (const double*)d_kmuse, d_fin);
     } else {
         const size_t sm = (size_t)(PH * PW) * sizeof(float);
-        hipLaunchKernelGGL(k_conv<float>, grid, dim3(256), sm, s, nl, d_pre, (const float*)d_ktt,
+        hipLaunchKernelGGL(k_conv<float>, grid, dim3(256), sm, s, nl, (const float*)d_pre,
+                           (const float*)d_ktt,
                            (const float*)d_kmuse, d_fin);
     }
 }
@@ -863,9 +865,9 @@ void launch_khat(hipStream_t s, int nker, const double* d_gamma, const double* d
     hipLaunchKernelGGL(k_khat, dim3(nker), dim3(256), 0, s, d_gamma, d_alpha, (cx<float>*)d_khat);
 }
 
-void launch_conv_fft(hipStream_t s, int ntask, int nl, const double* d_pre, const void* d_khat_tt,
+void launch_conv_fft(hipStream_t s, int ntask, int nl, const void* d_pre, const void* d_khat_tt,
                      const void* d_khat_muse, double* d_fin) {
-    hipLaunchKernelGGL(k_conv_fft, dim3(nl, ntask), dim3(256), 0, s, nl, d_pre,
+    hipLaunchKernelGGL(k_conv_fft, dim3(nl, ntask), dim3(256), 0, s, nl, (const float*)d_pre,
                        (const cx<float>*)d_khat_tt, (const cx<float>*)d_khat_muse, d_fin);
 }
 
