@@ -238,6 +238,14 @@ k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ 
     for (int pass = 0; pass < 2; ++pass) {
         const cx<float>* __restrict__ kh = pass == 0 ? khat_tt + (size_t)task * (CFH + 1) * CF
                                                      : khat_muse + (size_t)l * (CFH + 1) * CF;
+        // the thread's kernel-spectrum values, fetched now so that the row transforms hide the
+        // latency (slot 0 also carries the Nyquist column)
+        cx<float> khv[8], khn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            khv[e] = kh[slot * CF + t + 8 * e];
+            khn[e] = slot == 0 ? kh[CFH * CF + t + 8 * e] : cx<float>{0.f, 0.f};
+        }
         __syncthreads();
         if (slot < NS / 2) cf_rows_forward(img, NS, F, buf, tw, slot, t);
         __syncthreads();
@@ -251,10 +259,10 @@ k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ 
                 if (slot == 0) {
                     cx<float> a0, a32;
                     cf_split0(res, kx, a0, a32);
-                    const cx<float> b0 = cmul(a0, kh[kx]), b32 = cmul(a32, kh[CFH * CF + kx]);
+                    const cx<float> b0 = cmul(a0, khv[e]), b32 = cmul(a32, khn[e]);
                     v = {b0.x - b32.y, b0.y + b32.x};
                 } else {
-                    v = cmul(res[lds_pad(kx)], kh[slot * CF + kx]);
+                    v = cmul(res[lds_pad(kx)], khv[e]);
                 }
                 y[e] = conjf(v);
             }
@@ -409,22 +417,43 @@ struct NormEqT {
 };
 using NormEq = NormEqT<double>;
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave-wide sums for the fit, on the DPP path instead of ds_bpermute shuffles (21 sums per model
+// evaluation; a shuffle goes through the LDS crossbar and its latency sat on the critical path of
+// the serial LM iterations).  Quad swaps, half-row and row mirrors give every lane its row-of-16
+// sum; row_bcast15 / row_bcast31 fold the four rows into lane 63, which is read into a scalar
+// register -- the LM state is wave-uniform and lives in SGPRs.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_term(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                                         0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
-
-// A value every lane of the wave already agrees on, moved to scalar registers: the LM state of a
-// stamp is wave-uniform, and keeping it out of the VGPR file is what buys the third wave per SIMD.
-__device__ __forceinline__ float wave_uniform(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
-}
-__device__ __forceinline__ double wave_uniform(double x) {
-    const long long b = __builtin_bit_cast(long long, x);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_term(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL,
+                                                              ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK,
+                                                              0xf, false);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+__device__ __forceinline__ float lane63(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+__device__ __forceinline__ double lane63(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+template <typename T>
+__device__ __forceinline__ T wave_total(T v) {
+    v += dpp_term<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+    v += dpp_term<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+    v += dpp_term<0x141, 0xf>(v);    // row_half_mirror
+    v += dpp_term<0x140, 0xf>(v);    // row_mirror: every lane holds its row's sum
+    v += dpp_term<0x142, 0xa>(v);    // row_bcast15 into rows 1 and 3
+    v += dpp_term<0x143, 0xc>(v);    // row_bcast31 into rows 2 and 3: lane 63 holds the total
+    return lane63(v);
 }
 
 template <typename RE>
@@ -505,11 +534,11 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int first, con
             for (int y = x; y < 5; ++y) a[k++] += J[x] * J[y];
         }
     }
-    ne.chi2 = wave_uniform(wave_sum(chi2));
+    ne.chi2 = wave_total(chi2);
 #pragma unroll
-    for (int k = 0; k < 15; ++k) ne.a[k] = wave_uniform(wave_sum(a[k]));
+    for (int k = 0; k < 15; ++k) ne.a[k] = wave_total(a[k]);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) ne.g[k] = wave_uniform(wave_sum(g[k]));
+    for (int k = 0; k < 5; ++k) ne.g[k] = wave_total(g[k]);
     if constexpr (WPS > 1) {
         static_assert(WPS == 4, "cross-wave reduction written for 4 waves");
         const int wave = threadIdx.x >> 6;
@@ -632,6 +661,9 @@ __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][
     return true;
 }
 
+#ifndef MPSFR_POLISH_TOL
+#define MPSFR_POLISH_TOL 1.0e-5
+#endif
 #ifndef MPSFR_FIT_WAVES
 #define MPSFR_FIT_WAVES 3
 #endif
@@ -775,7 +807,7 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) v[k] += dx[k];
             ++it;
-            if (rel < 1.0e-5) break;      // error after this step ~ rel^2
+            if (rel < MPSFR_POLISH_TOL) break;      // error after this step ~ rel^2
         }
     }
     // back to (a, n); normal equations there for chi2 and the covariance
