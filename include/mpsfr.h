@@ -63,7 +63,8 @@ const char* mpsfr_last_error(void);
  * pipeline lanes -- consecutive chunks of a call alternate between two HIP streams with their own
  * workspaces so that one chunk's tail overlaps the other's body; results are independent of it
  * except for the summation order of psf_sum_out); "profile" (0/1: bracket every kernel launch
- * with HIP events on the stream it is launched on). */
+ * with HIP events on the stream it is launched on -- the event packets cost ~8 % of a step);
+ * "profile_only" (-1 = all kernels, else the kernel id of mpsfr_profile_name to time alone). */
 int mpsfr_set_option(mpsfr_ctx* ctx, const char* key, double value);
 
 /* Batched replacement of  Parallel(n_jobs)(delayed(compute_psf)(*args) ...)  (psfrec.py:1082-1083)

@@ -208,5 +208,10 @@ class Context:
             res[self.lib.mpsfr_profile_name(i).decode()] = (ms.value, n.value)
         return res
 
+    def profile_names(self):
+        """Kernel names in id order (the ids `profile_only` takes)."""
+        return [self.lib.mpsfr_profile_name(i).decode()
+                for i in range(self.lib.mpsfr_profile_count())]
+
     def profile_reset(self):
         _check(self.lib.mpsfr_profile_reset(self._h))

@@ -63,6 +63,7 @@ struct mpsfr_ctx {
     int chunk_tasks = 0;   // 0 = automatic
     bool fast_exp = true;    // mixed mode: exp(x) = v_exp_f32(x log2 e)
     bool profile = false;
+    int prof_only = -1;          // >= 0: time only this kernel id
     bool fft_conv = true;   // mixed mode: convolutions through 64-point FFTs
     // constant tables
     DevBuf tw64, tel, rows;
@@ -145,16 +146,18 @@ struct ProfScope {
     int id;
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t st;
+    bool on = false;
     ProfScope(mpsfr_ctx* ctx, int kid, hipStream_t stream = nullptr)
         : c(ctx), id(kid), st(stream ? stream : ctx->stream) {
-        if (c->profile) {
+        on = c->profile && (c->prof_only < 0 || c->prof_only == kid);
+        if (on) {
             a = get_event(c);
             b = get_event(c);
             (void)hipEventRecord(a, st);
         }
     }
     ~ProfScope() {
-        if (c->profile) {
+        if (on) {
             (void)hipEventRecord(b, st);
             c->pending.push_back({id, a, b});
         }
@@ -353,6 +356,10 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         c->fft_conv = value != 0.0;
     } else if (!strcmp(key, "profile")) {
         c->profile = value != 0.0;
+    } else if (!strcmp(key, "profile_only")) {
+        if (value != (int)value || value < -1.0 || value >= K_COUNT)
+            return fail(MPSFR_E_INVALID, "profile_only must be -1 or a kernel id");
+        c->prof_only = (int)value;
     } else {
         return fail(MPSFR_E_INVALID, "unknown option '%s'", key);
     }
