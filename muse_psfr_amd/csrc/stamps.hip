@@ -506,7 +506,7 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int first, con
     const double dKn_d = WN ? -(s_d + 1.0) * 0.69314718055994530942 / (n_d * n_d * s_d) : 0.0;
     const RE I = (RE)v[0], p0 = (RE)v[1], q0 = (RE)v[2], n = (RE)n_d, K = (RE)K_d;
     const RE i3 = (RE)(1.0 / v[3]), dKn = (RE)dKn_d;
-    constexpr int UF = MEM ? 1 : (NPX > 5 ? (NPX % 5 == 0 ? 5 : NPX) : NPX);
+    constexpr int UF = NPX > 5 ? (NPX % 5 == 0 ? 5 : NPX) : NPX;
 #pragma unroll UF
     for (int m = 0; m < NPX; ++m) {
         const int o = first + m * STRIDE;
@@ -559,6 +559,46 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int first, con
         ne.chi2 = (RE)((red[0][20] + red[1][20]) + (red[2][20] + red[3][20]));
         __syncthreads();
     }
+}
+
+// fp64 gradient J^T r of the Moffat model in (I, p0, q0, w, n) over the stamp in memory, for the
+// polish of the mixed mode: the fixed point of the iteration is where this vanishes, whatever
+// matrix the step is solved with, so the polish keeps the float normal matrix of the last LM
+// iteration (relative error ~1e-3: linear convergence at that rate) and only these five sums are
+// fp64 -- 10 accumulator registers instead of 42, which is what lets four waves share a SIMD.
+__device__ __forceinline__ double sgpr(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+
+__device__ __forceinline__ void moffat_gradient(const double* __restrict__ src, int lane,
+                                                const double* v, double* gout) {
+    const double n = sgpr(v[4]);
+    const double s = exp2(1.0 / n) - 1.0;
+    const double K = sgpr(4.0 * s / (v[3] * v[3]));
+    const double dKn = sgpr(-(s + 1.0) * 0.69314718055994530942 / (n * n * s));
+    const double I = sgpr(v[0]), p0 = sgpr(v[1]), q0 = sgpr(v[2]), i3 = sgpr(1.0 / v[3]);
+    double g[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int o = lane; o < NS * NS; o += 64) {
+        const double dp = (double)(o / NS) - p0, dq = (double)(o % NS) - q0;
+        const double u = dp * dp + dq * dq;
+        const double gg = 1.0 + u * K;
+        const double lg = log(gg);
+        const double e = exp(-n * lg);
+        const double mo = I * e;
+        const double r = mo - src[o];
+        const double cm = mo * n / gg;
+        const double c2 = cm * 2.0 * K * r;
+        g[0] += e * r;
+        g[1] += c2 * dp;
+        g[2] += c2 * dq;
+        g[3] += c2 * u * i3;
+        g[4] += (-mo * lg - cm * u * K * dKn) * r;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) gout[k] = wave_total(g[k]);
 }
 
 // Cholesky factor of the Marquardt-scaled normal matrix  A'_ij = A_ij / (d_i d_j) + mu delta_ij,
@@ -665,12 +705,16 @@ __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][
 #define MPSFR_POLISH_TOL 1.0e-5
 #endif
 #ifndef MPSFR_FIT_WAVES
-#define MPSFR_FIT_WAVES 3
+#define MPSFR_FIT_WAVES 4
 #endif
 // amdgpu_waves_per_eu: the serial LM iterations are latency-bound, so occupancy matters more than
-// the scheduler's appetite for registers (208 VGPRs -> 2 waves/SIMD without the hint).
+// the scheduler's appetite for registers (208 VGPRs -> 2 waves/SIMD without the hint).  The fp64
+// mode needs the registers (2 waves).
+template <typename RE>
+constexpr int fit_min_waves() { return sizeof(RE) == 4 ? MPSFR_FIT_WAVES : 2; }
+
 template <typename RE, int WPS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MPSFR_FIT_WAVES)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fit_min_waves<RE>())))
 k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
     constexpr int TPS = 64 * WPS;                         // threads per stamp
     constexpr int NPX = (NS * NS + TPS - 1) / TPS;        // pixels per thread: 25 or 7
@@ -681,6 +725,11 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
     if (st >= nstamp) return;   // WPS == 1: the whole wave exits together; WPS == 4: never taken
     const double* src = stamps + (size_t)st * NS * NS;
     RE dpix[NPX];
+    // the stamp in the evaluation type, LDS-resident for the LM evaluations (25 fewer VGPRs than
+    // register-resident pixels: with the gradient-only polish this reaches 4 waves per SIMD, so
+    // all 3500 stamps of the bench step are resident at once instead of in two rounds)
+    __shared__ RE spix[4][NS * NS];
+    RE* sp = spix[threadIdx.x >> 6];
     double best = -1.0e300;
     int besto = 0;
 #pragma unroll
@@ -688,6 +737,7 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
         const int o = first + m * TPS;
         const double d = o < NS * NS ? src[o] : -1.0e300;
         dpix[m] = o < NS * NS ? (RE)d : (RE)0;
+        if (o < NS * NS) sp[o] = (RE)d;
         if (d > best) { best = d; besto = o; }
     }
     // argmax (first maximum in C order, as np.argmax) and the pixel count above half maximum
@@ -738,7 +788,7 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
     // moffat_accumulate are identical in all of them), so the control flow is uniform.
     const double tol = sizeof(RE) == 4 ? 1.0e-3 : 1.0e-10;
     NormEqT<RE> ne;
-    moffat_accumulate<RE, true, false, NPX, WPS>(dpix, first, v, ne, red);
+    moffat_accumulate<RE, true, true, NPX, WPS>(sp, first, v, ne, red);
     double mu = 1.0e-2, nu = 2.0;
     int it = 0, status = 1;
     const int maxit = 200;
@@ -767,7 +817,7 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
         NormEqT<RE> nn;
         double rho = -1.0;
         if (inside) {
-            moffat_accumulate<RE, true, false, NPX, WPS>(dpix, first, vn, nn, red);
+            moffat_accumulate<RE, true, true, NPX, WPS>(sp, first, vn, nn, red);
             // predicted decrease of chi2: dx^T (mu D dx - g)
             double pred = 0.0;
             const int dg[5] = {0, 5, 9, 12, 14};
@@ -791,23 +841,29 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
     }
     if constexpr (sizeof(RE) == 4) {
         // The float evaluation has systematic errors of ~1e-6 in the wings (v_log/v_exp), enough
-        // to move beta by a few 1e-4 on flat-topped stamps.  Polish with fp64 Gauss-Newton steps
-        // from the float solution (quadratic convergence: one or two suffice).
-        for (int pz = 0; pz < 6 && status != 2; ++pz) {
-            NormEq np;
-            moffat_accumulate<double, true, true, NPX, WPS>(src, first, v, np, red);
+        // to move beta by a few 1e-4 on flat-topped stamps.  Polish from the float solution with
+        // steps  -A^-1 g,  g the fp64 gradient (moffat_gradient), A the float normal matrix of the
+        // last LM iteration: one or two steps suffice.
+        static_assert(WPS == 1, "the polish is written for one wave per stamp");
+        NormEq np;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) np.a[k] = (double)ne.a[k];
+        np.chi2 = 0.0;
+        for (int pz = 0; pz < 8 && status != 2; ++pz) {
+            moffat_gradient(src, lane, v, np.g);
             double dx[5];
             if (!lm_solve<double, double>(np, 1.0e-10, dx)) break;
             double rel = 0.0;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) rel = fmax(rel, fabs(dx[k]) / (fabs(v[k] + dx[k]) + 1.0e-300));
+            for (int k = 0; k < 5; ++k)
+                rel = fmax(rel, fabs(dx[k]) / (fabs(v[k] + dx[k]) + 1.0e-300));
             const bool inside = v[3] + dx[3] > 1.0e-3 && v[4] + dx[4] > 1.0e-2 &&
                                 v[4] + dx[4] < 1.0e3 && rel < 0.1;
             if (!inside) break;
 #pragma unroll
             for (int k = 0; k < 5; ++k) v[k] += dx[k];
             ++it;
-            if (rel < MPSFR_POLISH_TOL) break;      // error after this step ~ rel^2
+            if (rel < MPSFR_POLISH_TOL) break;      // error after this step ~ 1e-3 rel
         }
     }
     // back to (a, n); normal equations there for chi2 and the covariance
@@ -815,7 +871,7 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
     const double s2 = exp2(1.0 / n) - 1.0, sq = sqrt(s2);
     const double al = fabs(v[3]) / (2.0 * sq);
     double va[5] = {v[0], v[1], v[2], al, n};
-    moffat_accumulate<RE, false, false, NPX, WPS>(dpix, first, va, ne, red);
+    moffat_accumulate<RE, false, true, NPX, WPS>(sp, first, va, ne, red);
     if (threadIdx.x == 0 || (WPS == 1 && lane == 0)) {
         double* o = fit + (size_t)st * NFIT;
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = al; o[4] = n;
