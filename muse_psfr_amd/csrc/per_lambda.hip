@@ -142,8 +142,8 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
                 const R w = samp_a[ll * NS + i];
                 const int q = p + 1 == N ? 0 : p + 1;
                 const int mp = p == 0 ? 0 : N - p, mq = q == 0 ? 0 : N - q;
-                const cx<R> zp = res[lds_pad(p)], zmp = res[lds_pad(mp)];
-                const cx<R> zq = res[lds_pad(q)], zmq = res[lds_pad(mq)];
+                const cx<R> zp = res[lds_out<N, sizeof(cx<R>)>(p)], zmp = res[lds_out<N, sizeof(cx<R>)>(mp)];
+                const cx<R> zq = res[lds_out<N, sizeof(cx<R>)>(q)], zmq = res[lds_out<N, sizeof(cx<R>)>(mq)];
                 cx<R> f0, f1;
                 const R h = (R)0.5;
                 if (which == 0) {

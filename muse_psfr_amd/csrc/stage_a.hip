@@ -187,7 +187,7 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
         if (row0 + rr >= NR) continue;
         const cx<double>* rs = (L::WSYNC ? bufA : (res == bufA + slot * NPAD ? bufA : bufB)) +
                                (rr >> 1) * NPAD;
-        const cx<double> z = rs[lds_pad(y)], zm = rs[lds_pad(y == 0 ? 0 : N - y)];
+        const cx<double> z = rs[lds_out<N, 16>(y)], zm = rs[lds_out<N, 16>(y == 0 ? 0 : N - y)];
         cx<double> o;
         if ((rr & 1) == 0) o = {0.5 * (z.x + zm.x), 0.5 * (z.y - zm.y)};
         else o = {0.5 * (z.y + zm.y), -0.5 * (z.x - zm.x)};
@@ -251,7 +251,7 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
     if (y <= N / 2) {
         const double dc = s00[td];
         RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N;
-        for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[lds_pad(x)].x));
+        for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
     }
 }
 

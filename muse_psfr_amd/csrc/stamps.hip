@@ -189,9 +189,9 @@ __device__ __forceinline__ void cf_rows_forward(const float* im, int nrow, cx<fl
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int k = t + 8 * e;
-        const cx<float> zk = res[lds_pad(k)], zm = res[lds_pad((CF - k) % CF)];
+        const cx<float> zk = res[lds_out<CF, 8>(k)], zm = res[lds_out<CF, 8>((CF - k) % CF)];
         if (k == 0) {
-            const cx<float> zn = res[lds_pad(CFH)];
+            const cx<float> zn = res[lds_out<CF, 8>(CFH)];
             F[ra][0] = {zk.x, zn.x};      // (DC, Nyquist) of row ra, both real
             F[rb][0] = {zk.y, zn.y};
         } else {
@@ -217,7 +217,7 @@ __device__ __forceinline__ const cx<float>* cf_col_forward(cx<float> (*F)[CFP], 
 // split the packed column 0 spectrum into the DC column and the Nyquist column at kx
 __device__ __forceinline__ void cf_split0(const cx<float>* res, int kx, cx<float>& a0,
                                           cx<float>& a32) {
-    const cx<float> p = res[lds_pad(kx)], pm = res[lds_pad((CF - kx) % CF)];
+    const cx<float> p = res[lds_out<CF, 8>(kx)], pm = res[lds_out<CF, 8>((CF - kx) % CF)];
     a0 = {0.5f * (p.x + pm.x), 0.5f * (p.y - pm.y)};
     a32 = {0.5f * (p.y + pm.y), -0.5f * (p.x - pm.x)};
 }
@@ -262,7 +262,7 @@ k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ 
                     const cx<float> b0 = cmul(a0, khv[e]), b32 = cmul(a32, khn[e]);
                     v = {b0.x - b32.y, b0.y + b32.x};
                 } else {
-                    v = cmul(res[lds_pad(kx)], khv[e]);
+                    v = cmul(res[lds_out<CF, 8>(kx)], khv[e]);
                 }
                 y[e] = conjf(v);
             }
@@ -270,7 +270,7 @@ k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int r = t + 8 * e;
-                if (r >= KS / 2 && r < KS / 2 + NS) F[r][slot] = conjf(r2[lds_pad(r)]);
+                if (r >= KS / 2 && r < KS / 2 + NS) F[r][slot] = conjf(r2[lds_out<CF, 8>(r)]);
             }
         }
         __syncthreads();
@@ -301,7 +301,7 @@ k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ 
             for (int e = 0; e < 8; ++e) {
                 const int c = t + 8 * e;
                 if (c >= KS / 2 && c < KS / 2 + NS) {
-                    const cx<float> v = res[lds_pad(c)];
+                    const cx<float> v = res[lds_out<CF, 8>(c)];
                     const int i = 2 * slot, j = c - KS / 2;
                     if (pass == 0) {
                         img[i * NS + j] = v.x;
@@ -371,9 +371,9 @@ k_khat(const double* __restrict__ gam, const double* __restrict__ alp,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = t + 8 * e;
-            const cx<float> zk = res[lds_pad(k)], zm = res[lds_pad((CF - k) % CF)];
+            const cx<float> zk = res[lds_out<CF, 8>(k)], zm = res[lds_out<CF, 8>((CF - k) % CF)];
             if (k == 0) {
-                const cx<float> zn = res[lds_pad(CFH)];
+                const cx<float> zn = res[lds_out<CF, 8>(CFH)];
                 F[ra][0] = {zk.x, zn.x};
                 F[rb][0] = {zk.y, zn.y};
             } else {
@@ -394,7 +394,7 @@ k_khat(const double* __restrict__ gam, const double* __restrict__ alp,
             out[kx] = a0;
             out[CFH * CF + kx] = a32;
         } else {
-            out[slot * CF + kx] = res[lds_pad(kx)];
+            out[slot * CF + kx] = res[lds_out<CF, 8>(kx)];
         }
     }
 }
