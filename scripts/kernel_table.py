@@ -1,0 +1,44 @@
+"""Per-kernel resource table from scripts/prof_table.sh output (single lane, kernels do not overlap).
+usage: python scripts/kernel_table.py gpurun_out/prof_table > profiles/rNN_kernel_table.md"""
+import csv
+import re
+import sys
+
+d = sys.argv[1]
+txt = open(d + '/pmc_summary.txt').read()
+blocks = {b.split('\n')[0]: b for b in re.split(r'\n(?=\S)', txt)}
+
+
+def get(k, c):
+    for name, b in blocks.items():
+        if name.startswith(k):
+            m = re.search(c + r'\s+n=\s*\d+\s+mean=([0-9.e+]+)', b)
+            if m:
+                return float(m.group(1))
+    return 0.0
+
+
+dur = {}
+for r in csv.DictReader(open(d + '/kernel_stats.csv')):
+    m = re.search(r'k_\w+', r['Name'])
+    if m and m.group(0) not in dur:
+        dur[m.group(0)] = float(r['AverageNs']) * 1e-9
+print('# Per-kernel resource use (single lane: `bench.py --streams 1`, 100 rows x 35 lambda x 512^2)\n')
+print('Source: `scripts/prof_table.sh` -- rocprofv3 kernel trace (durations) and separate PMC passes.')
+print('VALU = SQ_INSTS_VALU x 2 issue cycles / (1024 SIMDs x kernel cycles at 2.4 GHz), a lower bound: fp64 '
+      'and transcendental instructions take 4; LDS = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles); '
+      'HBM = (FETCH_SIZE + WRITE_SIZE) / duration, uncorrected.\n')
+print('| kernel | avg us | VALU issue | LDS array busy | of which bank conflicts | HBM GB/s |')
+print('|---|---|---|---|---|---|')
+for k in ('k_otf_rowfft', 'k_fit', 'k_conv_fft', 'k_colpass_m', 'k_psd_rowfft', 'k_colfft_dphi',
+          'k_khat', 'k_stamp_sum', 'k_dc_sum'):
+    if k not in dur:
+        continue
+    t = dur[k]
+    cyc = t * 2.4e9
+    valu = get(k, 'SQ_INSTS_VALU') * 2 / (1024 * cyc)
+    lds = get(k, 'SQ_LDS_IDX_ACTIVE') / (256 * cyc)
+    conf = get(k, 'SQ_LDS_BANK_CONFLICT') / max(get(k, 'SQ_LDS_IDX_ACTIVE'), 1)
+    hbm = (get(k, 'FETCH_SIZE') + get(k, 'WRITE_SIZE')) * 1024 / t / 1e9
+    print('| `%s` | %.1f | %.0f %% | %.0f %% | %.0f %% | %.0f |' % (k, t * 1e6, valu * 100, lds * 100,
+                                                                 conf * 100, hbm))
