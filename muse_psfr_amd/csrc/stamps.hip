@@ -561,6 +561,22 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int first, con
     }
 }
 
+// chi2 alone at (I, p0, q0, a, n): the residual pass without the Jacobian (a third of the work)
+template <typename RE, typename DT>
+__device__ __forceinline__ RE moffat_chi2(const DT* pix, int lane, const double* va) {
+    const RE I = (RE)va[0], p0 = (RE)va[1], q0 = (RE)va[2], n = (RE)va[4];
+    const RE K = (RE)(1.0 / (va[3] * va[3]));
+    RE c[5] = {(RE)0, (RE)0, (RE)0, (RE)0, (RE)0};
+#pragma unroll 5
+    for (int m = 0; m < NS * NS / 64; ++m) {
+        const int o = lane + m * 64;
+        const RE dp = (RE)(o / NS) - p0, dq = (RE)(o % NS) - q0;
+        const RE r = I * fit_exp<RE>(-n * fit_log<RE>((RE)1 + (dp * dp + dq * dq) * K)) - (RE)pix[o];
+        c[m % 5] += r * r;
+    }
+    return wave_total(((c[0] + c[1]) + (c[2] + c[3])) + c[4]);
+}
+
 // fp64 gradient J^T r of the Moffat model in (I, p0, q0, w, n) over the stamp in memory, for the
 // polish of the mixed mode: the fixed point of the iteration is where this vanishes, whatever
 // matrix the step is solved with, so the polish keeps the float normal matrix of the last LM
@@ -866,28 +882,36 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
             if (rel < MPSFR_POLISH_TOL) break;      // error after this step ~ 1e-3 rel
         }
     }
-    // back to (a, n); normal equations there for chi2 and the covariance
+    // Outputs in (a, n).  chi2 is evaluated at the final point (residuals only); the covariance
+    // comes from the normal matrix of the last LM iteration (in (w, n), a point within ~1e-4 of
+    // the final one for well-posed stamps) -- no further Jacobian pass.  I, p0, q0, n are the
+    // same variables in both parametrisations, so their variances carry over; FWHM = w directly;
+    // alpha = w / (2 sqrt(2^(1/n) - 1)) through its partial derivatives.
     const double n = v[4];
-    const double s2 = exp2(1.0 / n) - 1.0, sq = sqrt(s2);
+    const double p2 = exp2(1.0 / n), s2 = p2 - 1.0, sq = sqrt(s2);
     const double al = fabs(v[3]) / (2.0 * sq);
-    double va[5] = {v[0], v[1], v[2], al, n};
-    moffat_accumulate<RE, false, true, NPX, WPS>(sp, first, va, ne, red);
-    if (threadIdx.x == 0 || (WPS == 1 && lane == 0)) {
+    static_assert(WPS == 1, "one wave per stamp");
+    const double va[5] = {v[0], v[1], v[2], al, n};
+    const double chi2 = (double)moffat_chi2<RE>(sp, lane, va);
+    if (lane == 0) {
         double* o = fit + (size_t)st * NFIT;
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = al; o[4] = n;
         o[5] = fabs(v[3]);
-        o[6] = (double)ne.chi2;
+        o[6] = chi2;
         o[7] = (double)it;
         double cov[5][5];
         const double dof = (double)(NS * NS - 5);
         if (spd_inverse(ne, cov)) {
-            const double s = (double)ne.chi2 / dof;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) o[8 + k] = sqrt(fmax(cov[k][k] * s, 0.0));
-            const double da = 2.0 * sq;
-            const double dn = -al * exp2(1.0 / n) * 0.69314718055994530942 / (sq * n * n);
-            const double var = da * da * cov[3][3] + 2.0 * da * dn * cov[3][4] + dn * dn * cov[4][4];
-            o[13] = sqrt(fmax(var * s, 0.0));
+            const double s = chi2 / dof;
+            o[8] = sqrt(fmax(cov[0][0] * s, 0.0));
+            o[9] = sqrt(fmax(cov[1][1] * s, 0.0));
+            o[10] = sqrt(fmax(cov[2][2] * s, 0.0));
+            const double aw = 1.0 / (2.0 * sq);
+            const double an = al * p2 * 0.69314718055994530942 / (2.0 * s2 * n * n);
+            const double var = aw * aw * cov[3][3] + 2.0 * aw * an * cov[3][4] + an * an * cov[4][4];
+            o[11] = sqrt(fmax(var * s, 0.0));
+            o[12] = sqrt(fmax(cov[4][4] * s, 0.0));
+            o[13] = sqrt(fmax(cov[3][3] * s, 0.0));
         } else {
             for (int k = 0; k < 6; ++k) o[8 + k] = 0.0;
             if (status == 0) status = 2;
