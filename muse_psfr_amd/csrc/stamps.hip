@@ -402,7 +402,7 @@ k_khat(const double* __restrict__ gam, const double* __restrict__ alp,
 // ------------------------------------------------------------------------------------------
 // K_FIT: 5-parameter circular Moffat least-squares fit per stamp (fit_psf_cube psfrec.py:861-871
 // -> mpdaf Image.moffat_fit(circular=True, fit_back=False)): I (1 + ((p-p0)^2+(q-q0)^2)/a^2)^-n,
-// unweighted, all 1600 pixels.  One workgroup (or one wavefront) per stamp, pixels in registers.
+// unweighted, all 1600 pixels.  One wavefront per stamp (25 pixels per lane), the stamp in LDS.
 // Levenberg-Marquardt (Marquardt scaling, Nielsen's gain-ratio damping update) iterated in the
 // better-conditioned variables (I, p0, q0, w = FWHM, n) -- the minimum is the same point.
 // Per-lane sums run in the evaluation type RE (float in mixed mode, double in f64 mode); the
@@ -482,18 +482,14 @@ __device__ __forceinline__ float fit_rsqrt<float>(float x) { return __builtin_am
 template <>
 __device__ __forceinline__ double fit_rsqrt<double>(double x) { return 1.0 / sqrt(x); }
 
-// Normal equations of the Moffat model at v over the thread's pixels o = first + m * stride
-// (m < NPX, o < 1600), reduced over the TPS threads that share the stamp.
-//   WN = true : v = (I, p0, q0, w, n), 1/a^2 = 4 (2^(1/n) - 1) / w^2
-//   WN = false: v = (I, p0, q0, a, n)
-// dpix: the thread's pixels in registers (MEM = false) or the stamp in memory (MEM = true).
+// Normal equations of the Moffat model at v = (I, p0, q0, w, n), 1/a^2 = 4 (2^(1/n) - 1) / w^2,
+// over the lane's pixels o = lane + 64 m of the stamp `pix` (LDS), summed over the wave.
 // Cross-lane sums run in the evaluation type: the float phase only has to reach the basin of
-// convergence (tol 1e-3); the polish and the f64 mode reduce in double.  With more than one wave
-// per stamp the wave sums meet in LDS (fixed order); every thread ends up with the same totals.
-template <typename RE, bool WN, bool MEM, int NPX, int WPS, typename DT>
-__device__ __forceinline__ void moffat_accumulate(const DT* dpix, int first, const double* v,
-                                                  NormEqT<RE>& ne, double (*red)[24]) {
-    constexpr int STRIDE = 64 * WPS;
+// convergence (tol 1e-3); the f64 mode reduces in double.  Every lane ends up with the totals.
+template <typename RE>
+__device__ __forceinline__ void moffat_accumulate(const RE* pix, int lane, const double* v,
+                                                  NormEqT<RE>& ne) {
+    constexpr int NPX = NS * NS / 64;
     RE a[15], g[5], chi2 = (RE)0;
 #pragma unroll
     for (int k = 0; k < 15; ++k) a[k] = (RE)0;
@@ -501,23 +497,21 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int first, con
     for (int k = 0; k < 5; ++k) g[k] = (RE)0;
     const double n_d = v[4];
     const double s_d = exp2(1.0 / n_d) - 1.0;
-    const double K_d = WN ? 4.0 * s_d / (v[3] * v[3]) : 1.0 / (v[3] * v[3]);
-    // d(1/a^2)/dn / (1/a^2) = s'/s with s' = -2^(1/n) ln2 / n^2   (WN only)
-    const double dKn_d = WN ? -(s_d + 1.0) * 0.69314718055994530942 / (n_d * n_d * s_d) : 0.0;
+    const double K_d = 4.0 * s_d / (v[3] * v[3]);
+    // d(1/a^2)/dn / (1/a^2) = s'/s with s' = -2^(1/n) ln2 / n^2
+    const double dKn_d = -(s_d + 1.0) * 0.69314718055994530942 / (n_d * n_d * s_d);
     const RE I = (RE)v[0], p0 = (RE)v[1], q0 = (RE)v[2], n = (RE)n_d, K = (RE)K_d;
     const RE i3 = (RE)(1.0 / v[3]), dKn = (RE)dKn_d;
-    constexpr int UF = NPX > 5 ? (NPX % 5 == 0 ? 5 : NPX) : NPX;
-#pragma unroll UF
+#pragma unroll 5
     for (int m = 0; m < NPX; ++m) {
-        const int o = first + m * STRIDE;
-        if (NPX * STRIDE != NS * NS && o >= NS * NS) break;
+        const int o = lane + m * 64;
         const RE dp = (RE)(o / NS) - p0, dq = (RE)(o % NS) - q0;
         const RE u = dp * dp + dq * dq;
         const RE gg = (RE)1 + u * K;
         const RE lg = fit_log<RE>(gg);
         const RE e = fit_exp<RE>(-n * lg);
         const RE mo = I * e;
-        const RE r = mo - (RE)(MEM ? dpix[o] : dpix[m]);
+        const RE r = mo - pix[o];
         chi2 += r * r;
         const RE cm = mo * n * fit_rcp<RE>(gg);
         RE J[5];
@@ -525,7 +519,7 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int first, con
         J[1] = cm * (RE)2 * K * dp;
         J[2] = cm * (RE)2 * K * dq;
         J[3] = cm * (RE)2 * K * u * i3;
-        J[4] = -mo * lg - (WN ? cm * u * K * dKn : (RE)0);
+        J[4] = -mo * lg - cm * u * K * dKn;
         int k = 0;
 #pragma unroll
         for (int x = 0; x < 5; ++x) {
@@ -539,26 +533,6 @@ __device__ __forceinline__ void moffat_accumulate(const DT* dpix, int first, con
     for (int k = 0; k < 15; ++k) ne.a[k] = wave_total(a[k]);
 #pragma unroll
     for (int k = 0; k < 5; ++k) ne.g[k] = wave_total(g[k]);
-    if constexpr (WPS > 1) {
-        static_assert(WPS == 4, "cross-wave reduction written for 4 waves");
-        const int wave = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int k = 0; k < 15; ++k) red[wave][k] = (double)ne.a[k];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) red[wave][15 + k] = (double)ne.g[k];
-            red[wave][20] = (double)ne.chi2;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 15; ++k)
-            ne.a[k] = (RE)((red[0][k] + red[1][k]) + (red[2][k] + red[3][k]));
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-            ne.g[k] = (RE)((red[0][15 + k] + red[1][15 + k]) + (red[2][15 + k] + red[3][15 + k]));
-        ne.chi2 = (RE)((red[0][20] + red[1][20]) + (red[2][20] + red[3][20]));
-        __syncthreads();
-    }
 }
 
 // chi2 alone at (I, p0, q0, a, n): the residual pass without the Jacobian (a third of the work)
@@ -729,18 +703,15 @@ __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][
 template <typename RE>
 constexpr int fit_min_waves() { return sizeof(RE) == 4 ? MPSFR_FIT_WAVES : 2; }
 
-template <typename RE, int WPS>
+template <typename RE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fit_min_waves<RE>())))
 k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
-    constexpr int TPS = 64 * WPS;                         // threads per stamp
-    constexpr int NPX = (NS * NS + TPS - 1) / TPS;        // pixels per thread: 25 or 7
-    __shared__ double red[4][24];
+    constexpr int NPX = NS * NS / 64;                     // 25 pixels per lane
+    static_assert(NPX * 64 == NS * NS, "the lane map assumes 1600 pixels");
     const int lane = threadIdx.x & 63;
-    const int first = WPS == 1 ? lane : (int)threadIdx.x;
-    const int st = WPS == 1 ? blockIdx.x * 4 + (threadIdx.x >> 6) : (int)blockIdx.x;
-    if (st >= nstamp) return;   // WPS == 1: the whole wave exits together; WPS == 4: never taken
+    const int st = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (st >= nstamp) return;                             // the whole wave exits together
     const double* src = stamps + (size_t)st * NS * NS;
-    RE dpix[NPX];
     // the stamp in the evaluation type, LDS-resident for the LM evaluations (25 fewer VGPRs than
     // register-resident pixels: with the gradient-only polish this reaches 4 waves per SIMD, so
     // all 3500 stamps of the bench step are resident at once instead of in two rounds)
@@ -750,49 +721,23 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
     int besto = 0;
 #pragma unroll
     for (int m = 0; m < NPX; ++m) {
-        const int o = first + m * TPS;
-        const double d = o < NS * NS ? src[o] : -1.0e300;
-        dpix[m] = o < NS * NS ? (RE)d : (RE)0;
-        if (o < NS * NS) sp[o] = (RE)d;
+        const int o = lane + m * 64;
+        const double d = src[o];
+        sp[o] = (RE)d;
         if (d > best) { best = d; besto = o; }
     }
     // argmax (first maximum in C order, as np.argmax) and the pixel count above half maximum
-    auto arg_reduce = [&]() {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ob = __shfl_xor(best, o, 64);
-            const int oo = __shfl_xor(besto, o, 64);
-            if (ob > best || (ob == best && oo < besto)) { best = ob; besto = oo; }
-        }
-        if constexpr (WPS > 1) {
-            const int wave = threadIdx.x >> 6;
-            if (lane == 0) { red[wave][0] = best; red[wave][1] = (double)besto; }
-            __syncthreads();
-            best = red[0][0];
-            besto = (int)red[0][1];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const double ob = red[w][0];
-                const int oo = (int)red[w][1];
-                if (ob > best || (ob == best && oo < besto)) { best = ob; besto = oo; }
-            }
-            __syncthreads();
-        }
-    };
-    arg_reduce();
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oo = __shfl_xor(besto, o, 64);
+        if (ob > best || (ob == best && oo < besto)) { best = ob; besto = oo; }
+    }
     int cnt = 0;
 #pragma unroll
-    for (int m = 0; m < NPX; ++m)
-        cnt += (first + m * TPS < NS * NS && (double)dpix[m] > 0.5 * best) ? 1 : 0;
+    for (int m = 0; m < NPX; ++m) cnt += (double)sp[lane + m * 64] > 0.5 * best ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if constexpr (WPS > 1) {
-        const int wave = threadIdx.x >> 6;
-        if (lane == 0) red[wave][0] = (double)cnt;
-        __syncthreads();
-        cnt = (int)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0]));
-        __syncthreads();
-    }
     // start values: peak and its position, FWHM from the area above half maximum, n = 2.5.
     // (The least-squares minimum is unique -- SURVEY.md 8(c) -- so the start only sets the
     // iteration count; the oracle starts from fwhm = 4 px, n = 2.)
@@ -800,11 +745,11 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
     fw0 = fmin(fmax(fw0, 1.5), (double)NS);
     double v[5] = {best, (double)(besto / NS), (double)(besto % NS), fw0, 2.5};
     // float evaluation only has to reach the basin of quadratic convergence: the fp64 polish
-    // below finishes the job.  Every thread of the stamp carries the same LM state (the totals of
-    // moffat_accumulate are identical in all of them), so the control flow is uniform.
+    // below finishes the job.  Every lane carries the same LM state (the totals of
+    // moffat_accumulate are wave-uniform), so the control flow is uniform.
     const double tol = sizeof(RE) == 4 ? 1.0e-3 : 1.0e-10;
     NormEqT<RE> ne;
-    moffat_accumulate<RE, true, true, NPX, WPS>(sp, first, v, ne, red);
+    moffat_accumulate<RE>(sp, lane, v, ne);
     double mu = 1.0e-2, nu = 2.0;
     int it = 0, status = 1;
     const int maxit = 200;
@@ -833,7 +778,7 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
         NormEqT<RE> nn;
         double rho = -1.0;
         if (inside) {
-            moffat_accumulate<RE, true, true, NPX, WPS>(sp, first, vn, nn, red);
+            moffat_accumulate<RE>(sp, lane, vn, nn);
             // predicted decrease of chi2: dx^T (mu D dx - g)
             double pred = 0.0;
             const int dg[5] = {0, 5, 9, 12, 14};
@@ -860,7 +805,6 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
         // to move beta by a few 1e-4 on flat-topped stamps.  Polish from the float solution with
         // steps  -A^-1 g,  g the fp64 gradient (moffat_gradient), A the float normal matrix of the
         // last LM iteration: one or two steps suffice.
-        static_assert(WPS == 1, "the polish is written for one wave per stamp");
         NormEq np;
 #pragma unroll
         for (int k = 0; k < 15; ++k) np.a[k] = (double)ne.a[k];
@@ -890,7 +834,6 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
     const double n = v[4];
     const double p2 = exp2(1.0 / n), s2 = p2 - 1.0, sq = sqrt(s2);
     const double al = fabs(v[3]) / (2.0 * sq);
-    static_assert(WPS == 1, "one wave per stamp");
     const double va[5] = {v[0], v[1], v[2], al, n};
     const double chi2 = (double)moffat_chi2<RE>(sp, lane, va);
     if (lane == 0) {
@@ -985,14 +928,14 @@ void launch_conv_fft(hipStream_t s, int ntask, int nl, const void* d_pre, const 
 
 void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit, bool f64) {
     if (nstamp <= 0) return;
-    // One wavefront per stamp (25 pixels per lane).  The kernel also instantiates with a whole
-    // workgroup per stamp (WPS = 4, 6-7 pixels per thread, wave sums meeting in LDS); measured on
-    // MI355X that is 1.8x slower at 3500 stamps (every wave repeats the 5x5 solves, 2 WGs/CU).
+    // One wavefront per stamp, four stamps per workgroup.  (A whole workgroup per stamp with the
+    // wave sums meeting in LDS measured 1.8x slower at 3500 stamps: every wave repeats the 5x5
+    // solves and the iterations serialise on barriers.)
     const dim3 grid((nstamp + 3) / 4);
     if (f64)
-        hipLaunchKernelGGL((k_fit<double, 1>), grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
+        hipLaunchKernelGGL(k_fit<double>, grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
     else
-        hipLaunchKernelGGL((k_fit<float, 1>), grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
+        hipLaunchKernelGGL(k_fit<float>, grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
 }
 
 void launch_stamp_sum(hipStream_t s, int ntask, int nl, const double* d_fin, double* d_sum,
