@@ -119,30 +119,42 @@ def main():
         ctx.set_option('streams', a.streams)
 
     from muse_psfr_amd.distributed import gather_fit_tables, reduce_psf_sum
-    fit = torch.zeros((rows, nl, NFIT), dtype=torch.float64, device=dev)
-    psum = torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev)
+    # Two sets of result buffers: the exchange of step i (on torch's stream) overlaps the
+    # reconstruction of step i+1 (on the library's stream), which writes the other set.
+    NBUF = 2 if world > 1 else 1
+    fits = [torch.zeros((rows, nl, NFIT), dtype=torch.float64, device=dev) for _ in range(NBUF)]
+    psums = [torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev) for _ in range(NBUF)]
+    fit = fits[0]
     three = np.zeros(rows, np.uint8)
     h = (100, 10000)
-    state = {}
+    state = {'i': 0, 'ev': [None] * NBUF}
 
     # The library runs on its own HIP stream; torch orders its collectives against it on the GPU
-    # (no host sync inside a step): torch stream waits for the library stream before the
-    # exchange, the library stream waits for the exchange before it overwrites fit/psum again.
+    # (no host sync inside a step): torch's stream waits for the library stream before the
+    # exchange, and the library stream waits for the exchange that last read a buffer set before
+    # it overwrites that set again.
     lib_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
 
     def step():
-        if world > 1:
-            lib_stream.wait_stream(torch.cuda.current_stream())
+        b = state['i'] % NBUF
+        state['i'] += 1
+        fit_b, psum_b = fits[b], psums[b]
+        if state['ev'][b] is not None:
+            lib_stream.wait_event(state['ev'][b])
         ctx.reconstruct_device(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, None,
-                               None, psum.data_ptr(), fit.data_ptr())
+                               None, psum_b.data_ptr(), fit_b.data_ptr())
         if world > 1:      # FIT_ROWS gather + PSF_MEAN numerator reduce
-            torch.cuda.current_stream().wait_stream(lib_stream)
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(lib_stream)
             if backend == 'nccl':
-                state['fit_all'] = gather_fit_tables(fit, world * rows)
-                reduce_psf_sum(psum, dst=0)
+                state['fit_all'] = gather_fit_tables(fit_b, world * rows)
+                reduce_psf_sum(psum_b, dst=0)
             else:          # CPU rehearsal of the same exchange
-                state['fit_all'] = gather_fit_tables(fit.cpu(), world * rows)
-                state['psum'] = reduce_psf_sum(psum.cpu(), dst=0)
+                state['fit_all'] = gather_fit_tables(fit_b.cpu(), world * rows)
+                state['psum'] = reduce_psf_sum(psum_b.cpu(), dst=0)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            state['ev'][b] = ev
 
     def fence():
         torch.cuda.synchronize()
