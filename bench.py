@@ -11,6 +11,7 @@ the RCCL all-gather of the fit tables and sum-reduce of the partial mean-PSF num
 Rank 0 prints ONE JSON line.  See DESIGN.md "Measurement" for the roofline definition.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -20,6 +21,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 DOMINANT = 'otf_rowfft'      # the kernel the roofline object describes
+PRIME_STEPS = 64             # untimed, before the warm-up steps
 sys.path.insert(0, ROOT)
 
 
@@ -163,6 +165,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the steps are queued from Python: a cyclic-GC pass in the middle of the timed loop (tens of
+    # ms with torch loaded) would starve the GPU, so collection is parked for the measurement
+    gc.collect()
+    gc.disable()
+    # untimed priming before the W warm-up steps: lets the HIP runtime grow its command/signal
+    # pools to the depth the host runs ahead by, and the GPU leave its idle clocks after the CPU
+    # baseline (the first ~50 calls of a process are 5-10 % slower)
+    for _ in range(PRIME_STEPS):
+        step()
+    fence()
     for _ in range(a.warmup):
         step()
     # Timed region: HIP events only around the dominant kernel (roofline.achieved); bracketing
@@ -175,6 +187,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    t_enq = time.perf_counter() - t0      # host time to queue the K steps (no GPU wait inside)
     fence()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
@@ -189,6 +202,7 @@ def main():
     fence()
     prof_all = ctx.profile()
     ctx.set_option('profile', 0)
+    gc.enable()
 
     if rank == 0:
         npsf = world * rows * nl * a.steps
@@ -245,6 +259,8 @@ def main():
                                   'frac_of_8TBps': round(pipe / 8000.0, 4),
                                   'frac_of_6.29TBps': round(pipe / 6290.0, 4)},
             'kernel_ms_per_step': {k: round(v[0] / a.steps, 4) for k, v in prof_all.items() if v[1]},
+            'prime_steps': PRIME_STEPS,
+            'host_enqueue_ms_per_step': round(t_enq / a.steps * 1e3, 4),
             'kernel_ms_per_step_note': 'second, untimed pass of the same steps with every launch '
                                        'bracketed by HIP events',
         }

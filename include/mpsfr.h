@@ -59,10 +59,11 @@ const char* mpsfr_last_error(void);
 
 /* Tunables: "chunk_tasks" (tasks per pipeline pass, 0 = automatic); "fast_exp" (mixed mode only,
  * default 1: hardware exp2 for the OTF); "fft_conv" (mixed mode only, default 1: the two 41x41
- * convolutions through 64-point FFTs instead of the direct form); "streams" (1 or 2, default 2:
- * pipeline lanes -- consecutive chunks of a call alternate between two HIP streams with their own
- * workspaces so that one chunk's tail overlaps the other's body; results are independent of it
- * except for the summation order of psf_sum_out); "profile" (0/1: bracket every kernel launch
+ * convolutions through 64-point FFTs instead of the direct form); "streams" (0 = automatic, the
+ * default, or 1..4 pipeline lanes: consecutive chunks of a call alternate between HIP streams with their own
+ * workspaces so that one chunk's tail overlaps the other's body; automatic = one lane for a call
+ * that fits one chunk, two for multi-chunk calls; results are independent of it except for the
+ * summation order of psf_sum_out); "profile" (0/1: bracket every kernel launch
  * with HIP events on the stream it is launched on -- the event packets cost ~8 % of a step);
  * "profile_only" (-1 = all kernels, else the kernel id of mpsfr_profile_name to time alone). */
 int mpsfr_set_option(mpsfr_ctx* ctx, const char* key, double value);

@@ -174,17 +174,11 @@ struct Tw64 {
 
 __device__ __forceinline__ cx<float> conjf(cx<float> a) { return {a.x, -a.y}; }
 
-// rows ra, rb of the real image `im` (pitch NS, zero beyond NS) -> half spectra in F
-__device__ __forceinline__ void cf_rows_forward(const float* im, int nrow, cx<float> (*F)[CFP],
+// rows ra = 2 slot, rb = ra + 1 of a real image, x[e] = (row ra, row rb) at column t + 8 e (zero
+// beyond the image) -> half spectra in F
+__device__ __forceinline__ void cf_rows_forward(const cx<float>* x, cx<float> (*F)[CFP],
                                                 cx<float>* buf, const Tw64& tw, int slot, int t) {
     const int ra = 2 * slot, rb = ra + 1;
-    cx<float> x[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = t + 8 * e;
-        x[e] = {(c < NS && ra < nrow) ? im[ra * NS + c] : 0.f,
-                (c < NS && rb < nrow) ? im[rb * NS + c] : 0.f};
-    }
     const cx<float>* res = fft_forward_regs<float, CF, true>(x, buf, buf, tw.w, t);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -225,7 +219,6 @@ __device__ __forceinline__ void cf_split0(const cx<float>* res, int kx, cx<float
 __global__ void __launch_bounds__(256)
 k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ khat_tt,
            const cx<float>* __restrict__ khat_muse, double* __restrict__ fin) {
-    __shared__ float img[NS * NS];
     __shared__ cx<float> F[CF][CFP];
     __shared__ cx<float> bufs[CFH][CFB];
     const int l = blockIdx.x, task = blockIdx.y;
@@ -233,8 +226,17 @@ k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ 
     Tw64 tw;
     tw.init(t);
     const float* src = pre + ((size_t)task * nl + l) * NS * NS;
-    for (int e = threadIdx.x; e < NS * NS; e += 256) img[e] = src[e];
     cx<float>* buf = bufs[slot];
+    // The image never sits in LDS: a slot reads its row pair of the input from global memory, and
+    // the rows it produces in the first convolution are exactly the ones it transforms in the
+    // second (taken from its own line buffer).
+    cx<float> x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = t + 8 * e;
+        const bool in = c < NS && slot < NS / 2;
+        x[e] = {in ? src[2 * slot * NS + c] : 0.f, in ? src[(2 * slot + 1) * NS + c] : 0.f};
+    }
     for (int pass = 0; pass < 2; ++pass) {
         const cx<float>* __restrict__ kh = pass == 0 ? khat_tt + (size_t)task * (CFH + 1) * CF
                                                      : khat_muse + (size_t)l * (CFH + 1) * CF;
@@ -246,8 +248,8 @@ k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ 
             khv[e] = kh[slot * CF + t + 8 * e];
             khn[e] = slot == 0 ? kh[CFH * CF + t + 8 * e] : cx<float>{0.f, 0.f};
         }
-        __syncthreads();
-        if (slot < NS / 2) cf_rows_forward(img, NS, F, buf, tw, slot, t);
+        __syncthreads();        // F is free: the inverse rows of the previous pass have read it
+        if (slot < NS / 2) cf_rows_forward(x, F, buf, tw, slot, t);
         __syncthreads();
         {   // columns: forward, multiply by the kernel spectrum, inverse (conjugation trick)
             const cx<float>* res = cf_col_forward(F, NS, buf, tw, slot, t);
@@ -303,14 +305,19 @@ k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ 
                 if (c >= KS / 2 && c < KS / 2 + NS) {
                     const cx<float> v = res[lds_out<CF, 8>(c)];
                     const int i = 2 * slot, j = c - KS / 2;
-                    if (pass == 0) {
-                        img[i * NS + j] = v.x;
-                        img[(i + 1) * NS + j] = -v.y;
-                    } else {
+                    if (pass == 1) {
                         double* out = fin + ((size_t)task * nl + l) * NS * NS;
                         out[i * NS + j] = (double)v.x;
                         out[(i + 1) * NS + j] = (double)(-v.y);
                     }
+                }
+            }
+            if (pass == 0) {    // rows 2 slot, 2 slot + 1 of the intermediate image, columns t + 8 e
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = t + 8 * e;
+                    const cx<float> v = res[lds_out<CF, 8>(c < NS ? c + KS / 2 : 0)];
+                    x[e] = c < NS ? cx<float>{v.x, -v.y} : cx<float>{0.f, 0.f};
                 }
             }
         }

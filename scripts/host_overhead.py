@@ -1,0 +1,31 @@
+"""Host-side cost of queueing reconstruct calls (no GPU wait inside the loop)."""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from muse_psfr_amd import Context, synthetic_rows, grid_pixscale
+n = 100
+see, gl, l0 = synthetic_rows(n)
+lb = np.linspace(465, 930, 35)
+three = np.zeros(n, np.uint8)
+dev = torch.device('cuda:0')
+fit = torch.zeros((n, 35, 16), dtype=torch.float64, device=dev)
+psum = torch.zeros((35, 40, 40), dtype=torch.float64, device=dev)
+for streams in (1, 2):
+    ctx = Context(dim=512, pixscale=grid_pixscale(512))
+    ctx.set_option('streams', streams)
+    for _ in range(3):
+        ctx.reconstruct_device(lb, see, gl, l0, three, (100, 10000), 12.0, 1, None, None,
+                               psum.data_ptr(), fit.data_ptr())
+    ctx.sync()
+    for k in (1, 4, 20, 20, 50, 20):
+        t0 = time.perf_counter()
+        for _ in range(k):
+            ctx.reconstruct_device(lb, see, gl, l0, three, (100, 10000), 12.0, 1, None, None,
+                                   psum.data_ptr(), fit.data_ptr())
+        t1 = time.perf_counter()
+        ctx.sync()
+        t2 = time.perf_counter()
+        print('streams=%d calls=%2d  enqueue %.3f ms/call   total %.3f ms/call' % (
+            streams, k, (t1 - t0) / k * 1e3, (t2 - t0) / k * 1e3))
+    ctx.close()

@@ -229,7 +229,8 @@ def test_pipeline_lanes_and_kernel_variants_agree(api):
     ps = api.grid_pixscale(128)
     three = (np.arange(64) % 5 == 0).astype(np.uint8)
     res = {}
-    for key, opts in (('base', {}), ('one_lane', {'streams': 1}), ('direct_conv', {'fft_conv': 0}),
+    for key, opts in (('base', {'streams': 2}), ('one_lane', {'streams': 1}), ('auto', {}),
+                      ('direct_conv', {'fft_conv': 0}),
                       ('expf', {'fast_exp': 0})):
         ctx = api.Context(dim=128, pixscale=ps, precision='mixed')
         for k, v in opts.items():
@@ -238,6 +239,7 @@ def test_pipeline_lanes_and_kernel_variants_agree(api):
         ctx.close()
     a, b = res['base'], res['one_lane']
     assert np.array_equal(a['psf'], b['psf']) and np.array_equal(a['fit'], b['fit'])
+    assert np.array_equal(res['auto']['fit'], b['fit'])      # one chunk: automatic = one lane
     np.testing.assert_allclose(a['psf_sum'], b['psf_sum'], rtol=1e-13)
     for key in ('direct_conv', 'expf'):
         assert rel_err(res[key]['psf'], a['psf']) < 1e-5, key
