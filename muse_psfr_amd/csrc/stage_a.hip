@@ -121,8 +121,21 @@ __global__ void __launch_bounds__(256) k_tel_otf(int N, const uint64_t* __restri
 template <int N>
 constexpr int psd_rows() { return N / 2 + NAO / 2; }
 
-// x^(-11/6) = cbrt(sqrt(x)) / x^2: ~3x cheaper than the generic fp64 pow, same accuracy class
-__device__ __forceinline__ double pow_m11_6(double x) { return cbrt(sqrt(x)) / (x * x); }
+// x^(-11/6) = (x^(-1/6))^11 for x > 0 in the float range.  y = x^(-1/6) from a hardware
+// log2/exp2 seed (relative error e0 ~ 1e-6) and two Newton steps on y^-6 = x,
+//   y <- y (7 - x y^6) / 6,   e' = -3.5 e^2   (1e-6 -> 1e-11 -> 1e-21),
+// then five multiplies: ~25 fp64 instructions against ~70 for cbrt(sqrt(x)) / x^2 (this function
+// is what K_PSD_ROWFFT spends its VALU time on: every element of every distinct PSD row).
+__device__ __forceinline__ double pow_m11_6(double x) {
+    double y = (double)__builtin_amdgcn_exp2f(-0.16666667f * __builtin_amdgcn_logf((float)x));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double y2 = y * y, y3 = y2 * y;
+        y = y * fma(-(1.0 / 6.0) * x, y3 * y3, 7.0 / 6.0);
+    }
+    const double y2 = y * y, y4 = y2 * y2;
+    return (y4 * y4) * (y2 * y);
+}
 
 template <int N>
 __device__ __forceinline__ double psd_value(int su, int sv, const TaskPar& p, double cfit,
