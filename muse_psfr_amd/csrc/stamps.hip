@@ -489,6 +489,38 @@ __device__ __forceinline__ float fit_rsqrt<float>(float x) { return __builtin_am
 template <>
 __device__ __forceinline__ double fit_rsqrt<double>(double x) { return 1.0 / sqrt(x); }
 
+// Lean fp64 exp / log for the polish (arguments are tame: z <= 0 for the model, x >= 1 for the
+// logarithm), ~18 and ~27 instructions against ~55 and ~65 for the general library routines.
+//   exp: z = k ln2 + r, |r| <= ln2 / 2, degree-13 Taylor in r (remainder 4e-18), v_ldexp_f64.
+//   log: l0 = hardware log2 in fp32 (error ~1e-7), then log x = l0 + log1p(d) with
+//        d = x exp(-l0) - 1 ~ 1e-7, three terms of the series (remainder d^4 / 4).
+__device__ __forceinline__ double lean_exp(double z) {
+    z = fmax(z, -700.0);
+    const double k = rint(z * 1.4426950408889634074);
+    double r = fma(-k, 6.93147180369123816490e-01, z);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+__device__ __forceinline__ double lean_log(double x) {
+    const double l0 = (double)(__builtin_amdgcn_logf((float)x) * 0.69314718f);
+    const double d = fma(x, lean_exp(-l0), -1.0);
+    return l0 + d * fma(d, fma(d, 1.0 / 3.0, -0.5), 1.0);
+}
+
 // Normal equations of the Moffat model at v = (I, p0, q0, w, n), 1/a^2 = 4 (2^(1/n) - 1) / w^2,
 // over the lane's pixels o = lane + 64 m of the stamp `pix` (LDS), summed over the wave.
 // Cross-lane sums run in the evaluation type: the float phase only has to reach the basin of
@@ -503,7 +535,7 @@ __device__ __forceinline__ void moffat_accumulate(const RE* pix, int lane, const
 #pragma unroll
     for (int k = 0; k < 5; ++k) g[k] = (RE)0;
     const double n_d = v[4];
-    const double s_d = exp2(1.0 / n_d) - 1.0;
+    const double s_d = lean_exp(0.69314718055994530942 / n_d) - 1.0;       // 2^(1/n) - 1
     const double K_d = 4.0 * s_d / (v[3] * v[3]);
     // d(1/a^2)/dn / (1/a^2) = s'/s with s' = -2^(1/n) ln2 / n^2
     const double dKn_d = -(s_d + 1.0) * 0.69314718055994530942 / (n_d * n_d * s_d);
@@ -558,38 +590,6 @@ __device__ __forceinline__ RE moffat_chi2(const DT* pix, int lane, const double*
     return wave_total(((c[0] + c[1]) + (c[2] + c[3])) + c[4]);
 }
 
-// Lean fp64 exp / log for the polish (arguments are tame: z <= 0 for the model, x >= 1 for the
-// logarithm), ~18 and ~27 instructions against ~55 and ~65 for the general library routines.
-//   exp: z = k ln2 + r, |r| <= ln2 / 2, degree-13 Taylor in r (remainder 4e-18), v_ldexp_f64.
-//   log: l0 = hardware log2 in fp32 (error ~1e-7), then log x = l0 + log1p(d) with
-//        d = x exp(-l0) - 1 ~ 1e-7, three terms of the series (remainder d^4 / 4).
-__device__ __forceinline__ double lean_exp(double z) {
-    z = fmax(z, -700.0);
-    const double k = rint(z * 1.4426950408889634074);
-    double r = fma(-k, 6.93147180369123816490e-01, z);
-    r = fma(-k, 1.90821492927058770002e-10, r);
-    double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)k);
-}
-__device__ __forceinline__ double lean_log(double x) {
-    const double l0 = (double)(__builtin_amdgcn_logf((float)x) * 0.69314718f);
-    const double d = fma(x, lean_exp(-l0), -1.0);
-    return l0 + d * fma(d, fma(d, 1.0 / 3.0, -0.5), 1.0);
-}
-
 // fp64 gradient J^T r of the Moffat model in (I, p0, q0, w, n) over the stamp in memory, for the
 // polish of the mixed mode: the fixed point of the iteration is where this vanishes, whatever
 // matrix the step is solved with, so the polish keeps the float normal matrix of the last LM
@@ -605,7 +605,7 @@ __device__ __forceinline__ double sgpr(double x) {
 __device__ __forceinline__ void moffat_gradient(const double* __restrict__ src, int lane,
                                                 const double* v, double* gout) {
     const double n = sgpr(v[4]);
-    const double s = exp2(1.0 / n) - 1.0;
+    const double s = lean_exp(0.69314718055994530942 / n) - 1.0;
     const double K = sgpr(4.0 * s / (v[3] * v[3]));
     const double dKn = sgpr(-(s + 1.0) * 0.69314718055994530942 / (n * n * s));
     const double I = sgpr(v[0]), p0 = sgpr(v[1]), q0 = sgpr(v[2]), i3 = sgpr(1.0 / v[3]);
