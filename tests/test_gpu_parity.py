@@ -276,6 +276,38 @@ def test_edge_cases_and_errors(api):
     ctx.close()
 
 
+def test_profile_options(api):
+    """Per-kernel HIP-event timing: all kernels, or only the one named by profile_only; and
+    back-to-back calls without a host wait in between (ring of parameter blobs)."""
+    see, gl, l0 = api.synthetic_rows(6)
+    lb = np.linspace(500, 900, 4)
+    ctx = api.Context(dim=128, pixscale=api.grid_pixscale(128))
+    names = ctx.profile_names()
+    assert 'otf_rowfft' in names and 'fit' in names
+    ctx.set_option('profile', 1)
+    ctx.profile_reset()
+    first = ctx.reconstruct(lb, see, gl, l0, np.zeros(6, np.uint8), H)
+    prof = ctx.profile()
+    assert prof['otf_rowfft'][1] == 1 and prof['fit'][1] == 1 and prof['otf_rowfft'][0] > 0
+    ctx.set_option('profile_only', names.index('otf_rowfft'))
+    ctx.profile_reset()
+    import torch
+    from muse_psfr_amd import NFIT
+    dev = torch.device('cuda:0')
+    fit = torch.zeros((6, 4, NFIT), dtype=torch.float64, device=dev)
+    psum = torch.zeros((4, 40, 40), dtype=torch.float64, device=dev)
+    for _ in range(9):          # more calls in flight than parameter blobs
+        ctx.reconstruct_device(lb, see, gl, l0, np.zeros(6, np.uint8), H, 12.0, 1, None, None,
+                               psum.data_ptr(), fit.data_ptr())
+    ctx.sync()
+    prof = ctx.profile()
+    assert prof['otf_rowfft'][1] == 9 and prof['fit'][1] == 0
+    np.testing.assert_array_equal(fit.cpu().numpy(), first['fit'])
+    with pytest.raises(api.MpsfrError):
+        ctx.set_option('profile_only', 99)
+    ctx.close()
+
+
 def test_float_altitudes_use_wind_12p5(api):
     """psfrec.py:61: np.full_like(h, 12.5) truncates to 12 only for integer altitudes."""
     ps = api.grid_pixscale(256)
