@@ -504,7 +504,8 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     if ((rc = ensure(c, c->aotab, (size_t)2 * ndir * 3 * NAO * NAO * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->samp_p, (size_t)nl * NS * sizeof(int)))) return rc;
     if ((rc = ensure(c, c->samp_a, (size_t)nl * NS * rsize(c)))) return rc;
-    if ((rc = ensure(c, c->G, (size_t)nl * H1 * NS * 2 * rsize(c)))) return rc;
+    // G rows are padded to a multiple of 8 lines (paired-line layout of the fp32 second pass)
+    if ((rc = ensure(c, c->G, (size_t)nl * ((H1 + 7) / 8 * 8) * NS * 2 * rsize(c)))) return rc;
     const bool use_fft_conv = !c->f64 && c->fft_conv;
     const size_t ksz = use_fft_conv ? (size_t)KHAT * 2 * sizeof(float) : (size_t)KS * KS * rsize(c);
     if ((rc = ensure(c, c->ktt, (size_t)ntask * ksz))) return rc;

@@ -16,6 +16,19 @@ namespace {
 // G[l][v][j] = w_v ((1-a_j) W^-(v p_j) + a_j W^-(v (p_j+1))), W = exp(-2 pi i/N), w_v = 1 for
 // v in {0, N/2} else 2: bilinear interpolation folded into the second (column) pass.
 // ------------------------------------------------------------------------------------------
+// Layout of G within one wavelength.  fp64: [v][j].  fp32 (consumed by the MFMA second pass): lines
+// are padded to a multiple of 8 and stored as [v / 8][v % 4][j][(v / 4) % 2], so that the lane
+// that supplies B[k = v % 4][j] to two consecutive k-steps fetches both elements with one 16-byte
+// load (8-byte loads kept the vector memory pipe, not the matrix pipe, busy).
+__host__ __device__ constexpr int g_lines(int N) { return (N / 2 + 1 + 7) / 8 * 8; }
+template <typename R>
+__device__ __forceinline__ size_t g_index(int v, int j) {
+    if constexpr (sizeof(R) == 4)
+        return ((size_t)((v >> 3) * 4 + (v & 3)) * NS + j) * 2 + ((v >> 2) & 1);
+    else
+        return (size_t)v * NS + j;
+}
+
 template <typename R>
 __global__ void __launch_bounds__(256)
 k_gtable(int N, const LamPar* __restrict__ lp, const cx<double>* __restrict__ twg,
@@ -28,16 +41,17 @@ k_gtable(int N, const LamPar* __restrict__ lp, const cx<double>* __restrict__ tw
         samp_p[l * NS + idx] = ((q / NS - npixc / 2) % N + N) % N;
         samp_a[l * NS + idx] = (R)((double)(q % NS) / NS);
     }
-    if (idx >= (N / 2 + 1) * NS) return;
+    const int H1 = N / 2 + 1, HP = g_lines(N);
+    if (idx >= HP * NS) return;
     const int v = idx / NS, j = idx % NS;
     const int q = j * npixc;
     const int p = ((q / NS - npixc / 2) % N + N) % N;
     const double a = (double)(q % NS) / NS;
     const cx<double> w0 = twg[(int)(((long)v * p) % N)];
     const cx<double> w1 = twg[(int)(((long)v * (p + 1)) % N)];
-    const double wv = (v == 0 || v == N / 2) ? 1.0 : 2.0;
+    const double wv = v >= H1 ? 0.0 : (v == 0 || v == N / 2) ? 1.0 : 2.0;   // padding lines: 0
     // conj(W^(v p)) = exp(+2 pi i v p / N)
-    G[((size_t)l * (N / 2 + 1) + v) * NS + j] = {(R)(wv * ((1.0 - a) * w0.x + a * w1.x)),
+    G[(size_t)l * HP * NS + g_index<R>(v, j)] = {(R)(wv * ((1.0 - a) * w0.x + a * w1.x)),
                                                  (R)(-wv * ((1.0 - a) * w0.y + a * w1.y))};
 }
 
@@ -191,7 +205,7 @@ k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
     const bool act = lane < 56;
     const int i0 = TI * (act ? lane >> 3 : 0), j0 = TJ * (lane & 7);
     const cx<R>* Tp = Tq + ((size_t)task * nl + l) * NV * NSH;
-    const cx<R>* Gp = G + (size_t)l * NV * NS;
+    const cx<R>* Gp = G + (size_t)l * g_lines(N) * NS;
     R accP[TI][TJ], accQ[TI][TJ];
 #pragma unroll
     for (int a = 0; a < TI; ++a)
@@ -303,7 +317,6 @@ __global__ void __launch_bounds__(256)
 k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>* __restrict__ G,
             float* __restrict__ pre) {
     constexpr int NV = N / 2 + 1, TPG = 3, MT = 4, NT = 3, NCOL = NT * 16;
-    constexpr int KST = (NV + 3) / 4;        // k-steps (four lines each)
     static_assert(TPG * NSH <= MT * 16 && NS <= NCOL, "tile map");
     __shared__ float red[2][MT * 16][NCOL];  // P, Q
     __shared__ double part[4][TPG];
@@ -316,11 +329,15 @@ k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>
     // rows without a task read the group's first task (valid memory); they are never used
     const cx<float>* ap = Tq + ((size_t)(aok ? tg * TPG + tl : tg * TPG) * nl + l) * NV * NSH +
                           (aok ? i : 0);
-    const cx<float>* bp[NT];
+    // B: G in the paired-line layout of g_index<float>: one 16-byte load carries this lane's
+    // element for k-steps 2 s and 2 s + 1 (lines 8 s + lk and 8 s + 4 + lk)
+    constexpr int NG = g_lines(N) / 8;                   // double steps
+    const f32x4* bp[NT];
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) {
         const int j = 16 * ct + lr;
-        bp[ct] = G + (size_t)l * NV * NS + (j < NS ? j : 0);     // columns 40..47 are dropped
+        bp[ct] = reinterpret_cast<const f32x4*>(G) + (size_t)l * NG * 4 * NS + (size_t)lk * NS +
+                 (j < NS ? j : 0);                       // columns 40..47 are dropped
     }
     f32x4 accP[NT], accQ[NT];
 #pragma unroll
@@ -328,36 +345,41 @@ k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>
         accP[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         accQ[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    constexpr int PF = 4;                        // k-steps in flight
-    auto load = [&](int ks, cx<float>& a, cx<float>* b) {
-        const int v = 4 * ks + lk;
-        const bool vok = v < NV;                 // k padding: A = 0
-        const int vc = vok ? v : NV - 1;
-        const cx<float> t = ap[(size_t)vc * NSH];
-        a = vok ? t : cx<float>{0.f, 0.f};
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) b[ct] = bp[ct][(size_t)vc * NS];
+    struct Ops {
+        cx<float> a0, a1;       // T[8 s + lk][i], T[8 s + 4 + lk][i]
+        f32x4 b[NT];
     };
-    // Branch-free ring: steps past the last line load line NV-1 again with A = 0 (load() clamps),
-    // so the loop simply runs to the next multiple of PF -- any branch in here makes the compiler
-    // drain the loads (s_waitcnt vmcnt(0)) at every step.
-    cx<float> ra[PF], rb[PF][NT];
+    auto load = [&](int s, Ops& o) {
+        const int sc = s < NG ? s : NG - 1;              // past the end: any valid address
+        const int v0 = 8 * sc + lk, v1 = v0 + 4;
+        const cx<float> t0 = ap[(size_t)(v0 < NV ? v0 : NV - 1) * NSH];
+        const cx<float> t1 = ap[(size_t)(v1 < NV ? v1 : NV - 1) * NSH];
+        o.a0 = (s < NG && v0 < NV) ? t0 : cx<float>{0.f, 0.f};     // line padding: A = 0
+        o.a1 = (s < NG && v1 < NV) ? t1 : cx<float>{0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < PF; ++k) load(k, ra[k], rb[k]);
-    for (int ks = 0; ks < KST; ks += PF) {
+        for (int ct = 0; ct < NT; ++ct) o.b[ct] = bp[ct][(size_t)sc * 4 * NS];
+    };
+    auto mma = [&](const Ops& o) {
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const cx<float> a = ra[k];
-            cx<float> b[NT];
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct) b[ct] = rb[k][ct];
-            load(ks + k + PF, ra[k], rb[k]);
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct) {
-                accP[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[ct].x, accP[ct], 0, 0, 0);
-                accQ[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[ct].y, accQ[ct], 0, 0, 0);
-            }
+        for (int ct = 0; ct < NT; ++ct) {
+            accP[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0.x, o.b[ct][0], accP[ct], 0, 0, 0);
+            accQ[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0.y, o.b[ct][1], accQ[ct], 0, 0, 0);
         }
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            accP[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1.x, o.b[ct][2], accP[ct], 0, 0, 0);
+            accQ[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1.y, o.b[ct][3], accQ[ct], 0, 0, 0);
+        }
+    };
+    // two operand sets, roles swapped inside the body (no register rotation at the back edge);
+    // the loop is branch-free: double steps past the end load valid memory with A = 0
+    Ops oa, ob;
+    load(0, oa);
+    for (int s = 0; s < NG; s += 2) {
+        load(s + 1, ob);
+        mma(oa);
+        load(s + 2, oa);
+        mma(ob);
     }
     // C layout of the 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + reg
 #pragma unroll
@@ -412,7 +434,7 @@ k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>
 
 void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void* d_tw64,
                    int* d_samp_p, void* d_samp_a, void* d_G, bool f64) {
-    dim3 grid(((N / 2 + 1) * NS + 255) / 256, nl);
+    dim3 grid((g_lines(N) * NS + 255) / 256, nl);
     if (f64)
         hipLaunchKernelGGL(k_gtable<double>, grid, dim3(256), 0, s, N, d_lp,
                            (const cx<double>*)d_tw64, d_samp_p, (double*)d_samp_a,
