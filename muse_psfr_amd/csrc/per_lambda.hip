@@ -111,9 +111,15 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
     }
     cx<R>* a = bufA + slot * NPAD;
     cx<R>* b = bufB + slot * NPAD;     // only used when a slot spans two wavefronts
+    // Single direction, hardware exp2: the telescope OTF goes into the exponent,
+    // tel * 2^(c d) = 2^(c d + log2 tel)  (tel = 0 -> 2^-inf = 0), one fma + v_exp_f32 per value.
+    constexpr bool FOLD = FASTEXP && ND == 1 && sizeof(R) == 4;
     R tel[EPT];
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) tel[e] = telT[(size_t)vv * N + t + e * TPR];
+    for (int e = 0; e < EPT; ++e) {
+        tel[e] = telT[(size_t)vv * N + t + e * TPR];
+        if constexpr (FOLD) tel[e] = __builtin_amdgcn_logf(tel[e]);      // log2
+    }
     const R* dline = D0t + ((size_t)task * ndir * (N / 2 + 1) + vv) * N;
     const size_t dstride = (size_t)(N / 2 + 1) * N;
     R dreg[ND == 1 ? EPT : 1];
@@ -130,7 +136,11 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             R ra = (R)0, rb = (R)0;
-            if constexpr (ND == 1) {
+            if constexpr (FOLD) {
+                x[e] = {exp_sel<R, true>(fmaf(ca, dreg[e], tel[e])),
+                        two ? exp_sel<R, true>(fmaf(cb, dreg[e], tel[e])) : (R)0};
+                continue;
+            } else if constexpr (ND == 1) {
                 ra = exp_sel<R, FASTEXP>(ca * dreg[e]);
                 rb = exp_sel<R, FASTEXP>(cb * dreg[e]);
             } else {
