@@ -160,14 +160,50 @@ constexpr int CFH = CF / 2;       // 32
 constexpr int CFP = 36;           // pitch of the half-spectrum frame (bank-conflict free)
 constexpr int CFB = CF + CF / 8;  // padded line buffer
 
+// exp(-2 pi i m / 64), m = 0..63: the pass twiddles of the 64-point lines come from this table
+// (seven sincospif per thread at kernel start were ~15 % of the kernel's VALU work)
+__constant__ float2 kTw64[64] = {
+    {1.000000000e+00f, 0.000000000e+00f}, {9.951847267e-01f, -9.801714033e-02f},
+    {9.807852804e-01f, -1.950903220e-01f}, {9.569403357e-01f, -2.902846773e-01f},
+    {9.238795325e-01f, -3.826834324e-01f}, {8.819212643e-01f, -4.713967368e-01f},
+    {8.314696123e-01f, -5.555702330e-01f}, {7.730104534e-01f, -6.343932842e-01f},
+    {7.071067812e-01f, -7.071067812e-01f}, {6.343932842e-01f, -7.730104534e-01f},
+    {5.555702330e-01f, -8.314696123e-01f}, {4.713967368e-01f, -8.819212643e-01f},
+    {3.826834324e-01f, -9.238795325e-01f}, {2.902846773e-01f, -9.569403357e-01f},
+    {1.950903220e-01f, -9.807852804e-01f}, {9.801714033e-02f, -9.951847267e-01f},
+    {6.123233996e-17f, -1.000000000e+00f}, {-9.801714033e-02f, -9.951847267e-01f},
+    {-1.950903220e-01f, -9.807852804e-01f}, {-2.902846773e-01f, -9.569403357e-01f},
+    {-3.826834324e-01f, -9.238795325e-01f}, {-4.713967368e-01f, -8.819212643e-01f},
+    {-5.555702330e-01f, -8.314696123e-01f}, {-6.343932842e-01f, -7.730104534e-01f},
+    {-7.071067812e-01f, -7.071067812e-01f}, {-7.730104534e-01f, -6.343932842e-01f},
+    {-8.314696123e-01f, -5.555702330e-01f}, {-8.819212643e-01f, -4.713967368e-01f},
+    {-9.238795325e-01f, -3.826834324e-01f}, {-9.569403357e-01f, -2.902846773e-01f},
+    {-9.807852804e-01f, -1.950903220e-01f}, {-9.951847267e-01f, -9.801714033e-02f},
+    {-1.000000000e+00f, -1.224646799e-16f}, {-9.951847267e-01f, 9.801714033e-02f},
+    {-9.807852804e-01f, 1.950903220e-01f}, {-9.569403357e-01f, 2.902846773e-01f},
+    {-9.238795325e-01f, 3.826834324e-01f}, {-8.819212643e-01f, 4.713967368e-01f},
+    {-8.314696123e-01f, 5.555702330e-01f}, {-7.730104534e-01f, 6.343932842e-01f},
+    {-7.071067812e-01f, 7.071067812e-01f}, {-6.343932842e-01f, 7.730104534e-01f},
+    {-5.555702330e-01f, 8.314696123e-01f}, {-4.713967368e-01f, 8.819212643e-01f},
+    {-3.826834324e-01f, 9.238795325e-01f}, {-2.902846773e-01f, 9.569403357e-01f},
+    {-1.950903220e-01f, 9.807852804e-01f}, {-9.801714033e-02f, 9.951847267e-01f},
+    {-1.836970199e-16f, 1.000000000e+00f}, {9.801714033e-02f, 9.951847267e-01f},
+    {1.950903220e-01f, 9.807852804e-01f}, {2.902846773e-01f, 9.569403357e-01f},
+    {3.826834324e-01f, 9.238795325e-01f}, {4.713967368e-01f, 8.819212643e-01f},
+    {5.555702330e-01f, 8.314696123e-01f}, {6.343932842e-01f, 7.730104534e-01f},
+    {7.071067812e-01f, 7.071067812e-01f}, {7.730104534e-01f, 6.343932842e-01f},
+    {8.314696123e-01f, 5.555702330e-01f}, {8.819212643e-01f, 4.713967368e-01f},
+    {9.238795325e-01f, 3.826834324e-01f}, {9.569403357e-01f, 2.902846773e-01f},
+    {9.807852804e-01f, 1.950903220e-01f}, {9.951847267e-01f, 9.801714033e-02f},
+};
+
 struct Tw64 {
     cx<float> w[7];
     __device__ __forceinline__ void init(int t) {
 #pragma unroll
         for (int q = 1; q < 8; ++q) {
-            float sn, cs;
-            sincospif(-2.0f * (float)(q * t) / 64.0f, &sn, &cs);
-            w[q - 1] = {cs, sn};
+            const float2 v = kTw64[(q * t) & 63];
+            w[q - 1] = {v.x, v.y};
         }
     }
 };
