@@ -219,6 +219,17 @@ def main():
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         bytes_per_psf = ndir * dim * dim * (3 * p + (5 * 8 + p) / nl)
         pipe = (npsf / dt) * bytes_per_psf / 1e9
+        # what actually bounds the dominant kernel (PMC passes committed under profiles/)
+        measured_bound = None
+        ufile = os.path.join(ROOT, 'profiles', 'r01_kernel_util.json')
+        if os.path.exists(ufile) and dim == 512 and a.precision == 'mixed':
+            u = json.load(open(ufile)).get('k_' + DOMINANT)
+            if u:
+                measured_bound = {'kernel': DOMINANT, 'lds_array_busy': u['lds_array_busy'],
+                                  'valu_issue': u['valu_issue'],
+                                  'lds_conflict_share': u['lds_conflict_share'],
+                                  'hbm_GBps': u['hbm_GBps'],
+                                  'source': 'profiles/r01_kernel_util.json (scripts/prof_table.sh)'}
         # HBM traffic of the dominant kernel from the committed PMC pass (profiles/), if it was
         # taken on this workload: (FETCH_SIZE + WRITE_SIZE) KiB per launch, no width correction
         traffic = None
@@ -254,6 +265,7 @@ def main():
                                  'never materialises them (traffic = measured FETCH_SIZE + WRITE_SIZE), '
                                  'so frac > 1; it is LDS-store/VALU bound (profiles/r01_pmc_summary.txt, '
                                  'DESIGN.md section 5)'},
+            'measured_bound': measured_bound,
             'roofline_pipeline': {'bytes_per_psf': bytes_per_psf,
                                   'achieved_GBps': round(pipe, 1),
                                   'frac_of_8TBps': round(pipe / 8000.0, 4),

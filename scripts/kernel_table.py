@@ -1,6 +1,7 @@
 """Per-kernel resource table from scripts/prof_table.sh output (single lane, kernels do not overlap).
 usage: python scripts/kernel_table.py gpurun_out/prof_table > profiles/rNN_kernel_table.md"""
 import csv
+import json
 import re
 import sys
 
@@ -30,6 +31,7 @@ print('VALU = SQ_INSTS_VALU x 2 issue cycles / (1024 SIMDs x kernel cycles at 2.
       'HBM = (FETCH_SIZE + WRITE_SIZE) / duration, uncorrected.\n')
 print('| kernel | avg us | VALU issue | LDS array busy | of which bank conflicts | HBM GB/s |')
 print('|---|---|---|---|---|---|')
+util = {}
 for k in ('k_otf_rowfft', 'k_fit', 'k_conv_fft', 'k_colpass_m', 'k_psd_rowfft', 'k_colfft_dphi',
           'k_khat', 'k_stamp_sum', 'k_dc_sum'):
     if k not in dur:
@@ -42,3 +44,7 @@ for k in ('k_otf_rowfft', 'k_fit', 'k_conv_fft', 'k_colpass_m', 'k_psd_rowfft', 
     hbm = (get(k, 'FETCH_SIZE') + get(k, 'WRITE_SIZE')) * 1024 / t / 1e9
     print('| `%s` | %.1f | %.0f %% | %.0f %% | %.0f %% | %.0f |' % (k, t * 1e6, valu * 100, lds * 100,
                                                                  conf * 100, hbm))
+    util[k] = {'avg_us': round(t * 1e6, 1), 'valu_issue': round(valu, 3), 'lds_array_busy': round(lds, 3),
+               'lds_conflict_share': round(conf, 3), 'hbm_GBps': round(hbm, 1)}
+if len(sys.argv) > 2:
+    json.dump(util, open(sys.argv[2], 'w'), indent=1)
