@@ -10,3 +10,5 @@ it = r['fit'][:, :, 7]
 print('iterations: min %d median %d mean %.1f max %d' % (it.min(), np.median(it), it.mean(), it.max()))
 print(np.bincount(it.astype(int).ravel()))
 print('beta range', r['fit'][:, :, 4].min(), r['fit'][:, :, 4].max(), 'fwhm px', r['fit'][:, :, 5].min(), r['fit'][:, :, 5].max())
+b = r['fit'][:, :, 4]
+print('beta percentiles 5/25/50/75/95:', np.percentile(b, [5, 25, 50, 75, 95]))
