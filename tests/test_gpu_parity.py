@@ -308,6 +308,28 @@ def test_profile_options(api):
     ctx.close()
 
 
+def test_context_pool_pipelines_independent_batches(api):
+    """Two contexts fed in turn: same results as one context, batch by batch."""
+    import torch
+    from muse_psfr_amd import NFIT
+    lb = np.linspace(480, 920, 5)
+    dev = torch.device('cuda:0')
+    ps = api.grid_pixscale(128)
+    batches = [api.synthetic_rows(7, seed=100 + k) for k in range(6)]
+    one = api.Context(dim=128, pixscale=ps)
+    ref = [one.reconstruct(lb, *b, np.zeros(7, np.uint8), H)['fit'] for b in batches]
+    one.close()
+    with api.ContextPool(2, dim=128, pixscale=ps) as pool:
+        fits = [torch.zeros((7, 5, NFIT), dtype=torch.float64, device=dev) for _ in batches]
+        psum = [torch.zeros((5, 40, 40), dtype=torch.float64, device=dev) for _ in batches]
+        for k, b in enumerate(batches):
+            pool.next().reconstruct_device(lb, *b, np.zeros(7, np.uint8), H, 12.0, 1, None, None,
+                                           psum[k].data_ptr(), fits[k].data_ptr())
+        pool.sync()
+        for k in range(len(batches)):
+            np.testing.assert_array_equal(fits[k].cpu().numpy(), ref[k])
+
+
 def test_float_altitudes_use_wind_12p5(api):
     """psfrec.py:61: np.full_like(h, 12.5) truncates to 12 only for integer altitudes."""
     ps = api.grid_pixscale(256)
