@@ -110,7 +110,7 @@ int mpsfr_sync(mpsfr_ctx* ctx);
 void* mpsfr_stream(mpsfr_ctx* ctx);
 
 /* Copy an intermediate of the most recent mpsfr_reconstruct pipeline pass (last chunk) to the
- * host as float64 (parity tests, tests/test_stages_gpu.py).  `what`:
+ * host as float64 (parity tests, tests/test_gpu_parity.py).  `what`:
  *   "ao_tables"  [2 geometries][ndir][3 (T0,T1,noise)][80][80]   (psfrec.py:531-613)
  *   "tel"        [dim/2+1][dim]  telescope OTF, transposed half plane (psfrec.py:784-790)
  *   "dphi0"      [chunk tasks][ndir][dim/2+1][dim] structure function / lambda-factor,
@@ -127,6 +127,10 @@ int mpsfr_profile_reset(mpsfr_ctx* ctx);
 
 /* Library/ABI version (major*100 + minor). */
 int mpsfr_version(void);
+
+/* Hash of the sources, headers and compiler flags this binary was built from (written by
+ * muse_psfr_amd/_build.py; "unstamped" for a hand build).  bench.py records it. */
+const char* mpsfr_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,7 @@
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
 git-ignored but travels with the tree to the GPU box.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -24,12 +25,26 @@ def _hipcc():
     return exe
 
 
+STAMP = LIB + '.stamp'
+
+
+def source_hash():
+    """sha256 over the sources, headers and compiler flags: the identity of a build.  It is
+    written beside the .so (libmpsfr.so.stamp) and compiled into it (mpsfr_build_id)."""
+    h = hashlib.sha256()
+    h.update(' '.join(FLAGS).encode())
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(f.encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
-    if not os.path.exists(LIB):
+    """A shipped .so is only reused if it was built from exactly these sources and flags."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build_library(force=False, verbose=True):
@@ -37,13 +52,15 @@ def build_library(force=False, verbose=True):
     if not force and not is_stale():
         return LIB
     hipcc = _hipcc()
+    build_id = source_hash()
     objs = []
     bdir = os.path.join(HERE, 'build')
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for src in SOURCES:          # the translation units compile in parallel
         obj = os.path.join(bdir, os.path.splitext(src)[0] + '.o')
-        cmd = [hipcc] + FLAGS + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + ['-DMPSFR_BUILD_ID="%s"' % build_id, '-x', 'hip', '-c',
+                                 os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
@@ -55,6 +72,8 @@ def build_library(force=False, verbose=True):
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, 'w') as fh:
+        fh.write(build_id + '\n')
     return LIB
 
 

@@ -81,6 +81,8 @@ def load():
     lib.mpsfr_profile_reset.restype = C.c_int
     lib.mpsfr_version.argtypes = []
     lib.mpsfr_version.restype = C.c_int
+    lib.mpsfr_build_id.argtypes = []
+    lib.mpsfr_build_id.restype = C.c_char_p
     _lib = lib
     return lib
 
@@ -88,7 +90,7 @@ def load():
 EXPORTS = ['mpsfr_create', 'mpsfr_destroy', 'mpsfr_last_error', 'mpsfr_set_option',
            'mpsfr_reconstruct', 'mpsfr_fit_stamps', 'mpsfr_sync', 'mpsfr_stream', 'mpsfr_debug_fetch',
            'mpsfr_profile_count', 'mpsfr_profile_name', 'mpsfr_profile_get',
-           'mpsfr_profile_reset', 'mpsfr_version']
+           'mpsfr_profile_reset', 'mpsfr_version', 'mpsfr_build_id']
 
 
 def _check(rc):

@@ -139,10 +139,12 @@ hipEvent_t get_event(mpsfr_ctx* c) {
         c->pool.pop_back();
         return e;
     }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
+
+int resolve_profile(mpsfr_ctx* c);
 
 struct ProfScope {
     mpsfr_ctx* c;
@@ -156,13 +158,21 @@ struct ProfScope {
         if (on) {
             a = get_event(c);
             b = get_event(c);
-            (void)hipEventRecord(a, st);
+            if (!a || !b) {          // out of events: this launch goes untimed
+                if (a) c->pool.push_back(a);
+                if (b) c->pool.push_back(b);
+                on = false;
+            } else {
+                (void)hipEventRecord(a, st);
+            }
         }
     }
     ~ProfScope() {
         if (on) {
             (void)hipEventRecord(b, st);
             c->pending.push_back({id, a, b});
+            // a caller that never reads the profile must not grow the event list without bound
+            if (c->pending.size() >= 8192) (void)resolve_profile(c);
         }
     }
 };
@@ -280,7 +290,12 @@ extern "C" {
 
 const char* mpsfr_last_error(void) { return g_err.c_str(); }
 
-int mpsfr_version(void) { return 100; }
+int mpsfr_version(void) { return 101; }
+
+#ifndef MPSFR_BUILD_ID
+#define MPSFR_BUILD_ID "unstamped"
+#endif
+const char* mpsfr_build_id(void) { return MPSFR_BUILD_ID; }
 
 int mpsfr_create(mpsfr_ctx** out, int device_id, int dim, int dimpsf, double pixscale,
                  int precision) {
@@ -573,7 +588,10 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
             TC = (ntask + NL - 1) / NL;     // one chunk per lane, >= 1024 stamps each
     }
     if (TC > ntask) TC = ntask;
-    if (ntask <= TC) NL = 1;
+    // never more lanes than chunks: a lane without a chunk would leave its partial stamp sum
+    // unwritten, and the final sum over lanes would read stale memory
+    const int nchunks = (ntask + TC - 1) / TC;
+    if (NL > nchunks) NL = nchunks;
     const size_t per_stamp = (size_t)NS * NS;
     const bool dev_out = on_device != 0;
     for (int k = 0; k < NL; ++k) {

@@ -59,3 +59,75 @@ def test_two_rank_sharding_matches_single_process(ntask):
     fit1, psum1 = _fake_local(see)(0, ntask)
     np.testing.assert_array_equal(fit_all, fit1.numpy())
     np.testing.assert_allclose(mean, psum1.numpy() / ntask, rtol=1e-14)
+
+
+def _worker_reuse(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from muse_psfr_amd.distributed import ShardExchange, shard_bounds
+    ntask = 5                                   # ragged: 3 + 2
+    ex = ShardExchange(ntask, 3, 16, torch.device('cpu'))
+    a, b = shard_bounds(ntask, world)[rank]
+    outs = []
+    ptrs = set()
+    for step in range(3):                       # the same buffers serve every step
+        fit = torch.full((b - a, 3, 16), float(10 * step + rank), dtype=torch.float64)
+        g = ex.gather(fit)
+        ptrs.add(g.data_ptr())
+        psum = torch.full((3, 40, 40), float(step + 1), dtype=torch.float64)
+        ex.reduce(psum, dst=0)
+        outs.append((g.clone().numpy(), psum.numpy().copy()))
+    if rank == 0:
+        q.put((outs, len(ptrs)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_buffers_are_allocated_once():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_reuse, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs, nptr = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert nptr == 1
+    for step, (g, psum) in enumerate(outs):
+        assert g.shape == (5, 3, 16)
+        assert np.all(g[:3] == 10 * step) and np.all(g[3:] == 10 * step + 1)
+        assert np.all(psum == 2 * (step + 1))
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher environment starts N ranks through
+    torch.distributed.run on 127.0.0.1 and passes its arguments on."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    seen = {}
+
+    class R:
+        returncode = 0
+
+    def fake_run(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return R()
+    monkeypatch.setattr(bench.subprocess, 'run', fake_run)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '7'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-4:] == ['--gpus', '4', '--steps', '7'] and cmd[-5].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'

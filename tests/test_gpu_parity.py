@@ -247,6 +247,33 @@ def test_pipeline_lanes_and_kernel_variants_agree(api):
         api.Context(dim=128, pixscale=ps).set_option('streams', 5)
 
 
+@pytest.mark.parametrize('streams', [3, 4])
+@pytest.mark.parametrize('ntask,chunk', [(10, 5), (12, 5), (7, 7)])
+def test_more_lanes_than_chunks(api, streams, ntask, chunk):
+    """A call with fewer chunks than pipeline lanes (2 or 3 chunks, or 1, on 3-4 lanes): lanes
+    without a chunk must not contribute to the stamp sum.  With at most one chunk per lane the sum
+    over lanes adds the chunk sums in the same order as a single lane does: bit for bit."""
+    see, gl, l0 = api.synthetic_rows(ntask)
+    lb = np.linspace(465, 930, 4)
+    ps = api.grid_pixscale(128)
+    three = (np.arange(ntask) % 4 == 1).astype(np.uint8)
+    out = {}
+    for key, st in (('one', 1), ('many', streams)):
+        ctx = api.Context(dim=128, pixscale=ps, precision='mixed')
+        ctx.set_option('streams', st)
+        ctx.set_option('chunk_tasks', chunk)
+        # dirty the per-lane partial sums with a call that uses every lane
+        if st > 1:
+            ctx.reconstruct(lb, *api.synthetic_rows(4 * st, seed=9), np.zeros(4 * st, np.uint8), H)
+            ctx.set_option('chunk_tasks', chunk)
+        out[key] = ctx.reconstruct(lb, see, gl, l0, three, H)
+        ctx.close()
+    a, b = out['one'], out['many']
+    assert np.array_equal(a['psf'], b['psf']) and np.array_equal(a['fit'], b['fit'])
+    np.testing.assert_array_equal(a['psf_sum'], b['psf_sum'])
+    np.testing.assert_allclose(b['psf_sum'], b['psf'].sum(axis=0), rtol=1e-13)
+
+
 def test_edge_cases_and_errors(api):
     from muse_psfr_amd import MpsfrError
     ps = api.grid_pixscale(128)
