@@ -119,8 +119,9 @@ def main():
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--fast-exp', type=int, default=1)
     ap.add_argument('--streams', type=int, default=0, help='pipeline lanes (0: library default)')
-    ap.add_argument('--inflight', type=int, default=2,
-                    help='steps in flight: contexts (stream + workspaces) fed in turn')
+    ap.add_argument('--inflight', type=int, default=1,
+                    help='contexts fed in turn (each context already pipelines consecutive calls '
+                         'over its two internal lanes)')
     ap.add_argument('--cpu-rows', type=int, default=-1,
                     help='rows of the CPU-baseline sample (-1: automatic, 0: skip)')
     ap.add_argument('--f64-steps', type=int, default=-1,
@@ -197,29 +198,33 @@ def main():
             if a.streams:
                 c.set_option('streams', a.streams)
             ctxs.append(c)
-        fits = [torch.zeros((rows, nl, NFIT), dtype=torch.float64, device=dev) for _ in range(nctx)]
-        psums = [torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev) for _ in range(nctx)]
-        # the exchange buffers are allocated once (one set per context)
+        # Two sets of result buffers per context: consecutive calls of one context overlap on its
+        # internal lanes, and calls that share an output buffer would be serialised.
+        nset = 2 * nctx
+        fits = [torch.zeros((rows, nl, NFIT), dtype=torch.float64, device=dev) for _ in range(nset)]
+        psums = [torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev) for _ in range(nset)]
+        # the exchange buffers are allocated once (one set per result-buffer set)
         xdev = dev if backend == 'nccl' else torch.device('cpu')
-        exch = [ShardExchange(world * rows, nl, NFIT, xdev) for _ in range(nctx)] if world > 1 else None
-        state = {'i': 0, 'ev': [None] * nctx}
-        # Each context runs on its own HIP stream; torch orders its collectives against it on the
-        # GPU (no host sync inside a step): torch's stream waits for the context's stream before
-        # the exchange, and that stream waits for the exchange that last read its buffer set
-        # before the set is overwritten.
+        exch = [ShardExchange(world * rows, nl, NFIT, xdev) for _ in range(nset)] if world > 1 else None
+        state = {'i': 0, 'ev': [None] * nset}
+        # torch orders its collectives against the library on the GPU (no host sync inside a
+        # step): torch's stream waits for the context's stream (which is ordered after every call
+        # made so far) before the exchange, and the call that next overwrites a buffer set waits
+        # for the exchange that last read it (mpsfr_wait_event).
         lib_streams = [torch.cuda.ExternalStream(c.stream_handle(), device=dev) for c in ctxs]
 
         def step():
-            b = state['i'] % nctx
+            k = state['i'] % nctx
+            b = state['i'] % nset
             state['i'] += 1
             fit_b, psum_b = fits[b], psums[b]
             if state['ev'][b] is not None:
-                lib_streams[b].wait_event(state['ev'][b])
-            ctxs[b].reconstruct_device(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin,
+                ctxs[k].wait_event(state['ev'][b].cuda_event)
+            ctxs[k].reconstruct_device(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin,
                                        None, None, psum_b.data_ptr(), fit_b.data_ptr())
             if world > 1:      # FIT_ROWS gather + PSF_MEAN numerator reduce
                 cur = torch.cuda.current_stream()
-                cur.wait_stream(lib_streams[b])
+                cur.wait_stream(lib_streams[k])
                 if backend == 'nccl':
                     state['fit_all'] = exch[b].gather(fit_b)
                     exch[b].reduce(psum_b, dst=0)
@@ -240,10 +245,15 @@ def main():
 
         def timed(nsteps):
             fence()
+            for c in ctxs:
+                c.profile_reset()
             t0 = time.perf_counter()
+            c0 = time.thread_time()
             for _ in range(nsteps):
                 step()
-            t_enq = time.perf_counter() - t0     # host time to queue the steps (no GPU wait)
+            # host cost of queueing the steps: CPU time of this thread (the wall time of the loop
+            # is the GPU's pace once the command queue is full)
+            t_enq = time.thread_time() - c0
             fence()
             dt = time.perf_counter() - t0
             tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
@@ -262,8 +272,11 @@ def main():
         def close():
             for c in ctxs:
                 c.close()
+        def host_lib():
+            tot = [c.host_time() for c in ctxs]
+            return sum(t[0] for t in tot) / max(1, sum(t[1] for t in tot))
         return dict(ctxs=ctxs, step=step, fence=fence, timed=timed, profile_sum=profile_sum,
-                    fits=fits, close=close)
+                    fits=fits, close=close, host_lib=host_lib)
 
     def parity_block(fitg, n):
         return {'rows_checked': n,
@@ -291,9 +304,9 @@ def main():
     for c in ctxs:
         c.set_option('profile_only', c.profile_names().index(DOMINANT))
         c.set_option('profile', 1)
-        c.profile_reset()
     dt, t_enq = R['timed'](a.steps)
     prof = R['profile_sum']()
+    host_lib_s = R['host_lib']()
     nprof = min(a.steps, 40) if a.profile_steps < 0 else a.profile_steps
     prof_all = {}
     if nprof > 0:
@@ -402,8 +415,11 @@ def main():
             'fit_iterations': {'mean': round(float(fitg[:, :, 7].mean()), 2),
                                'max': int(fitg[:, :, 7].max())},
             'prime_steps': PRIME_STEPS,
-            'inflight_steps': max(1, a.inflight),
+            'contexts': max(1, a.inflight), 'lanes_per_context': a.streams or 2,
             'host_enqueue_ms_per_step': round(t_enq / a.steps * 1e3, 4),
+            'host_enqueue_note': 'CPU time of the Python thread per step (ctypes call + library); '
+                                 'host_library_ms_per_call = inside mpsfr_reconstruct (wall)',
+            'host_library_ms_per_call': round(host_lib_s * 1e3, 4),
             'build_id': load_lib().mpsfr_build_id().decode(),
         }
         if f64 is not None:

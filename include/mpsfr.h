@@ -7,8 +7,19 @@
  * Conventions: plain pointers and sizes only; all arrays C-contiguous; every function returns 0
  * on success or a negative error code (MPSFR_E_*), with a thread-local message available from
  * mpsfr_last_error(); nothing is allocated across the ABI; no exceptions cross it.  A context
- * owns one GPU (one process per GPU, one context per process is the intended use), one HIP
- * stream and all device workspaces; it is not re-entrant.
+ * owns one GPU (one process per GPU, one context per process is the intended use), its HIP
+ * streams and all device workspaces; it is not re-entrant.
+ *
+ * Asynchronous calls (on_device = 1) are pipelined inside the context: consecutive calls run on
+ * alternating internal streams ("lanes") with their own workspaces, so the transforms of one
+ * call overlap the convolutions and fits of the one before.  What a caller may rely on:
+ *   - mpsfr_stream() is ordered after every call made so far (wait on it, or mpsfr_sync, before
+ *     reading results);
+ *   - two calls that write the same output buffer run in call order;
+ *   - calls with distinct output buffers may run concurrently and finish in any order;
+ *   - to make the NEXT call wait for the caller's own GPU work, register an event with
+ *     mpsfr_wait_event (work queued on mpsfr_stream() does not hold back later calls).
+ * Option "pipeline_calls" = 0 restores strictly serial calls.
  */
 #ifndef MPSFR_H
 #define MPSFR_H
@@ -59,11 +70,12 @@ const char* mpsfr_last_error(void);
 
 /* Tunables: "chunk_tasks" (tasks per pipeline pass, 0 = automatic); "fast_exp" (mixed mode only,
  * default 1: hardware exp2 for the OTF); "fft_conv" (mixed mode only, default 1: the two 41x41
- * convolutions through 64-point FFTs instead of the direct form); "streams" (0 = automatic, the
- * default, or 1..4 pipeline lanes: consecutive chunks of a call alternate between HIP streams with their own
- * workspaces so that one chunk's tail overlaps the other's body; automatic = one lane for a call
- * that fits one chunk, two for multi-chunk calls; results are independent of it except for the
- * summation order of psf_sum_out); "profile" (0/1: bracket every kernel launch
+ * convolutions through 64-point FFTs instead of the direct form); "streams" (0 = automatic = 2,
+ * or 1..4 pipeline lanes: consecutive chunks -- of one call and of consecutive asynchronous
+ * calls -- go to successive HIP streams with their own workspaces so that one chunk's tail
+ * overlaps the next one's body; results are independent of it except for the summation order of
+ * psf_sum_out in multi-chunk calls); "pipeline_calls" (default 1: asynchronous calls rotate over
+ * the lanes; 0: every call starts on the first lane); "profile" (0/1: bracket every kernel launch
  * with HIP events on the stream it is launched on -- the event packets cost ~8 % of a step);
  * "profile_only" (-1 = all kernels, else the kernel id of mpsfr_profile_name to time alone). */
 int mpsfr_set_option(mpsfr_ctx* ctx, const char* key, double value);
@@ -102,12 +114,22 @@ int mpsfr_reconstruct(mpsfr_ctx* ctx, int ntask, const double* seeing, const dou
 int mpsfr_fit_stamps(mpsfr_ctx* ctx, int nstamp, const double* stamps, double* fit_out,
                      int on_device);
 
-/* Block until everything queued on the context's stream has finished. */
+/* Block until every call made so far has finished. */
 int mpsfr_sync(mpsfr_ctx* ctx);
 
-/* The context's hipStream_t (as void*), so that a caller can order its own GPU work against the
- * asynchronous (on_device = 1) calls without a host sync, e.g. torch.cuda.ExternalStream. */
+/* The context's hipStream_t (as void*): it is ordered after every asynchronous (on_device = 1)
+ * call made so far, so a caller can queue its own GPU work behind the results without a host
+ * sync, e.g. torch.cuda.current_stream().wait_stream(torch.cuda.ExternalStream(...)). */
 void* mpsfr_stream(mpsfr_ctx* ctx);
+
+/* Make the next mpsfr_reconstruct wait (on the GPU, no host sync) for `hip_event`, a recorded
+ * hipEvent_t of the caller, e.g. the end of a collective that still reads the buffers the call
+ * will overwrite.  One-shot: consumed by the next call. */
+int mpsfr_wait_event(mpsfr_ctx* ctx, void* hip_event);
+
+/* Host wall time spent inside mpsfr_reconstruct since the last mpsfr_profile_reset, and the
+ * number of calls (what queueing a call costs the host thread). */
+int mpsfr_host_time(mpsfr_ctx* ctx, double* seconds, long* calls);
 
 /* Copy an intermediate of the most recent mpsfr_reconstruct pipeline pass (last chunk) to the
  * host as float64 (parity tests, tests/test_gpu_parity.py).  `what`:

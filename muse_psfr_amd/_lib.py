@@ -69,6 +69,10 @@ def load():
     lib.mpsfr_sync.restype = C.c_int
     lib.mpsfr_stream.argtypes = [p]
     lib.mpsfr_stream.restype = C.c_void_p
+    lib.mpsfr_wait_event.argtypes = [p, C.c_void_p]
+    lib.mpsfr_wait_event.restype = C.c_int
+    lib.mpsfr_host_time.argtypes = [p, dp, C.POINTER(C.c_long)]
+    lib.mpsfr_host_time.restype = C.c_int
     lib.mpsfr_debug_fetch.argtypes = [p, C.c_char_p, dp, C.c_size_t]
     lib.mpsfr_debug_fetch.restype = C.c_long
     lib.mpsfr_profile_count.argtypes = []
@@ -88,7 +92,8 @@ def load():
 
 
 EXPORTS = ['mpsfr_create', 'mpsfr_destroy', 'mpsfr_last_error', 'mpsfr_set_option',
-           'mpsfr_reconstruct', 'mpsfr_fit_stamps', 'mpsfr_sync', 'mpsfr_stream', 'mpsfr_debug_fetch',
+           'mpsfr_reconstruct', 'mpsfr_fit_stamps', 'mpsfr_sync', 'mpsfr_stream', 'mpsfr_wait_event',
+           'mpsfr_host_time', 'mpsfr_debug_fetch',
            'mpsfr_profile_count', 'mpsfr_profile_name', 'mpsfr_profile_get',
            'mpsfr_profile_reset', 'mpsfr_version', 'mpsfr_build_id']
 
@@ -132,6 +137,17 @@ class Context:
 
     def sync(self):
         _check(self.lib.mpsfr_sync(self._h))
+
+    def wait_event(self, hip_event):
+        """The next reconstruct call waits on the GPU for this recorded hipEvent_t (an integer
+        handle, e.g. torch.cuda.Event.cuda_event)."""
+        _check(self.lib.mpsfr_wait_event(self._h, C.c_void_p(int(hip_event))))
+
+    def host_time(self):
+        """(seconds spent inside mpsfr_reconstruct, calls) since the last profile_reset()."""
+        sec, n = C.c_double(), C.c_long()
+        _check(self.lib.mpsfr_host_time(self._h, C.byref(sec), C.byref(n)))
+        return sec.value, n.value
 
     def stream_handle(self):
         """hipStream_t of the context as an integer (for torch.cuda.ExternalStream)."""

@@ -463,3 +463,53 @@ def test_pipelined_async_calls_match_sequential_ones(api):
         assert np.array_equal(fits[b].cpu().numpy(), ref[b]['fit']), b
         assert np.array_equal(sums[b].cpu().numpy(), ref[b]['psf_sum']), b
     ctx.close()
+
+
+def test_consecutive_calls_overlap_on_lanes_and_stay_ordered_per_buffer(api):
+    """Asynchronous calls of one context rotate over its lanes: distinct output buffers may run
+    concurrently, a reused buffer ends with the LAST call's result, and mpsfr_wait_event holds a
+    call back behind the caller's own GPU work."""
+    import torch
+    from muse_psfr_amd import NFIT
+    ps = api.grid_pixscale(128)
+    lb = np.linspace(465, 930, 6)
+    dev = torch.device('cuda', 0)
+    batches = [api.synthetic_rows(9, seed=500 + k) for k in range(5)]
+    z = np.zeros(9, np.uint8)
+    ref = api.Context(dim=128, pixscale=ps)
+    want = [ref.reconstruct(lb, *b, z, H, want_psf=False) for b in batches]
+    ref.close()
+    ctx = api.Context(dim=128, pixscale=ps)
+    fits = [torch.zeros((9, 6, NFIT), dtype=torch.float64, device=dev) for _ in batches]
+    sums = [torch.zeros((6, 40, 40), dtype=torch.float64, device=dev) for _ in batches]
+    for k, b in enumerate(batches):                       # distinct buffers
+        ctx.reconstruct_device(lb, *b, z, H, 12.0, 1, None, None, sums[k].data_ptr(), fits[k].data_ptr())
+    ctx.sync()
+    for k in range(len(batches)):
+        assert np.array_equal(fits[k].cpu().numpy(), want[k]['fit']), k
+        assert np.array_equal(sums[k].cpu().numpy(), want[k]['psf_sum']), k
+    for k, b in enumerate(batches):                       # one buffer, five calls: the last wins
+        ctx.reconstruct_device(lb, *b, z, H, 12.0, 1, None, None, sums[0].data_ptr(), fits[0].data_ptr())
+    ctx.sync()
+    assert np.array_equal(fits[0].cpu().numpy(), want[-1]['fit'])
+    assert np.array_equal(sums[0].cpu().numpy(), want[-1]['psf_sum'])
+    # a call held back by a caller's event: the caller's copy of the old content must complete
+    # before the call overwrites the buffer
+    keep = torch.empty_like(fits[1])
+    big = torch.randn(4096, 4096, device=dev)
+    for _ in range(4):
+        big = big @ big * 1e-4                            # keeps torch's stream busy for a while
+    keep.copy_(fits[1])
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    ctx.wait_event(ev.cuda_event)
+    ctx.reconstruct_device(lb, *batches[3], z, H, 12.0, 1, None, None, sums[1].data_ptr(), fits[1].data_ptr())
+    ctx.sync()
+    torch.cuda.synchronize()
+    assert np.array_equal(keep.cpu().numpy(), want[1]['fit'])
+    assert np.array_equal(fits[1].cpu().numpy(), want[3]['fit'])
+    ctx.set_option('pipeline_calls', 0)
+    ctx.reconstruct_device(lb, *batches[2], z, H, 12.0, 1, None, None, sums[2].data_ptr(), fits[2].data_ptr())
+    ctx.sync()
+    assert np.array_equal(fits[2].cpu().numpy(), want[2]['fit'])
+    ctx.close()
