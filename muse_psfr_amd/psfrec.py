@@ -369,20 +369,78 @@ def fit_psf_with_polynom(lbda, fwhm, beta, deg=(5, 5), output=0):
     return res
 
 
+def direction_perf(npts, field_size=60, plot=False, lgs=None, ngs=None, ax=None):
+    """Grid of directions (arcsec) where the PSF is estimated (psfrec.py:154-180): (2, npts^2),
+    (mgrid - npts // 2) * field_size / 2.  With ``plot`` the directions (and the guide stars, if
+    given) are drawn on ``ax``."""
+    gx, gy = (np.mgrid[:npts, :npts] - npts // 2) * field_size / 2
+    dirperf = np.array([gx, gy]).reshape(2, -1)
+    if plot:
+        import matplotlib.pyplot as plt
+        if ax is None:
+            _, ax = plt.subplots()
+        extent = np.max(dirperf)
+        ax.scatter(dirperf[0], dirperf[1], marker='o', s=10, label='Reconstruction directions')
+        for stars, size, label in ((lgs, 60, 'LGS'), (ngs, 40, 'NGS')):
+            if stars is not None:
+                extent = max(extent, np.max(stars))
+                ax.scatter(stars[0], stars[1], marker='*', s=size, label=label)
+        ax.set_xlim((-1.25 * extent, 1.25 * extent))
+        ax.set_ylim((-1.25 * extent, 1.25 * extent))
+        ax.set_xlabel('arcsecond')
+        ax.set_ylabel('arcsecond')
+        ax.legend(loc='upper center')
+    return dirperf
+
+
+def radial_profile(arr, binsize=1):
+    """Azimuthal mean of ``arr`` in rings of width ``binsize`` around pixel
+    (int(n0/2 + .5), int(n1/2 + .5)) (psfrec.py:810-823).  Returns (bin centres, mean per ring);
+    empty rings give nan, as in the reference."""
+    arr = np.asarray(arr, dtype=float)
+    c0, c1 = int(arr.shape[0] / 2 + .5), int(arr.shape[1] / 2 + .5)
+    r = np.hypot(np.arange(arr.shape[0])[:, None] - c0, np.arange(arr.shape[1])[None, :] - c1)
+    nbins = int(np.round(r.max() / binsize) + 1)
+    edges = np.linspace(0, nbins * binsize, nbins + 1)
+    count = np.histogram(r, edges)[0]
+    total = np.histogram(r, edges, weights=arr)[0]
+    with np.errstate(invalid='ignore', divide='ignore'):
+        return (edges[1:] + edges[:-1]) / 2, total / count
+
+
 def plot_psf(filename, npsflin=1):
-    """Quick-look figure of PSF_MEAN and the FIT_MEAN curves (psfrec.py:826-858, simplified)."""
+    """Figure of a reconstruction result (psfrec.py:826-858): 2 x 3 panels -- the second plane of
+    PSF_MEAN (log scale), an empty panel, the reconstruction directions with the four LGS at 63
+    arcsec; the radial profile of that plane (log), FWHM(lambda) and beta(lambda) from FIT_MEAN.
+    ``filename`` is an HDUList (astropy's or this package's) or a path to the FITS file."""
     import matplotlib.pyplot as plt
     from matplotlib.colors import LogNorm
-    hdul = filename if not isinstance(filename, (str, os.PathLike)) else (
-        _astropy()[0] or _minifits).open(filename)
-    psf = hdul['PSF_MEAN'].data
-    fit = hdul['FIT_MEAN'].data
-    fig, axes = plt.subplots(1, 3, figsize=(12, 3.5), tight_layout=True)
-    im = axes[0].imshow(psf[min(1, len(psf) - 1)], origin='lower', norm=LogNorm())
-    fig.colorbar(im, ax=axes[0])
-    axes[0].set_title('PSF')
-    axes[1].plot(fit['lbda'], np.asarray(fit['fwhm'])[:, 0])
-    axes[1].set_title(r'$FWHM(\\lambda)$')
-    axes[2].plot(fit['lbda'], fit['n'])
-    axes[2].set_title(r'$\\beta(\\lambda)$')
+    opened = isinstance(filename, (str, os.PathLike))
+    hdul = (_astropy()[0] or _minifits).open(filename) if opened else filename
+    try:
+        psf = np.array(hdul['PSF_MEAN'].data, dtype=float)
+        fit = hdul['FIT_MEAN'].data
+        lbda = np.array(fit['lbda'], dtype=float)
+        fwhm = np.array(fit['fwhm'], dtype=float)[:, 0]
+        beta = np.array(fit['n'], dtype=float)
+    finally:
+        if opened:
+            hdul.close()
+    plane = psf[1]
+    fig, axes = plt.subplots(2, 3, figsize=(12, 6), tight_layout=True)
+    top, bottom = axes
+    im = top[0].imshow(plane, origin='lower', norm=LogNorm())
+    fig.colorbar(im, ax=top[0])
+    top[0].set_title('PSF')
+    top[1].axis('off')
+    poslgs = 63.0 * np.array([[1, 1], [-1, -1], [-1, 1], [1, -1]], dtype=float).T   # arcsec
+    direction_perf(npsflin, plot=True, lgs=poslgs, ax=top[2])
+    centers, prof = radial_profile(plane)
+    bottom[0].plot(centers[1:], prof[1:], lw=1)
+    bottom[0].set_yscale('log')
+    bottom[0].set_title('radial profile')
+    bottom[1].plot(lbda, fwhm)
+    bottom[1].set_title(r'$FWHM(\lambda)$')
+    bottom[2].plot(lbda, beta)
+    bottom[2].set_title(r'$\beta(\lambda)$')
     return fig

@@ -5,7 +5,9 @@ Imports /root/reference/muse_psfr/psfrec.py *unmodified* under /opt/conda/bin/py
 stand-in module is seeded: psfrec.py only needs `mpdaf.obj.Cube` to exist at import time and
 nothing in the numerical path before the Moffat fit calls it.  The Moffat fit itself is NOT
 reference code (it lives in mpdaf); goldens for it come from the scipy
-restatement in oracle/psfr_oracle.py.
+restatement in oracle/psfr_oracle.py -- the stand-in Cube yields planes whose `moffat_fit` is
+that restatement, so that the reference's own compute_psf / compute_psf_from_sparta run end to
+end (section `lgs` of make_golden.py).
 
 `load_reference(dim=None, pixscale=None)` returns a module object.  With dim/pixscale given the
 reference *source text* is patched in memory (the hard-coded locals psfrec.py:659, :899, :955)
@@ -20,6 +22,36 @@ import numpy as np
 REF = '/root/reference/muse_psfr/psfrec.py'
 
 
+class _FitResult:
+    """What psfrec.py:866-870 reads from mpdaf's fit object (its __dict__ becomes a table row)."""
+
+
+class _Image:
+    """One plane of the stand-in Cube.  moffat_fit is the scipy/MINPACK restatement of
+    oracle/psfr_oracle.py: the Moffat fit is NOT reference code (mpdaf)."""
+
+    def __init__(self, data):
+        self.data = data
+
+    def moffat_fit(self, unit_center=None, unit_fwhm=None, circular=True, fit_back=False,
+                   verbose=False):
+        import psfr_oracle as O
+        assert circular and not fit_back and unit_center is None and unit_fwhm is None
+        (peak, p0, q0, fwhm_arcsec, n), chi2, _ = O.moffat_fit(self.data, 0.2, full=True)
+        r = _FitResult()
+        fw = fwhm_arcsec / 0.2                      # pixels: psfrec.py:868 multiplies by 0.2
+        a = fw / (2 * np.sqrt(2 ** (1 / n) - 1))
+        r.center = np.array([p0, q0])
+        r.flux = peak * np.pi * a * a / (n - 1)
+        r.fwhm = np.array([fw, fw])
+        r.cont, r.n, r.rot, r.peak = 0.0, n, 0.0, peak
+        r.err_center = np.zeros(2)
+        r.err_flux, r.err_fwhm, r.err_cont, r.err_n, r.err_rot, r.err_peak = (
+            0.0, np.zeros(2), 0.0, 0.0, 0.0, 0.0)
+        r.ima = None
+        return r
+
+
 def _seed():
     # astropy 4.3.1 references names removed from numpy >= 1.23
     if not hasattr(np, 'asscalar'):
@@ -30,9 +62,12 @@ def _seed():
         mp = types.ModuleType('mpdaf')
         obj = types.ModuleType('mpdaf.obj')
 
-        class Cube:  # inert: only has to exist for `from mpdaf.obj import Cube`
+        class Cube:  # stand-in for `from mpdaf.obj import Cube`: planes with the scipy Moffat fit
             def __init__(self, data=None, copy=False):
                 self.data = data
+
+            def __iter__(self):
+                return (_Image(p) for p in self.data)
         obj.Cube = Cube
         mp.obj = obj
         sys.modules['mpdaf'] = mp

@@ -7,7 +7,7 @@ NumPy restatement oracle/psfr_oracle.py agrees with it stage by stage, and write
 fixtures (inputs + the reference's outputs) to tests/golden/.  Nothing here travels as code the
 GPU box needs; the fixtures are data.
 
-Sections: masks native grids sparta
+Sections: masks native grids sparta lgs
 """
 import os
 import sys
@@ -180,9 +180,51 @@ def section_sparta(ref):
                         fin_row0=fin[0], fin_row17=fin[17], pre_row0=res[0][0])
 
 
+def section_lgs(ref):
+    """G7: the reference's own compute_psf_from_sparta (psfrec.py:981-1120) end to end on a
+    5-row table whose four LGS columns are jittered by +-5 % (BASELINE.json configs[3]), one
+    laser with L0 = 100 m (rejected -> 3-LGS mode, psfrec.py:1049-1054) and one row with no valid
+    laser at all (skipped, :1056-1060): mean_of_lgs=True (one task per row) and mean_of_lgs=False
+    (one task per valid laser, :1071-1076)."""
+    from astropy.io import fits
+    from astropy.table import Table
+    rng = np.random.default_rng(3553)
+    nrow = 5
+    see, gl, l0 = synthetic_rows(nrow)
+    cols = {}
+    for k in range(1, 5):
+        j = 1 + 0.05 * rng.normal(size=(3, nrow))
+        cols['LGS%d_SEEING' % k] = see * j[0]
+        cols['LGS%d_TUR_GND' % k] = np.clip(gl * j[1], 0.05, 0.98)
+        cols['LGS%d_L0' % k] = np.clip(l0 * j[2], 8.5, 29.5)
+    cols['LGS3_L0'][1] = 100.0                      # one rejected laser in row 2
+    for k in range(1, 5):
+        cols['LGS%d_L0' % k][3] = 150.0             # row 4: nothing valid
+    tbl = fits.table_to_hdu(Table(cols))
+    tbl.name = 'SPARTA_ATM_DATA'
+    out = {'colnames': np.array(list(cols)), 'table': np.array([cols[c] for c in cols]),
+           'lmin': 490.0, 'lmax': 930.0, 'nl': 4}
+    for tag, mean in (('mean', True), ('lgs', False)):
+        t = time.time()
+        res = ref.compute_psf_from_sparta(fits.HDUList([fits.PrimaryHDU(), tbl]), lmin=490, lmax=930,
+                                          nl=4, n_jobs=1, mean_of_lgs=mean, verbose=False)
+        print('reference compute_psf_from_sparta(mean_of_lgs=%s): %.1fs, %d FIT_ROWS rows' % (
+            mean, time.time() - t, len(res['FIT_ROWS'].data)), flush=True)
+        assert [h.name for h in res] == ['PRIMARY', 'SPARTA_ATM_DATA', 'FIT_ROWS', 'FIT_MEAN', 'PSF_MEAN']
+        fr, fm = res['FIT_ROWS'].data, res['FIT_MEAN'].data
+        for c in ('lbda', 'fwhm', 'n', 'peak', 'center', 'SEEING', 'GL', 'L0', 'row_idx', 'lgs_idx'):
+            out['%s_rows_%s' % (tag, c)] = np.array(fr[c])
+        for c in ('lbda', 'fwhm', 'n'):
+            out['%s_mean_%s' % (tag, c)] = np.array(fm[c])
+        hdr = res['FIT_MEAN'].header
+        out['%s_mean_hdr' % tag] = np.array([hdr['SEEING'], hdr['GL'], hdr['L0']])
+        out['%s_psf_mean' % tag] = np.array(res['PSF_MEAN'].data)
+    np.savez_compressed(os.path.join(OUT, 'g7_sparta_lgs.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    secs = sys.argv[1:] or ['masks', 'native', 'grids', 'sparta']
+    secs = sys.argv[1:] or ['masks', 'native', 'grids', 'sparta', 'lgs']
     ref = load_reference()
     for s in secs:
         print('== section', s, flush=True)

@@ -160,3 +160,56 @@ def test_script_with_file(api, tmp_path, monkeypatch):
     assert lines[2:] == ['OB None None Airmass 0.00-0.00', '-' * 68,
                          'Sparta Seeing: 1.00 arcsec GL: 0.70 L0:25.00 m', 'LBDA 5000 7000 9000',
                          'FWHM 0.85 0.73 0.62', 'BETA 2.73 2.55 2.23', '-' * 68]
+
+
+def test_plot(api, tmp_path):
+    """test_psfrec.py:173-188: 2 rows, the default 35 wavelengths on the native grid, plot_psf on
+    the result and on the file written from it (Agg backend)."""
+    import matplotlib
+    matplotlib.use('agg', force=True)
+    testfile = os.path.join(str(tmp_path), 'sparta.fits')
+    api.create_sparta_table(outfile=testfile, nlines=2)
+    res = api.compute_psf_from_sparta(testfile)
+    assert res['PSF_MEAN'].data.shape == (35, 40, 40)
+    assert len(res['FIT_ROWS'].data) == 70
+    outfile = os.path.join(str(tmp_path), 'fitres.fits')
+    res.writeto(outfile, overwrite=True)
+    fig = api.plot_psf(res)
+    fig.savefig(os.path.join(str(tmp_path), 'fig.png'))
+    fig = api.plot_psf(outfile)
+    fig.savefig(os.path.join(str(tmp_path), 'fig.png'))
+    assert os.path.getsize(os.path.join(str(tmp_path), 'fig.png')) > 0
+    # `plot=True` path of compute_psf_from_sparta (psfrec.py:1115-1118) on a non-interactive backend
+    res2 = api.compute_psf_from_sparta(testfile, lmin=500, lmax=900, nl=3, plot=True)
+    assert len(res2) == 5
+
+
+@pytest.mark.parametrize('tag,mean', [('mean', True), ('lgs', False)])
+def test_sparta_front_end_against_the_reference(api, golden, ref_masks, tag, mean):
+    """G7: the reference's own compute_psf_from_sparta end to end (psfrec.py:981-1120) on a table
+    with the four LGS columns jittered by +-5 % (BASELINE.json configs[3]), one rejected laser
+    (3-LGS mode) and one row without a valid laser: FIT_ROWS incl. row_idx / lgs_idx, FIT_MEAN,
+    PSF_MEAN, for mean_of_lgs=True and mean_of_lgs=False (psfrec.py:1066-1076)."""
+    from collections import OrderedDict
+    from muse_psfr_amd.psfrec import _table_hdu
+    g = golden('g7_sparta_lgs')
+    cols = OrderedDict((str(n), np.array(v)) for n, v in zip(g['colnames'], g['table']))
+    tbl = _table_hdu(cols, {}, 'SPARTA_ATM_DATA')
+    res = api.compute_psf_from_sparta(_hdul(tbl), lmin=float(g['lmin']), lmax=float(g['lmax']),
+                                      nl=int(g['nl']), mean_of_lgs=mean, cutoff_masks=ref_masks,
+                                      verbose=False)
+    fr, fm = res['FIT_ROWS'].data, res['FIT_MEAN'].data
+    assert np.array_equal(np.asarray(fr['row_idx']), g[tag + '_rows_row_idx'])
+    assert np.array_equal(np.asarray(fr['lgs_idx']), g[tag + '_rows_lgs_idx'])
+    for c in ('lbda', 'SEEING', 'GL', 'L0'):
+        np.testing.assert_allclose(np.asarray(fr[c]), g[tag + '_rows_' + c], rtol=1e-13)
+    assert np.abs(np.asarray(fr['fwhm']) - g[tag + '_rows_fwhm']).max() < 1e-4
+    assert np.abs(np.asarray(fr['n']) - g[tag + '_rows_n']).max() < 1e-4
+    assert np.abs(np.asarray(fr['center']) - g[tag + '_rows_center']).max() < 1e-4
+    assert np.abs(np.asarray(fr['peak']) / g[tag + '_rows_peak'] - 1).max() < 1e-4
+    assert np.abs(np.asarray(fm['fwhm']) - g[tag + '_mean_fwhm']).max() < 1e-4
+    assert np.abs(np.asarray(fm['n']) - g[tag + '_mean_n']).max() < 1e-4
+    hdr = res['FIT_MEAN'].header
+    np.testing.assert_allclose([hdr['SEEING'], hdr['GL'], hdr['L0']], g[tag + '_mean_hdr'], rtol=1e-13)
+    pm = np.asarray(res['PSF_MEAN'].data)
+    assert np.abs(pm - g[tag + '_psf_mean']).max() / g[tag + '_psf_mean'].max() < 2e-5

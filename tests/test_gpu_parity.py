@@ -106,23 +106,33 @@ def test_reference_known_answers_through_the_gpu(api, ref_masks):
     np.testing.assert_allclose(f[:, 1:3], 20, atol=1e-3)
 
 
-@pytest.mark.parametrize('dim', [512, 1024])
-def test_patched_grid_goldens(api, golden, ref_masks, dim):
+@pytest.mark.parametrize('prec', ['mixed', 'f64'])
+@pytest.mark.parametrize('dim', [128, 256, 512, 1024])
+def test_patched_grid_goldens(api, golden, ref_masks, dim, prec):
+    """G6: the reference source with its hard-coded dim / pixscale patched in memory, for every
+    grid of BASELINE.json (incl. the npsflin = 3 row at 256^2 and a 3-LGS row).  On 128^2 / 256^2
+    the stamp is narrower than the PSF core and the Moffat fit is ill-posed:
+    those grids are graded on the stamps, before and after the convolutions."""
     g = golden('g6_grids')
     lb = g['n%d_lbda' % dim]
     ps = api.grid_pixscale(dim)
-    ctx = api.Context(dim=dim, pixscale=ps, precision='mixed')
+    ctx = api.Context(dim=dim, pixscale=ps, precision=prec)
     k = 0
+    seen_npl = set()
     while 'n%d_r%d_in' % (dim, k) in g:
         s, gl, l0, npl, three, ps_g = g['n%d_r%d_in' % (dim, k)]
         assert abs(ps_g - ps) < 1e-15
         r = ctx.reconstruct(lb, [s], [gl], [l0], [int(three)], H, npsflin=int(npl), masks=ref_masks)
-        assert rel_err(r['psf'][0], g['n%d_r%d_fin' % (dim, k)]) < TOL['mixed']['stamp']
-        fit = g['n%d_r%d_fit' % (dim, k)]
-        assert np.abs(r['fit'][0][:, 5] * ps - fit[:, 3]).max() < 1e-4
-        assert np.abs(r['fit'][0][:, 4] - fit[:, 4]).max() < 1e-4
+        pre = ctx.debug_fetch('pre', (1, lb.size, 40, 40))
+        assert rel_err(pre[0], g['n%d_r%d_pre' % (dim, k)]) < TOL[prec]['stamp']
+        assert rel_err(r['psf'][0], g['n%d_r%d_fin' % (dim, k)]) < TOL[prec]['stamp']
+        if dim >= 512:
+            fit = g['n%d_r%d_fit' % (dim, k)]
+            assert np.abs(r['fit'][0][:, 5] * ps - fit[:, 3]).max() < TOL[prec]['fit']
+            assert np.abs(r['fit'][0][:, 4] - fit[:, 4]).max() < TOL[prec]['fit']
+        seen_npl.add(int(npl))
         k += 1
-    assert k >= 2
+    assert k >= 2 and (dim != 256 or 3 in seen_npl)
     ctx.close()
 
 
@@ -513,3 +523,118 @@ def test_consecutive_calls_overlap_on_lanes_and_stay_ordered_per_buffer(api):
     ctx.sync()
     assert np.array_equal(fits[2].cpu().numpy(), want[2]['fit'])
     ctx.close()
+
+
+def _oracle_rows(api, lb, see, gl, l0, three, dim, ps, npl, rows, lam_idx):
+    """Oracle (fit, final stamps) for a sample of rows at a sample of wavelengths."""
+    out = {}
+    tabs = {t: O.ao_tables(H, bool(t), npl, exact_masks=True) for t in set(int(three[k]) for k in rows)}
+    for k in rows:
+        out[k] = O.compute_psf(lb[lam_idx], see[k], gl[k], l0[k], npl, H, bool(three[k]), dim=dim,
+                               pixscale=ps, tables=tabs[int(three[k])])
+    return out
+
+
+def test_config_1000_rows_512(api):
+    """BASELINE.json configs[2] on one GPU (its shard layout is exercised by tests/test_dist.py
+    and tests/test_gpu_dist.py): 1000 rows x 35 wavelengths x 512^2 = 35 000 PSFs through one
+    call -- nine chunks over two lanes -- with the oracle on sampled rows and size-independent
+    properties on everything."""
+    n = 1000
+    see, gl, l0 = api.synthetic_rows(n)
+    lb = np.linspace(465, 930, 35)
+    ps = api.grid_pixscale(512)
+    three = (np.arange(n) % 97 == 5).astype(np.uint8)
+    ctx = api.Context(dim=512, pixscale=ps, precision='mixed')
+    r = ctx.reconstruct(lb, see, gl, l0, three, H)
+    psf, fit = r['psf'], r['fit']
+    assert np.isfinite(psf).all() and np.isfinite(fit).all()
+    np.testing.assert_allclose(r['psf_sum'], psf.sum(axis=0), rtol=1e-12)
+    assert np.all(fit[:, :, 14] == 0) and np.abs(fit[:, :, 1:3] - 20).max() < 0.1
+    assert np.all(fit[:, -1, 5] < fit[:, 0, 5])
+    # the first 100 rows are the bench workload: same bits as a 100-row call (chunking invariance)
+    r100 = ctx.reconstruct(lb, see[:100], gl[:100], l0[:100], three[:100], H, want_psf=False)
+    assert np.array_equal(r100['fit'], fit[:100])
+    ctx.close()
+    li = [0, 17, 34]
+    for k, (ofit, ofin) in _oracle_rows(api, lb, see, gl, l0, three, 512, ps, 1, [5, 499, 999], li).items():
+        assert rel_err(psf[k][li], ofin) < 2e-5, k
+        assert np.abs(fit[k][li, 5] * ps - ofit[:, 3]).max() < 1e-4, k
+        assert np.abs(fit[k][li, 4] - ofit[:, 4]).max() < 1e-4, k
+
+
+def test_config_nine_directions_256(api):
+    """BASELINE.json configs[3]: 100 rows x 35 wavelengths x 256^2, npsflin = 3 (nine evaluation
+    directions per PSF, unweighted PSF mean -- SURVEY.md 8(d) item 3), through the SPARTA front
+    end with the four LGS columns jittered by +-5 % and mean_of_lgs=True; the oracle on sampled
+    rows (stamps: at 256^2 the fit is ill-posed)."""
+    from collections import OrderedDict
+    from muse_psfr_amd.psfrec import _table_hdu
+    from muse_psfr_amd import _minifits as mf
+    n = 100
+    see, gl, l0 = api.synthetic_rows(n)
+    rng = np.random.default_rng(77)
+    cols = OrderedDict()
+    for q in range(1, 5):
+        j = 1 + 0.05 * rng.normal(size=(3, n))
+        cols['LGS%d_SEEING' % q] = see * j[0]
+        cols['LGS%d_TUR_GND' % q] = np.clip(gl * j[1], 0.05, 0.98)
+        cols['LGS%d_L0' % q] = np.clip(l0 * j[2], 8.5, 29.5)
+    tbl = _table_hdu(cols, {}, 'SPARTA_ATM_DATA')
+    hdul = mf.HDUList([mf.PrimaryHDU(), tbl]) if isinstance(tbl, mf.BinTableHDU) else None
+    if hdul is None:
+        from astropy.io import fits
+        hdul = fits.HDUList([fits.PrimaryHDU(), tbl])
+    ps = api.grid_pixscale(256)
+    lb = np.linspace(465, 930, 35)
+    res = api.compute_psf_from_sparta(hdul, npsflin=3, lbda=lb, dim=256, pixscale=ps,
+                                      cutoff_masks='exact', verbose=False)
+    fr = res['FIT_ROWS'].data
+    assert len(fr) == n * 35 and np.all(np.asarray(fr['lgs_idx']) == -1)
+    vals = np.array([[cols['LGS%d_%s' % (q, c)] for c in ('SEEING', 'TUR_GND', 'L0')] for q in range(1, 5)])
+    mean = vals.mean(axis=0)                               # (3, n): psfrec.py:1067
+    np.testing.assert_allclose(np.asarray(fr['SEEING'])[::35], mean[0], rtol=1e-13)
+    np.testing.assert_allclose(np.asarray(fr['L0'])[::35], mean[2], rtol=1e-13)
+    # the same tasks through the C ABI with the stamps kept, against the oracle
+    ctx = api.Context(dim=256, pixscale=ps, precision='mixed')
+    r = ctx.reconstruct(lb, mean[0], mean[1], mean[2], np.zeros(n, np.uint8), H, npsflin=3)
+    ctx.close()
+    np.testing.assert_allclose(np.asarray(res['PSF_MEAN'].data), r['psf_sum'] / n, rtol=1e-12)
+    np.testing.assert_array_equal(np.asarray(fr['n']), r['fit'][:, :, 4].reshape(-1))
+    li = [0, 20, 34]
+    for k, (_, ofin) in _oracle_rows(api, lb, mean[0], mean[1], mean[2], np.zeros(n, np.uint8), 256, ps, 3,
+                                     [0, 63], li).items():
+        assert rel_err(r['psf'][k][li], ofin) < 2e-5, k
+
+
+def test_config_high_resolution_1024(api, golden, ref_masks):
+    """BASELINE.json configs[4]: 200 rows x 70 wavelengths x 1024^2 = 14 000 PSFs.  Row 0 is the
+    G6 golden row of the patched reference at 465 and 930 nm; the oracle on another sampled row;
+    properties on everything."""
+    n = 200
+    see, gl, l0 = api.synthetic_rows(n)
+    lb = np.linspace(465, 930, 70)
+    ps = api.grid_pixscale(1024)
+    ctx = api.Context(dim=1024, pixscale=ps, precision='mixed')
+    r = ctx.reconstruct(lb, see, gl, l0, np.zeros(n, np.uint8), H, masks=ref_masks)
+    ctx.close()
+    psf, fit = r['psf'], r['fit']
+    assert np.isfinite(psf).all() and np.isfinite(fit).all() and np.all(fit[:, :, 14] == 0)
+    np.testing.assert_allclose(r['psf_sum'], psf.sum(axis=0), rtol=1e-12)
+    assert np.all(fit[:, -1, 5] < fit[:, 0, 5])
+    g = golden('g6_grids')
+    gin = g['n1024_r1_in']
+    assert (gin[0], gin[1], gin[2]) == (see[0], gl[0], l0[0]) and int(gin[3]) == 1 and int(gin[4]) == 0
+    glb = g['n1024_lbda']
+    for gi, li in ((0, 0), (3, 69)):
+        assert glb[gi] == lb[li]
+        assert rel_err(psf[0][li], g['n1024_r1_fin'][gi]) < 2e-5
+        assert abs(fit[0][li, 5] * ps - g['n1024_r1_fit'][gi, 3]) < 1e-4
+        assert abs(fit[0][li, 4] - g['n1024_r1_fit'][gi, 4]) < 1e-4
+    tabs = O.ao_tables(H, False, 1, masks=ref_masks)
+    li = [1, 35]
+    ofit, ofin = O.compute_psf(lb[li], see[150], gl[150], l0[150], 1, H, False, dim=1024, pixscale=ps,
+                               tables=tabs)
+    assert rel_err(psf[150][li], ofin) < 2e-5
+    assert np.abs(fit[150][li, 5] * ps - ofit[:, 3]).max() < 1e-4
+    assert np.abs(fit[150][li, 4] - ofit[:, 4]).max() < 1e-4

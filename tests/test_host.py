@@ -174,3 +174,63 @@ def test_cli_argument_errors():
         main([])
     with pytest.raises(SystemExit, match='--values must contain a list.*'):
         main(['--values', '0.1,0.2'])
+
+
+def test_direction_perf_and_radial_profile():
+    """psfrec.py:154-158 (n=1 -> (0,0); n=2 -> {-30,0}^2; n=3 -> {-30,0,30}^2) and
+    psfrec.py:810-823."""
+    from muse_psfr_amd import direction_perf, radial_profile
+    assert direction_perf(1).tolist() == [[0.0], [0.0]]
+    d2 = direction_perf(2)
+    assert sorted(set(d2[0])) == [-30.0, 0.0] and d2.shape == (2, 4)
+    d3 = direction_perf(3)
+    assert d3.shape == (2, 9) and sorted(set(d3[1])) == [-30.0, 0.0, 30.0]
+    assert d3[:, 0].tolist() == [-30.0, -30.0] and d3[:, 1].tolist() == [-30.0, 0.0]   # y fastest
+    np.testing.assert_array_equal(direction_perf(3), O.eval_directions(3))
+    # a radially symmetric image comes back as its own profile
+    n = 40
+    x, y = np.ogrid[:n, :n]
+    r = np.hypot(x - 20, y - 20)
+    centers, prof = radial_profile(np.ones((n, n)))
+    assert centers[0] == 0.5 and np.allclose(np.diff(centers), 1.0)
+    assert np.allclose(prof[np.isfinite(prof)], 1.0)
+    centers, prof = radial_profile(np.floor(r))           # ring k holds the value k exactly
+    k = np.arange(len(prof))
+    ok = np.isfinite(prof)
+    np.testing.assert_allclose(prof[ok], k[ok])
+    assert len(prof) == int(np.round(r.max()) + 1)
+    c2, p2 = radial_profile(np.floor(r), binsize=2)
+    assert c2[0] == 1.0 and len(p2) == int(np.round(r.max() / 2) + 1)
+
+
+def test_plot_psf_on_a_result_list(tmp_path):
+    """plot_psf (psfrec.py:826-858) on an HDUList and on the file written from it."""
+    import matplotlib
+    matplotlib.use('agg', force=True)
+    from muse_psfr_amd import _minifits as mf
+    from muse_psfr_amd import plot_psf
+    from muse_psfr_amd.psfrec import _table_hdu
+    lb = np.linspace(490, 930, 5)
+    x, y = np.ogrid[:40, :40]
+    psf = np.array([(1 + ((x - 20) ** 2 + (y - 20) ** 2) / (4.0 + k)) ** -2.5 for k in range(5)])
+    fit = _table_hdu({'lbda': lb, 'fwhm': np.repeat(np.linspace(0.8, 0.6, 5)[:, None], 2, axis=1),
+                      'n': np.linspace(2.7, 2.2, 5)}, {'SEEING': 1.0}, 'FIT_MEAN')
+    if isinstance(fit, mf.BinTableHDU):
+        hdul = mf.HDUList([mf.PrimaryHDU(), fit, mf.ImageHDU(data=psf, name='PSF_MEAN')])
+    else:
+        from astropy.io import fits
+        hdul = fits.HDUList([fits.PrimaryHDU(), fit, fits.ImageHDU(data=psf, name='PSF_MEAN')])
+    fig = plot_psf(hdul, npsflin=3)
+    assert len(fig.axes) == 7                    # 2 x 3 panels + the colour bar
+    titles = [a.get_title() for a in fig.axes]
+    assert 'PSF' in titles and 'radial profile' in titles
+    xs, ys = fig.axes[4].lines[0].get_data()     # FWHM(lambda) panel
+    np.testing.assert_allclose(xs, lb)
+    np.testing.assert_allclose(ys, np.linspace(0.8, 0.6, 5))
+    assert len(fig.axes[2].collections) == 2     # directions + LGS
+    fig.savefig(str(tmp_path / 'fig.png'))
+    out = str(tmp_path / 'res.fits')
+    hdul.writeto(out, overwrite=True)
+    fig2 = plot_psf(out)
+    fig2.savefig(str(tmp_path / 'fig2.png'))
+    assert os.path.getsize(str(tmp_path / 'fig2.png')) > 0

@@ -127,3 +127,24 @@ def test_sparta_golden_is_self_consistent(golden):
     fit = O.fit_psf_cube(g['psf_mean'][[0, 17, 34]])
     np.testing.assert_allclose(fit, g['fit_mean'][[0, 17, 34]], rtol=1e-7)
     np.testing.assert_allclose(O.fit_psf_cube(g['fin_row0'][[5]]), g['fit_rows'][0][[5]], rtol=1e-7)
+
+
+def test_oracle_reproduces_the_reference_sparta_front_end(golden, ref_masks):
+    """G7: the reference's own compute_psf_from_sparta (psfrec.py:981-1120, jittered LGS columns,
+    mean_of_lgs True / False) -- the oracle's compute_psf on the task values the reference
+    derived, for the 3-LGS row of each mode."""
+    g = golden('g7_sparta_lgs')
+    lb = np.linspace(float(g['lmin']), float(g['lmax']), int(g['nl']))
+    for tag in ('mean', 'lgs'):
+        rows = g[tag + '_rows_row_idx']
+        three_task = 2 if tag == 'mean' else 5            # row 2 lost a laser (psfrec.py:1053-1054)
+        sel = rows == three_task
+        see, gl, l0 = g[tag + '_rows_SEEING'][sel][0], g[tag + '_rows_GL'][sel][0], g[tag + '_rows_L0'][sel][0]
+        tabs = O.ao_tables(H, True, 1, masks=ref_masks)
+        fit, _ = O.compute_psf(lb, see, gl, l0, 1, H, True, tables=tabs)
+        np.testing.assert_allclose(fit[:, 3], g[tag + '_rows_fwhm'][sel][:, 0], atol=1e-9)
+        np.testing.assert_allclose(fit[:, 4], g[tag + '_rows_n'][sel], atol=1e-8)
+    # bookkeeping of the reference: one task per row / per valid laser, 1-based task index
+    assert g['mean_rows_lgs_idx'].tolist() == [-1] * 16
+    assert g['lgs_rows_lgs_idx'][::4].tolist() == [1, 2, 3, 4, 1, 2, 4, 1, 2, 3, 4, 1, 2, 3, 4]
+    assert g['lgs_rows_row_idx'][::4].tolist() == list(range(1, 16))
