@@ -47,19 +47,22 @@ def is_stale():
         return fh.read().strip() != source_hash()
 
 
-def build_library(force=False, verbose=True):
-    """Compile csrc/*.hip, csrc/*.cpp into muse_psfr_amd/libmpsfr.so.  Returns the path."""
-    if not force and not is_stale():
+def build_library(force=False, verbose=True, out=None, extra_flags=()):
+    """Compile csrc/*.hip, csrc/*.cpp into muse_psfr_amd/libmpsfr.so.  Returns the path.
+    `out` / `extra_flags`: build a variant (e.g. -DMPSFR_...=...) into another file, for kernel
+    experiments (load it with MPSFR_LIB_PATH)."""
+    variant = out is not None
+    if not variant and not force and not is_stale():
         return LIB
     hipcc = _hipcc()
-    build_id = source_hash()
+    build_id = source_hash() + ('+' + ' '.join(extra_flags) if variant else '')
     objs = []
-    bdir = os.path.join(HERE, 'build')
+    bdir = os.path.join(HERE, 'build' + ('_' + os.path.basename(out) if variant else ''))
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for src in SOURCES:          # the translation units compile in parallel
         obj = os.path.join(bdir, os.path.splitext(src)[0] + '.o')
-        cmd = [hipcc] + FLAGS + ['-DMPSFR_BUILD_ID="%s"' % build_id, '-x', 'hip', '-c',
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ['-DMPSFR_BUILD_ID="%s"' % build_id, '-x', 'hip', '-c',
                                  os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
@@ -68,13 +71,15 @@ def build_library(force=False, verbose=True):
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    target = out if variant else LIB
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', target] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
-    with open(STAMP, 'w') as fh:
-        fh.write(build_id + '\n')
-    return LIB
+    if not variant:
+        with open(STAMP, 'w') as fh:
+            fh.write(build_id + '\n')
+    return target
 
 
 if __name__ == '__main__':

@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libmpsfr.so')
+# MPSFR_LIB_PATH: load another build of the library (kernel experiments, scripts/variants.py)
+LIB_PATH = os.environ.get('MPSFR_LIB_PATH') or os.path.join(HERE, 'libmpsfr.so')
 
 NFIT = 16
 DIM_AO = 80

@@ -557,12 +557,24 @@ __device__ __forceinline__ double lean_log(double x) {
     return l0 + d * fma(d, fma(d, 1.0 / 3.0, -0.5), 1.0);
 }
 
-// Normal equations of the Moffat model at v = (I, p0, q0, w, n), 1/a^2 = 4 (2^(1/n) - 1) / w^2,
+// Normal equations of the Moffat model at v = (I, p0, q0, w, eta), eta = 1/n,
+// 1/a^2 = 4 (2^eta - 1) / w^2,
 // over the lane's pixels o = lane + 64 m of the stamp `pix` (LDS), summed over the wave.
 // Cross-lane sums run in the evaluation type: the float phase only has to reach the basin of
 // convergence (tol 1e-3); the f64 mode reduces in double.  Every lane ends up with the totals.
 template <typename RE>
-__device__ __forceinline__ void moffat_accumulate(const RE* pix, int lane, const double* v,
+__device__ __forceinline__ RE fit_exp2m1(RE eta);           // 2^eta - 1, eta in (0, 100)
+template <>
+__device__ __forceinline__ float fit_exp2m1<float>(float eta) {
+    return __builtin_amdgcn_exp2f(eta) - 1.0f;
+}
+template <>
+__device__ __forceinline__ double fit_exp2m1<double>(double eta) {
+    return lean_exp(0.69314718055994530942 * eta) - 1.0;
+}
+
+template <typename RE>
+__device__ __forceinline__ void moffat_accumulate(const RE* pix, int lane, const RE* v,
                                                   NormEqT<RE>& ne) {
     constexpr int NPX = NS * NS / 64;
     RE a[15], g[5], chi2 = (RE)0;
@@ -570,13 +582,16 @@ __device__ __forceinline__ void moffat_accumulate(const RE* pix, int lane, const
     for (int k = 0; k < 15; ++k) a[k] = (RE)0;
 #pragma unroll
     for (int k = 0; k < 5; ++k) g[k] = (RE)0;
-    const double n_d = v[4];
-    const double s_d = lean_exp(0.69314718055994530942 / n_d) - 1.0;       // 2^(1/n) - 1
-    const double K_d = 4.0 * s_d / (v[3] * v[3]);
-    // d(1/a^2)/dn / (1/a^2) = s'/s with s' = -2^(1/n) ln2 / n^2
-    const double dKn_d = -(s_d + 1.0) * 0.69314718055994530942 / (n_d * n_d * s_d);
-    const RE I = (RE)v[0], p0 = (RE)v[1], q0 = (RE)v[2], n = (RE)n_d, K = (RE)K_d;
-    const RE i3 = (RE)(1.0 / v[3]), dKn = (RE)dKn_d;
+    // wave-uniform scalars in the evaluation type: in the mixed mode the whole LM phase is float
+    // (fp64 here put ~40 double instructions and four double divisions on the serial path of
+    // every iteration); the fp64 polish of k_fit removes what that costs in accuracy
+    const RE n = fit_rcp<RE>(v[4]);                                         // v[4] = eta = 1/n
+    const RE s_ = fit_exp2m1<RE>(v[4]);                                     // 2^eta - 1
+    const RE i3 = fit_rcp<RE>(v[3]);
+    const RE K = (RE)4 * s_ * i3 * i3;
+    // d(1/a^2)/d eta / (1/a^2) = s'/s with s' = 2^eta ln2
+    const RE dKn = (s_ + (RE)1) * (RE)0.69314718055994530942 * fit_rcp<RE>(s_);
+    const RE I = v[0], p0 = v[1], q0 = v[2], nsq = n * n;
 #pragma unroll 5
     for (int m = 0; m < NPX; ++m) {
         const int o = lane + m * 64;
@@ -594,7 +609,7 @@ __device__ __forceinline__ void moffat_accumulate(const RE* pix, int lane, const
         J[1] = cm * (RE)2 * K * dp;
         J[2] = cm * (RE)2 * K * dq;
         J[3] = cm * (RE)2 * K * u * i3;
-        J[4] = -mo * lg - cm * u * K * dKn;
+        J[4] = nsq * mo * lg - cm * u * K * dKn;         // d model / d eta
         int k = 0;
 #pragma unroll
         for (int x = 0; x < 5; ++x) {
@@ -639,19 +654,20 @@ __device__ __forceinline__ double sgpr(double x) {
 }
 
 __device__ __forceinline__ void moffat_gradient(const double* __restrict__ src, int lane,
-                                                const double* v, double* gout) {
+                                                const double* v, double* gout, double* chi2out) {
     // Only the residual r = model - data needs fp64: a systematic 1e-6 error of the float
     // log/exp model is what biases the fit.  The Jacobian multiplies r, which is ~1e-3 of the
     // peak at the solution, so its float rounding (6e-8, unbiased) moves the fixed point by
     // ~1e-10: J, the products J r and the 25 per-lane partial sums run in float (a third of the
     // fp64 instructions of an all-fp64 gradient).
-    const double n = sgpr(v[4]);
-    const double s = lean_exp(0.69314718055994530942 / n) - 1.0;
+    const double n = sgpr(1.0 / v[4]);
+    const double s = lean_exp(0.69314718055994530942 * v[4]) - 1.0;
     const double K = sgpr(4.0 * s / (v[3] * v[3]));
-    const float dKn = (float)sgpr(-(s + 1.0) * 0.69314718055994530942 / (n * n * s));
+    const float dKn = (float)sgpr((s + 1.0) * 0.69314718055994530942 / s);
+    const float nsq = (float)(n * n);
     const double I = sgpr(v[0]), p0 = sgpr(v[1]), q0 = sgpr(v[2]);
     const float i3 = (float)sgpr(1.0 / v[3]), nf = (float)n, K2 = 2.0f * (float)K, Kf = (float)K;
-    float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, c2sum = 0.f;
 #pragma unroll 5
     for (int m = 0; m < NS * NS / 64; ++m) {
         const int o = lane + m * 64;
@@ -662,6 +678,7 @@ __device__ __forceinline__ void moffat_gradient(const double* __restrict__ src, 
         const double e = lean_exp(-n * lg);
         const double mo = I * e;
         const float r = (float)(mo - src[o]);
+        c2sum += r * r;
         const float mof = (float)mo, uf = (float)u;
         const float cm = mof * nf * __builtin_amdgcn_rcpf((float)gg);
         const float c2 = cm * K2 * r;
@@ -669,10 +686,11 @@ __device__ __forceinline__ void moffat_gradient(const double* __restrict__ src, 
         g[1] += c2 * (float)dp;
         g[2] += c2 * (float)dq;
         g[3] += c2 * uf * i3;
-        g[4] += (-mof * (float)lg - cm * uf * Kf * dKn) * r;
+        g[4] += (nsq * mof * (float)lg - cm * uf * Kf * dKn) * r;
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) gout[k] = wave_total((double)g[k]);    // lanes cancel: fp64
+    *chi2out = (double)wave_total(c2sum);
 }
 
 // Cholesky factor of the Marquardt-scaled normal matrix  A'_ij = A_ij / (d_i d_j) + mu delta_ij,
@@ -680,7 +698,7 @@ __device__ __forceinline__ void moffat_gradient(const double* __restrict__ src, 
 // is what lets the float phase factor it in float.  Fully unrolled: the factor lives in registers
 // (dynamic indexing put it in scratch).  Li holds 1 / L_ii.  Returns false if not positive definite.
 template <typename S, typename T>
-__device__ __forceinline__ bool chol5(const NormEqT<T>& ne, double mu, S L[5][5], S Li[5], S id[5]) {
+__device__ __forceinline__ bool chol5(const NormEqT<T>& ne, S mu, S L[5][5], S Li[5], S id[5]) {
     S A[5][5];
     {
         int k = 0;
@@ -704,7 +722,7 @@ __device__ __forceinline__ bool chol5(const NormEqT<T>& ne, double mu, S L[5][5]
 #pragma unroll
         for (int j = 0; j < 5; ++j) L[i][j] = A[i][j] * id[i] * id[j];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) L[i][i] = (S)(1.0 + mu);
+    for (int i = 0; i < 5; ++i) L[i][i] = (S)1 + mu;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         S s = L[j][j];
@@ -725,9 +743,9 @@ __device__ __forceinline__ bool chol5(const NormEqT<T>& ne, double mu, S L[5][5]
 }
 
 // x = A^-1 b through the factor of chol5 (b and x in unscaled units)
-template <typename S>
+template <typename S, typename X>
 __device__ __forceinline__ void chol5_solve(const S L[5][5], const S Li[5], const S id[5],
-                                            const S b[5], double* x) {
+                                            const S b[5], X* x) {
     S y[5], z[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -744,17 +762,17 @@ __device__ __forceinline__ void chol5_solve(const S L[5][5], const S Li[5], cons
         z[i] = t * Li[i];
     }
 #pragma unroll
-    for (int i = 0; i < 5; ++i) x[i] = (double)(z[i] * id[i]);
+    for (int i = 0; i < 5; ++i) x[i] = (X)(z[i] * id[i]);
 }
 
 // solve (A + mu diag(A)) x = -g; S = arithmetic type of the factorisation
 template <typename S, typename T>
-__device__ __forceinline__ bool lm_solve(const NormEqT<T>& ne, double mu, double* x) {
+__device__ __forceinline__ bool lm_solve(const NormEqT<T>& ne, S mu, S* x) {
     S L[5][5], Li[5], id[5], b[5];
     if (!chol5<S, T>(ne, mu, L, Li, id)) return false;
 #pragma unroll
     for (int i = 0; i < 5; ++i) b[i] = -(S)ne.g[i];
-    chol5_solve<S>(L, Li, id, b, x);
+    chol5_solve<S, S>(L, Li, id, b, x);
     return true;
 }
 
@@ -763,14 +781,14 @@ __device__ __forceinline__ bool lm_solve(const NormEqT<T>& ne, double mu, double
 template <typename T>
 __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][5]) {
     T L[5][5], Li[5], id[5];
-    if (!chol5<T, T>(ne, 0.0, L, Li, id)) return false;
+    if (!chol5<T, T>(ne, (T)0, L, Li, id)) return false;
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
         T b[5];
         double x[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) b[k] = (k == c) ? (T)1 : (T)0;
-        chol5_solve<T>(L, Li, id, b, x);
+        chol5_solve<T, double>(L, Li, id, b, x);
 #pragma unroll
         for (int k = 0; k < 5; ++k) cov[k][c] = x[k];
     }
@@ -778,10 +796,10 @@ __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][
 }
 
 // A polish step of relative size `rel` leaves an error of about c * rel, c = the contraction
-// factor of the iteration (error of the float Gauss-Newton matrix, <~ 1e-2): steps below 3e-4 end
-// the polish without a further gradient pass (error <~ 3e-6, under what the fp32 stamps allow).
+// factor of the iteration (error of the float Gauss-Newton matrix, <~ 1e-2): steps below 1e-4 end
+// the polish without a further gradient pass (error <~ 1e-6, under what the fp32 stamps allow).
 #ifndef MPSFR_POLISH_TOL
-#define MPSFR_POLISH_TOL 3.0e-4
+#define MPSFR_POLISH_TOL 1.0e-4
 #endif
 #ifndef MPSFR_FIT_WAVES
 #define MPSFR_FIT_WAVES 4
@@ -797,6 +815,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fit_mi
 k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
     constexpr int NPX = NS * NS / 64;                     // 25 pixels per lane
     static_assert(NPX * 64 == NS * NS, "the lane map assumes 1600 pixels");
+    using S = RE;                                         // type of the LM state
     const int lane = threadIdx.x & 63;
     const int st = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (st >= nstamp) return;                             // the whole wave exits together
@@ -829,35 +848,43 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     // start values: peak and its position, FWHM from the area above half maximum, n = 2.5.
     // (The least-squares minimum is unique -- SURVEY.md 8(c) -- so the start only sets the
-    // iteration count; the oracle starts from fwhm = 4 px, n = 2.)
+    // iteration count; the oracle starts from fwhm = 4 px, n = 2.  A start from two points of
+    // the radial profile saved 0.3 iterations on average and cost more than it saved.)
     double fw0 = 2.0 * sqrt((double)cnt / kPi);
     fw0 = fmin(fmax(fw0, 1.5), (double)NS);
-    double v[5] = {best, (double)(besto / NS), (double)(besto % NS), fw0, 2.5};
+    // LM variables (I, p0, q0, w = FWHM, eta = 1/n): towards broad, Gaussian-like profiles the
+    // model is nearly linear in 1/n, and the valley that n -> large opens in (w, n) stays short --
+    // at most 4 iterations where the fit in n took up to 29
+    S v[5] = {(S)best, (S)(besto / NS), (S)(besto % NS), (S)fw0, (S)0.4};
     // float evaluation only has to reach the basin of quadratic convergence: the fp64 polish
     // below finishes the job.  Every lane carries the same LM state (the totals of
     // moffat_accumulate are wave-uniform), so the control flow is uniform.
-    const double tol = sizeof(RE) == 4 ? 1.0e-3 : 1.0e-10;
+    const S tol = sizeof(RE) == 4 ? (S)1.0e-3 : (S)1.0e-10;
     NormEqT<RE> ne;
     moffat_accumulate<RE>(sp, lane, v, ne);
-    double mu = 1.0e-2, nu = 2.0;
+    S mu = (S)1.0e-2, nu = (S)2;
+    const S mu_max = sizeof(RE) == 4 ? (S)1.0e15f : (S)1.0e15;
     int it = 0, status = 1;
-    const int maxit = 200;
+#ifndef MPSFR_FIT_MAXIT
+#define MPSFR_FIT_MAXIT 200
+#endif
+    const int maxit = MPSFR_FIT_MAXIT;
     while (it < maxit) {
         ++it;
-        double dx[5];
-        if (!lm_solve<RE, RE>(ne, mu, dx)) {
+        S dx[5];
+        if (!lm_solve<S, RE>(ne, mu, dx)) {
             mu *= nu;
-            nu *= 2.0;
-            if (mu > 1.0e15) { status = 2; break; }
+            nu *= (S)2;
+            if (mu > mu_max) { status = 2; break; }
             continue;
         }
-        double vn[5], rel = 0.0;
+        S vn[5], rel = (S)0;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             vn[k] = v[k] + dx[k];
-            rel = fmax(rel, fabs(dx[k]) / (fabs(vn[k]) + 1.0e-300));
+            rel = fmax(rel, fabs(dx[k]) * fit_rcp<S>(fabs(vn[k]) + (S)1.0e-30));
         }
-        const bool inside = vn[3] > 1.0e-3 && vn[4] > 1.0e-2 && vn[4] < 1.0e3;
+        const bool inside = vn[3] > (S)1.0e-3 && vn[4] > (S)1.0e-3 && vn[4] < (S)1.0e2;
         if (inside && rel < tol) {       // converged: take the last (tiny) Gauss-Newton step
 #pragma unroll
             for (int k = 0; k < 5; ++k) v[k] = vn[k];
@@ -865,30 +892,34 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
             break;
         }
         NormEqT<RE> nn;
-        double rho = -1.0;
+        S rho = (S)-1;
         if (inside) {
             moffat_accumulate<RE>(sp, lane, vn, nn);
             // predicted decrease of chi2: dx^T (mu D dx - g)
-            double pred = 0.0;
+            S pred = (S)0;
             const int dg[5] = {0, 5, 9, 12, 14};
 #pragma unroll
             for (int k = 0; k < 5; ++k)
-                pred += dx[k] * (mu * (double)ne.a[dg[k]] * dx[k] - (double)ne.g[k]);
-            rho = ((double)ne.chi2 - (double)nn.chi2) / pred;    // NaN -> rejected
+                pred += dx[k] * (mu * (S)ne.a[dg[k]] * dx[k] - (S)ne.g[k]);
+            rho = ((S)ne.chi2 - (S)nn.chi2) * fit_rcp<S>(pred);    // NaN -> rejected
         }
-        if (rho > 0.0) {
+        if (rho > (S)0) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) v[k] = vn[k];
             ne = nn;
-            const double c = 2.0 * rho - 1.0;
-            mu = fmax(mu * fmax(1.0 / 3.0, 1.0 - c * c * c), 1.0e-14);
-            nu = 2.0;
+            const S c = (S)2 * rho - (S)1;
+            mu = fmax(mu * fmax((S)(1.0 / 3.0), (S)1 - c * c * c), (S)1.0e-14);
+            nu = (S)2;
         } else {
             mu *= nu;
-            nu *= 2.0;
-            if (mu > 1.0e15) { status = 0; break; }   // no further descent: at the minimum
+            nu *= (S)2;
+            if (mu > mu_max) { status = 0; break; }   // no further descent: at the minimum
         }
     }
+    double vd[5];                          // from here on in fp64
+#pragma unroll
+    for (int k = 0; k < 5; ++k) vd[k] = (double)v[k];
+    double polish_chi2 = -1.0;
     if constexpr (sizeof(RE) == 4) {
         // The float evaluation has systematic errors of ~1e-6 in the wings (v_log/v_exp), enough
         // to move beta by a few 1e-4 on flat-topped stamps.  Polish from the float solution with
@@ -897,38 +928,45 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
         NormEq np;
 #pragma unroll
         for (int k = 0; k < 15; ++k) np.a[k] = (double)ne.a[k];
-        np.chi2 = 0.0;
-        for (int pz = 0; pz < 8 && status != 2; ++pz) {
-            moffat_gradient(src, lane, v, np.g);
+        np.chi2 = -1.0;
+#ifndef MPSFR_POLISH_MAX
+#define MPSFR_POLISH_MAX 8
+#endif
+        for (int pz = 0; pz < MPSFR_POLISH_MAX && status != 2; ++pz) {
+            moffat_gradient(src, lane, vd, np.g, &np.chi2);
             double dx[5];
             if (!lm_solve<double, double>(np, 1.0e-10, dx)) break;
             double rel = 0.0;
 #pragma unroll
             for (int k = 0; k < 5; ++k)
-                rel = fmax(rel, fabs(dx[k]) / (fabs(v[k] + dx[k]) + 1.0e-300));
-            const bool inside = v[3] + dx[3] > 1.0e-3 && v[4] + dx[4] > 1.0e-2 &&
-                                v[4] + dx[4] < 1.0e3 && rel < 0.1;
+                rel = fmax(rel, fabs(dx[k]) / (fabs(vd[k] + dx[k]) + 1.0e-300));
+            const bool inside = vd[3] + dx[3] > 1.0e-3 && vd[4] + dx[4] > 1.0e-3 &&
+                                vd[4] + dx[4] < 1.0e2 && rel < 0.1;
             if (!inside) break;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) v[k] += dx[k];
+            for (int k = 0; k < 5; ++k) vd[k] += dx[k];
             ++it;
+            polish_chi2 = rel < 1.0e-3 ? np.chi2 : -1.0;
             if (rel < MPSFR_POLISH_TOL) break;      // error after this step ~ 1e-3 rel
         }
     }
-    // Outputs in (a, n).  chi2 is evaluated at the final point (residuals only); the covariance
-    // comes from the normal matrix of the last LM iteration (in (w, n), a point within ~1e-4 of
-    // the final one for well-posed stamps) -- no further Jacobian pass.  I, p0, q0, n are the
-    // same variables in both parametrisations, so their variances carry over; FWHM = w directly;
-    // alpha = w / (2 sqrt(2^(1/n) - 1)) through its partial derivatives.
-    const double n = v[4];
+    // Outputs in (a, n).  The covariance comes from the normal matrix of the last LM iteration (in
+    // (w, eta), a point within ~1e-4 of the final one for well-posed stamps) -- no further
+    // Jacobian pass.  I, p0, q0 are the same variables in both parametrisations, so their
+    // variances carry over; FWHM = w directly; n = 1/eta and alpha = w / (2 sqrt(2^eta - 1))
+    // through their partial derivatives.
+    const double n = 1.0 / vd[4];
     const double p2 = exp2(1.0 / n), s2 = p2 - 1.0, sq = sqrt(s2);
-    const double al = fabs(v[3]) / (2.0 * sq);
-    const double va[5] = {v[0], v[1], v[2], al, n};
-    const double chi2 = (double)moffat_chi2<RE>(sp, lane, va);
+    const double al = fabs(vd[3]) / (2.0 * sq);
+    const double va[5] = {vd[0], vd[1], vd[2], al, n};
+    // chi2: the residuals of the last polish pass (fp64 model; one step of relative size < 1e-3
+    // before the final point, so equal to first order) or, without a polish, a residual pass
+    double chi2 = polish_chi2;
+    if (chi2 < 0.0) chi2 = (double)moffat_chi2<RE>(sp, lane, va);
     if (lane == 0) {
         double* o = fit + (size_t)st * NFIT;
-        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = al; o[4] = n;
-        o[5] = fabs(v[3]);
+        o[0] = vd[0]; o[1] = vd[1]; o[2] = vd[2]; o[3] = al; o[4] = n;
+        o[5] = fabs(vd[3]);
         o[6] = chi2;
         o[7] = (double)it;
         double cov[5][5];
@@ -939,17 +977,17 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
             o[9] = sqrt(fmax(cov[1][1] * s, 0.0));
             o[10] = sqrt(fmax(cov[2][2] * s, 0.0));
             const double aw = 1.0 / (2.0 * sq);
-            const double an = al * p2 * 0.69314718055994530942 / (2.0 * s2 * n * n);
+            const double an = -al * p2 * 0.69314718055994530942 / (2.0 * s2);     // d alpha / d eta
             const double var = aw * aw * cov[3][3] + 2.0 * aw * an * cov[3][4] + an * an * cov[4][4];
             o[11] = sqrt(fmax(var * s, 0.0));
-            o[12] = sqrt(fmax(cov[4][4] * s, 0.0));
+            o[12] = n * n * sqrt(fmax(cov[4][4] * s, 0.0));                        // |dn/d eta| = n^2
             o[13] = sqrt(fmax(cov[3][3] * s, 0.0));
         } else {
             for (int k = 0; k < 6; ++k) o[8 + k] = 0.0;
             if (status == 0) status = 2;
         }
         o[14] = (double)status;
-        o[15] = v[0] * kPi * al * al / (n - 1.0);
+        o[15] = vd[0] * kPi * al * al / (n - 1.0);
     }
 }
 
