@@ -29,6 +29,24 @@ __device__ __forceinline__ size_t g_index(int v, int j) {
         return (size_t)v * NS + j;
 }
 
+// Layout of the sampled first-pass lines Tq within one (task, wavelength) block.  fp64: [v][i].
+// fp32 (consumed by the MFMA second pass): lines padded to a multiple of 8 and stored as
+// [v / 8][i][v % 4][(v / 4) % 2]: the lane that supplies A[row i][k = v % 4] to two consecutive
+// k-steps fetches both elements with one 16-byte load, and the 64 lanes of a 16-row tile read one
+// contiguous KiB (with [v][i] a wave-load was four 128-byte pieces of 8-byte elements, and the
+// second pass was bound by its request rate, not by HBM).
+template <typename R>
+__host__ __device__ constexpr int tq_block(int N) {
+    return (sizeof(R) == 4 ? g_lines(N) : N / 2 + 1) * NSH;
+}
+template <typename R>
+__device__ __forceinline__ size_t tq_index(int v, int i) {
+    if constexpr (sizeof(R) == 4)
+        return ((size_t)((v >> 3) * NSH + i) * 4 + (v & 3)) * 2 + ((v >> 2) & 1);
+    else
+        return (size_t)v * NSH + i;
+}
+
 template <typename R>
 __global__ void __launch_bounds__(256)
 k_gtable(int N, const LamPar* __restrict__ lp, const cx<double>* __restrict__ twg,
@@ -177,7 +195,7 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
                     f0 = {h * (zp.y + zmp.y), -h * (zp.x - zmp.x)};
                     f1 = {h * (zq.y + zmq.y), -h * (zq.x - zmq.x)};
                 }
-                Tq[(((size_t)task * nl + ll) * (N / 2 + 1) + v) * NSH + i] = {
+                Tq[((size_t)task * nl + ll) * tq_block<R>(N) + tq_index<R>(v, i)] = {
                     ((R)1 - w) * f0.x + w * f1.x, ((R)1 - w) * f0.y + w * f1.y};
             }
         }
@@ -214,7 +232,8 @@ k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool act = lane < 56;
     const int i0 = TI * (act ? lane >> 3 : 0), j0 = TJ * (lane & 7);
-    const cx<R>* Tp = Tq + ((size_t)task * nl + l) * NV * NSH;
+    static_assert(sizeof(R) == 8, "the tiled second pass reads the fp64 [v][i] layout");
+    const cx<R>* Tp = Tq + ((size_t)task * nl + l) * tq_block<R>(N);
     const cx<R>* Gp = G + (size_t)l * g_lines(N) * NS;
     R accP[TI][TJ], accQ[TI][TJ];
 #pragma unroll
@@ -322,8 +341,11 @@ k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
 // 82 % of the multiplies are useful; P and Q share their operand loads (T and G are complex).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MPSFR_COLPASS_WAVES
+#define MPSFR_COLPASS_WAVES 4
+#endif
 template <int N>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MPSFR_COLPASS_WAVES)))
 k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>* __restrict__ G,
             float* __restrict__ pre) {
     constexpr int NV = N / 2 + 1, TPG = 3, MT = 4, NT = 3, NCOL = NT * 16;
@@ -336,9 +358,12 @@ k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>
     // wave w owns row tile w (all lines, all columns): no cross-wave reduction
     const int r = 16 * wave + lr, tl = r / NSH, i = r - tl * NSH;
     const bool aok = tl < TPG && tg * TPG + tl < ntask;
-    // rows without a task read the group's first task (valid memory); they are never used
-    const cx<float>* ap = Tq + ((size_t)(aok ? tg * TPG + tl : tg * TPG) * nl + l) * NV * NSH +
-                          (aok ? i : 0);
+    // rows without a task read the group's first task (valid memory); they are never used.
+    // A: Tq in the layout of tq_index<float>: one 16-byte load carries this lane's element for
+    // k-steps 2 s and 2 s + 1 (lines 8 s + lk and 8 s + 4 + lk)
+    const f32x4* ap = reinterpret_cast<const f32x4*>(
+                          Tq + ((size_t)(aok ? tg * TPG + tl : tg * TPG) * nl + l) * tq_block<float>(N)) +
+                      (size_t)(aok ? i : 0) * 4 + lk;
     // B: G in the paired-line layout of g_index<float>: one 16-byte load carries this lane's
     // element for k-steps 2 s and 2 s + 1 (lines 8 s + lk and 8 s + 4 + lk)
     constexpr int NG = g_lines(N) / 8;                   // double steps
@@ -362,10 +387,10 @@ k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>
     auto load = [&](int s, Ops& o) {
         const int sc = s < NG ? s : NG - 1;              // past the end: any valid address
         const int v0 = 8 * sc + lk, v1 = v0 + 4;
-        const cx<float> t0 = ap[(size_t)(v0 < NV ? v0 : NV - 1) * NSH];
-        const cx<float> t1 = ap[(size_t)(v1 < NV ? v1 : NV - 1) * NSH];
-        o.a0 = (s < NG && v0 < NV) ? t0 : cx<float>{0.f, 0.f};     // line padding: A = 0
-        o.a1 = (s < NG && v1 < NV) ? t1 : cx<float>{0.f, 0.f};
+        const f32x4 t = ap[(size_t)sc * NSH * 4];
+        // line padding (never written by K_OTF_ROWFFT) and steps past the end: A = 0
+        o.a0 = (s < NG && v0 < NV) ? cx<float>{t[0], t[1]} : cx<float>{0.f, 0.f};
+        o.a1 = (s < NG && v1 < NV) ? cx<float>{t[2], t[3]} : cx<float>{0.f, 0.f};
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) o.b[ct] = bp[ct][(size_t)sc * 4 * NS];
     };
@@ -382,7 +407,8 @@ k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>
         }
     };
     // two operand sets, roles swapped inside the body (no register rotation at the back edge);
-    // the loop is branch-free: double steps past the end load valid memory with A = 0
+    // the loop is branch-free: double steps past the end load valid memory with A = 0.  (A ring
+    // of four sets -- three double steps of loads in flight -- measured no faster.)
     Ops oa, ob;
     load(0, oa);
     for (int s = 0; s < NG; s += 2) {
@@ -459,7 +485,10 @@ static void launch_otf_t(hipStream_t s, int ntask, int ndir, int nl, const void*
                          const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
                          const void* d_samp_a, void* d_Tq, const void* d_tw64) {
     constexpr int SL = LineCfg<NN>::SLOTS;
-    constexpr size_t sm = fft_smem<R, NN>(!use_reg_twiddles<NN>(), fft_nbuf<NN>());
+#ifndef MPSFR_OTF_EXTRA_LDS
+#define MPSFR_OTF_EXTRA_LDS 0
+#endif
+    constexpr size_t sm = fft_smem<R, NN>(!use_reg_twiddles<NN>(), fft_nbuf<NN>()) + MPSFR_OTF_EXTRA_LDS;
     allow_smem(k_otf_rowfft<R, NN, ND, FE>, sm);
     dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntask);
     hipLaunchKernelGGL((k_otf_rowfft<R, NN, ND, FE>), grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir,
