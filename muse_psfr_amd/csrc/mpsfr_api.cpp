@@ -675,8 +675,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         if ((rc = ensure(c, ln.C, (size_t)TC * ndir * (N / 2 + NAO / 2) * H1 * 2 * sizeof(double)))) return rc;
         if ((rc = ensure(c, ln.s00, (size_t)TC * ndir * sizeof(double)))) return rc;
         if ((rc = ensure(c, ln.D0t, (size_t)TC * ndir * H1 * N * rsize(c)))) return rc;
-        // (lines padded to a multiple of 8: paired-line layout of the fp32 second pass)
-        if ((rc = ensure(c, ln.Tq, (size_t)TC * nl * ((H1 + 7) / 8 * 8) * NSH * 2 * rsize(c)))) return rc;
+        if ((rc = ensure(c, ln.Tq, (size_t)TC * nl * H1 * NSH * 2 * rsize(c)))) return rc;
         if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * (c->f64 ? 8 : 4)))) return rc;
         if ((rc = ensure(c, ln.fin, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
     }

@@ -29,22 +29,19 @@ __device__ __forceinline__ size_t g_index(int v, int j) {
         return (size_t)v * NS + j;
 }
 
-// Layout of the sampled first-pass lines Tq within one (task, wavelength) block.  fp64: [v][i].
-// fp32 (consumed by the MFMA second pass): lines padded to a multiple of 8 and stored as
-// [v / 8][i][v % 4][(v / 4) % 2]: the lane that supplies A[row i][k = v % 4] to two consecutive
-// k-steps fetches both elements with one 16-byte load, and the 64 lanes of a 16-row tile read one
-// contiguous KiB (with [v][i] a wave-load was four 128-byte pieces of 8-byte elements, and the
-// second pass was bound by its request rate, not by HBM).
+// Layout of the sampled first-pass lines Tq within one (task, wavelength) block: [v][i], i.e. the
+// 21 samples of a line are one contiguous 168-byte run written by the wave that owns the line.
+// (A paired-line layout [v / 8][i][v % 4][(v / 4) % 2], which gives the MFMA second pass 16-byte
+// coalesced operand loads, made that pass 10 % faster but doubled the HBM write traffic of
+// K_OTF_ROWFFT: four waves then fill each 32-byte piece at different times and the partly
+// written lines leave the L2 before they are complete -- WRITE_SIZE 305 MB against 156 MB.)
 template <typename R>
 __host__ __device__ constexpr int tq_block(int N) {
-    return (sizeof(R) == 4 ? g_lines(N) : N / 2 + 1) * NSH;
+    return (N / 2 + 1) * NSH;
 }
 template <typename R>
 __device__ __forceinline__ size_t tq_index(int v, int i) {
-    if constexpr (sizeof(R) == 4)
-        return ((size_t)((v >> 3) * NSH + i) * 4 + (v & 3)) * 2 + ((v >> 2) & 1);
-    else
-        return (size_t)v * NSH + i;
+    return (size_t)v * NSH + i;
 }
 
 template <typename R>
@@ -97,7 +94,14 @@ __device__ __forceinline__ R exp_sel(R x) {
     }
 }
 
-template <typename R, int N, int ND, bool FASTEXP>
+// LDS table of the extraction, one entry per (wavelength, sample i <= 20): the positions of
+// Z[p], Z[-p], Z[p+1], Z[-p-1] in the finished line (lds_out indices) and the bilinear weight.
+struct SampOff {
+    unsigned short p, mp, q, mq;
+};
+constexpr int kOtfLdsTabMaxNl = 128;      // above this the table would crowd the line buffers
+
+template <typename R, int N, int ND, bool FASTEXP, bool LTAB>
 __global__ void __launch_bounds__(LineCfg<N>::THREADS)
 k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ telT,
              const LamPar* __restrict__ lp, const int* __restrict__ samp_p,
@@ -111,6 +115,10 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
     cx<R>* twl = reinterpret_cast<cx<R>*>(smem);          // only used when !REGTW
     cx<R>* bufA = twl + (REGTW ? 0 : NPAD);
     cx<R>* bufB = bufA + SLOTS * NPAD;
+    // after the line buffers: [nl][NSH] SampOff, [nl][NSH] weights, [nl] exponent factors
+    SampOff* stab = reinterpret_cast<SampOff*>(bufA + fft_nbuf<N>() * SLOTS * NPAD);
+    R* swt = reinterpret_cast<R*>(stab + (LTAB ? nl * NSH : 0));
+    R* scl = swt + (LTAB ? nl * NSH : 0);
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
     const int v = blockIdx.x * SLOTS + slot;
     const int task = blockIdx.y;
@@ -125,8 +133,23 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
         for (int i = threadIdx.x; i < N; i += THREADS)
             twl[lds_pad(i)] = {(R)twg[i].x, (R)twg[i].y};
         twp = twl;
-        __syncthreads();
     }
+    if constexpr (LTAB) {
+        // Nothing inside the wavelength loop reads global memory: every wait on the vector-memory
+        // counter there would also wait for the Tq stores of the wavelength before (the counter
+        // is in issue order), i.e. expose a store round trip per transform.
+        for (int e = threadIdx.x; e < nl * NSH; e += THREADS) {
+            const int ll = e / NSH, i = e - ll * NSH;
+            const int p = samp_p[ll * NS + i];
+            const int q = p + 1 == N ? 0 : p + 1;
+            const int mp = p == 0 ? 0 : N - p, mq = q == 0 ? 0 : N - q;
+            stab[e] = {(unsigned short)lds_out<N, sizeof(cx<R>)>(p), (unsigned short)lds_out<N, sizeof(cx<R>)>(mp),
+                       (unsigned short)lds_out<N, sizeof(cx<R>)>(q), (unsigned short)lds_out<N, sizeof(cx<R>)>(mq)};
+            swt[e] = samp_a[ll * NS + i];
+        }
+        for (int e = threadIdx.x; e < nl; e += THREADS) scl[e] = exp_scale<R, FASTEXP>((R)lp[e].c);
+    }
+    if constexpr (LTAB || !REGTW) __syncthreads();
     cx<R>* a = bufA + slot * NPAD;
     cx<R>* b = bufB + slot * NPAD;     // only used when a slot spans two wavefronts
     // Single direction, hardware exp2: the telescope OTF goes into the exponent,
@@ -145,11 +168,21 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
 #pragma unroll
         for (int e = 0; e < EPT; ++e) dreg[e] = dline[t + e * TPR];
     }
+    // the line is in registers before the loop starts (vmcnt(0)): the compiler then places no
+    // vector-memory wait inside the loop, where it would also wait for the stores in flight
+    if constexpr (ND == 1 && LTAB) __builtin_amdgcn_s_waitcnt(0x0F70);
+    cx<R>* tq_task = Tq + (size_t)task * nl * tq_block<R>(N);
     // two wavelengths per complex transform: z = otf(la) + i otf(lb), both real lines
     for (int l = 0; l < nl; l += 2) {
         const bool two = l + 1 < nl;
-        const R ca = exp_scale<R, FASTEXP>((R)lp[l].c);
-        const R cb = exp_scale<R, FASTEXP>((R)lp[two ? l + 1 : l].c);
+        R ca, cb;
+        if constexpr (LTAB) {
+            ca = scl[l];
+            cb = scl[two ? l + 1 : l];
+        } else {
+            ca = exp_scale<R, FASTEXP>((R)lp[l].c);
+            cb = exp_scale<R, FASTEXP>((R)lp[two ? l + 1 : l].c);
+        }
         cx<R> x[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
@@ -180,12 +213,20 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
                 const int which = idx / NSH, i = idx - which * NSH;
                 if (which == 1 && !two) continue;
                 const int ll = l + which;
-                const int p = samp_p[ll * NS + i];
-                const R w = samp_a[ll * NS + i];
-                const int q = p + 1 == N ? 0 : p + 1;
-                const int mp = p == 0 ? 0 : N - p, mq = q == 0 ? 0 : N - q;
-                const cx<R> zp = res[lds_out<N, sizeof(cx<R>)>(p)], zmp = res[lds_out<N, sizeof(cx<R>)>(mp)];
-                const cx<R> zq = res[lds_out<N, sizeof(cx<R>)>(q)], zmq = res[lds_out<N, sizeof(cx<R>)>(mq)];
+                cx<R> zp, zmp, zq, zmq;
+                R w;
+                if constexpr (LTAB) {
+                    const SampOff o = stab[ll * NSH + i];
+                    w = swt[ll * NSH + i];
+                    zp = res[o.p]; zmp = res[o.mp]; zq = res[o.q]; zmq = res[o.mq];
+                } else {
+                    const int p = samp_p[ll * NS + i];
+                    w = samp_a[ll * NS + i];
+                    const int q = p + 1 == N ? 0 : p + 1;
+                    const int mp = p == 0 ? 0 : N - p, mq = q == 0 ? 0 : N - q;
+                    zp = res[lds_out<N, sizeof(cx<R>)>(p)]; zmp = res[lds_out<N, sizeof(cx<R>)>(mp)];
+                    zq = res[lds_out<N, sizeof(cx<R>)>(q)]; zmq = res[lds_out<N, sizeof(cx<R>)>(mq)];
+                }
                 cx<R> f0, f1;
                 const R h = (R)0.5;
                 if (which == 0) {
@@ -195,7 +236,7 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
                     f0 = {h * (zp.y + zmp.y), -h * (zp.x - zmp.x)};
                     f1 = {h * (zq.y + zmq.y), -h * (zq.x - zmq.x)};
                 }
-                Tq[((size_t)task * nl + ll) * tq_block<R>(N) + tq_index<R>(v, i)] = {
+                tq_task[(size_t)ll * tq_block<R>(N) + tq_index<R>(v, i)] = {
                     ((R)1 - w) * f0.x + w * f1.x, ((R)1 - w) * f0.y + w * f1.y};
             }
         }
@@ -232,7 +273,6 @@ k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool act = lane < 56;
     const int i0 = TI * (act ? lane >> 3 : 0), j0 = TJ * (lane & 7);
-    static_assert(sizeof(R) == 8, "the tiled second pass reads the fp64 [v][i] layout");
     const cx<R>* Tp = Tq + ((size_t)task * nl + l) * tq_block<R>(N);
     const cx<R>* Gp = G + (size_t)l * g_lines(N) * NS;
     R accP[TI][TJ], accQ[TI][TJ];
@@ -358,12 +398,9 @@ k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>
     // wave w owns row tile w (all lines, all columns): no cross-wave reduction
     const int r = 16 * wave + lr, tl = r / NSH, i = r - tl * NSH;
     const bool aok = tl < TPG && tg * TPG + tl < ntask;
-    // rows without a task read the group's first task (valid memory); they are never used.
-    // A: Tq in the layout of tq_index<float>: one 16-byte load carries this lane's element for
-    // k-steps 2 s and 2 s + 1 (lines 8 s + lk and 8 s + 4 + lk)
-    const f32x4* ap = reinterpret_cast<const f32x4*>(
-                          Tq + ((size_t)(aok ? tg * TPG + tl : tg * TPG) * nl + l) * tq_block<float>(N)) +
-                      (size_t)(aok ? i : 0) * 4 + lk;
+    // rows without a task read the group's first task (valid memory); they are never used
+    const cx<float>* ap = Tq + ((size_t)(aok ? tg * TPG + tl : tg * TPG) * nl + l) * tq_block<float>(N) +
+                          (aok ? i : 0);
     // B: G in the paired-line layout of g_index<float>: one 16-byte load carries this lane's
     // element for k-steps 2 s and 2 s + 1 (lines 8 s + lk and 8 s + 4 + lk)
     constexpr int NG = g_lines(N) / 8;                   // double steps
@@ -387,10 +424,10 @@ k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>
     auto load = [&](int s, Ops& o) {
         const int sc = s < NG ? s : NG - 1;              // past the end: any valid address
         const int v0 = 8 * sc + lk, v1 = v0 + 4;
-        const f32x4 t = ap[(size_t)sc * NSH * 4];
-        // line padding (never written by K_OTF_ROWFFT) and steps past the end: A = 0
-        o.a0 = (s < NG && v0 < NV) ? cx<float>{t[0], t[1]} : cx<float>{0.f, 0.f};
-        o.a1 = (s < NG && v1 < NV) ? cx<float>{t[2], t[3]} : cx<float>{0.f, 0.f};
+        const cx<float> t0 = ap[(size_t)(v0 < NV ? v0 : NV - 1) * NSH];
+        const cx<float> t1 = ap[(size_t)(v1 < NV ? v1 : NV - 1) * NSH];
+        o.a0 = (s < NG && v0 < NV) ? t0 : cx<float>{0.f, 0.f};     // line padding: A = 0
+        o.a1 = (s < NG && v1 < NV) ? t1 : cx<float>{0.f, 0.f};
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) o.b[ct] = bp[ct][(size_t)sc * 4 * NS];
     };
@@ -480,20 +517,36 @@ void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void*
                            (const cx<double>*)d_tw64, d_samp_p, (float*)d_samp_a, (cx<float>*)d_G);
 }
 
-template <typename R, int NN, int ND, bool FE>
-static void launch_otf_t(hipStream_t s, int ntask, int ndir, int nl, const void* d_D0t,
-                         const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
-                         const void* d_samp_a, void* d_Tq, const void* d_tw64) {
+template <typename R, int NN, int ND, bool FE, bool LTAB>
+static void launch_otf_tt(hipStream_t s, int ntask, int ndir, int nl, const void* d_D0t,
+                          const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
+                          const void* d_samp_a, void* d_Tq, const void* d_tw64) {
     constexpr int SL = LineCfg<NN>::SLOTS;
 #ifndef MPSFR_OTF_EXTRA_LDS
 #define MPSFR_OTF_EXTRA_LDS 0
 #endif
-    constexpr size_t sm = fft_smem<R, NN>(!use_reg_twiddles<NN>(), fft_nbuf<NN>()) + MPSFR_OTF_EXTRA_LDS;
-    allow_smem(k_otf_rowfft<R, NN, ND, FE>, sm);
+    const size_t sm = fft_smem<R, NN>(!use_reg_twiddles<NN>(), fft_nbuf<NN>()) + MPSFR_OTF_EXTRA_LDS +
+                      (LTAB ? (size_t)nl * (NSH * (sizeof(SampOff) + sizeof(R)) + sizeof(R)) : 0);
+    allow_smem(k_otf_rowfft<R, NN, ND, FE, LTAB>, sm);
     dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntask);
-    hipLaunchKernelGGL((k_otf_rowfft<R, NN, ND, FE>), grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir,
-                       nl, (const R*)d_D0t, (const R*)d_tel, d_lp, d_samp_p, (const R*)d_samp_a,
-                       (cx<R>*)d_Tq, (const cx<double>*)d_tw64);
+    hipLaunchKernelGGL((k_otf_rowfft<R, NN, ND, FE, LTAB>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
+                       ndir, nl, (const R*)d_D0t, (const R*)d_tel, d_lp, d_samp_p,
+                       (const R*)d_samp_a, (cx<R>*)d_Tq, (const cx<double>*)d_tw64);
+}
+
+template <typename R, int NN, int ND, bool FE>
+static void launch_otf_t(hipStream_t s, int ntask, int ndir, int nl, const void* d_D0t,
+                         const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
+                         const void* d_samp_a, void* d_Tq, const void* d_tw64) {
+#ifndef MPSFR_OTF_LDSTAB
+#define MPSFR_OTF_LDSTAB 1
+#endif
+    if (MPSFR_OTF_LDSTAB && nl <= kOtfLdsTabMaxNl)
+        launch_otf_tt<R, NN, ND, FE, true>(s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p,
+                                           d_samp_a, d_Tq, d_tw64);
+    else
+        launch_otf_tt<R, NN, ND, FE, false>(s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p,
+                                            d_samp_a, d_Tq, d_tw64);
 }
 
 #define OTF_ARGS s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p, d_samp_a, d_Tq, d_tw64
