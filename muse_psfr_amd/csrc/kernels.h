@@ -70,9 +70,15 @@ void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void*
                    int* d_samp_p, void* d_samp_a, void* d_G, bool f64);
 void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
                            void* d_out, bool f64);
+// d_xtab: extraction table of the radix-16 plans (launch_xtab), used when otf_uses_r16()
 void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
                        const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
-                       const void* d_samp_a, void* d_Tq, const void* d_tw64, bool f64, bool fast_exp);
+                       const void* d_samp_a, const void* d_xtab, void* d_Tq, const void* d_tw64,
+                       bool f64, bool fast_exp);
+bool otf_uses_r16(int N, bool f64, int nl, int ndir);
+size_t xtab_bytes(int nl);
+void launch_xtab(hipStream_t s, int N, int nl, const int* d_samp_p, const void* d_samp_a,
+                 const void* d_tw64, void* d_xtab);
 // d_pre: stamps before the convolutions, float (mixed) or double (f64)
 void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, const void* d_G,
                     void* d_pre, bool f64);

@@ -69,7 +69,7 @@ struct mpsfr_ctx {
     // constant tables
     DevBuf tw64, tel, rows;
     // per-call tables
-    DevBuf aotab, samp_p, samp_a, G, kmuse;
+    DevBuf aotab, samp_p, samp_a, G, kmuse, xtab;
     // Pipeline lanes: each lane owns a HIP stream and a set of chunk workspaces.  Consecutive
     // chunks -- of one call or of consecutive asynchronous calls -- go to successive lanes, so one
     // chunk's low-occupancy tail (convolutions, fit) overlaps the next chunk's transforms.
@@ -115,6 +115,8 @@ struct mpsfr_ctx {
     int cache_lbda_mode = -1;
     const void* cache_G_ptr = nullptr;
     const void* cache_kmuse_ptr = nullptr;
+    const void* cache_xtab_ptr = nullptr;
+    bool cache_xtab_valid = false;
     std::vector<unsigned char> cache_geom;
     const void* cache_ao_ptr = nullptr;
     // bookkeeping for debug_fetch
@@ -380,7 +382,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         release(sl.ktt);
     }
     DevBuf* all[] = {&c->tw64, &c->tel, &c->rows, &c->aotab, &c->samp_p, &c->samp_a, &c->G,
-                     &c->kmuse, &c->fit, &c->sum, &c->stage, &c->lsum};
+                     &c->xtab, &c->kmuse, &c->fit, &c->sum, &c->stage, &c->lsum};
     for (auto b : all) release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -620,6 +622,8 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     // G rows are padded to a multiple of 8 lines (paired-line layout of the fp32 second pass)
     if ((rc = ensure(c, c->G, (size_t)nl * ((H1 + 7) / 8 * 8) * NS * 2 * rsize(c)))) return rc;
     if ((rc = ensure(c, c->kmuse, (size_t)nl * ksz))) return rc;
+    const bool r16 = otf_uses_r16(N, c->f64, nl, ndir);
+    if (r16 && (rc = ensure(c, c->xtab, xtab_bytes(nl)))) return rc;
     std::vector<unsigned char> key(sizeof(AoGeom) + 1 + (mask_rec ? 2 * NAO * NAO : 0));
     memcpy(key.data(), &g, sizeof(AoGeom));
     key[sizeof(AoGeom)] = mask_rec ? 1 : 0;
@@ -630,7 +634,8 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     const bool ao_cached = key == c->cache_geom && c->cache_ao_ptr == c->aotab.p;
     const std::vector<double> lb_key(lbda_nm, lbda_nm + nl);
     const bool lam_cached = lb_key == c->cache_lbda && c->cache_lbda_mode == (use_fft_conv ? 1 : 0) &&
-                            c->cache_G_ptr == c->G.p && c->cache_kmuse_ptr == c->kmuse.p;
+                            c->cache_G_ptr == c->G.p && c->cache_kmuse_ptr == c->kmuse.p &&
+                            (!r16 || (c->cache_xtab_valid && c->cache_xtab_ptr == c->xtab.p));
     if (!ao_cached || !lam_cached) {
         for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
             if (c->lane[k].busy && c->lane[k].stream != s0)
@@ -646,6 +651,8 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
                 ProfScope ps(c, K_GTABLE, s0);
                 launch_gtable(s0, N, nl, d_lp, c->tw64.p, (int*)c->samp_p.p, c->samp_a.p, c->G.p,
                               c->f64);
+                if (r16)
+                    launch_xtab(s0, N, nl, (const int*)c->samp_p.p, c->samp_a.p, c->tw64.p, c->xtab.p);
             }
             ProfScope ps(c, K_MOFFAT_KERNELS, s0);
             if (use_fft_conv) launch_khat(s0, nl, d_gam + ntask, d_alp + ntask, c->kmuse.p);
@@ -654,6 +661,8 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
             c->cache_lbda_mode = use_fft_conv ? 1 : 0;
             c->cache_G_ptr = c->G.p;
             c->cache_kmuse_ptr = c->kmuse.p;
+            c->cache_xtab_ptr = c->xtab.p;
+            c->cache_xtab_valid = r16;
         }
         if (!c->cache_ready) HIPCHK(hipEventCreateWithFlags(&c->cache_ready, hipEventDisableTiming));
         HIPCHK(hipEventRecord(c->cache_ready, s0));
@@ -728,8 +737,8 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         {
             ProfScope ps(c, K_OTF_ROWFFT, ls);
             launch_otf_rowfft(ls, N, tc, ndir, nl, ln.D0t.p, c->tel.p, d_lp,
-                              (const int*)c->samp_p.p, c->samp_a.p, ln.Tq.p, c->tw64.p, c->f64,
-                              c->fast_exp);
+                              (const int*)c->samp_p.p, c->samp_a.p, c->xtab.p, ln.Tq.p, c->tw64.p,
+                              c->f64, c->fast_exp);
         }
         {
             ProfScope ps(c, K_COLPASS, ls);

@@ -4,6 +4,7 @@
 //
 // Per-wavelength stage: sampling tables, OTF lines -> sampled first pass, second pass.
 #include "device_common.h"
+#include "fft_r16.h"
 
 namespace mpsfr {
 
@@ -241,6 +242,211 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
             }
         }
         fft_sync<WS>();     // extraction reads done before the next transform overwrites
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K_OTF_R16: K_OTF_ROWFFT with the radix-16 plans of fft_r16.h (fp32, N = 256 / 512 / 1024): two
+// LDS crossings per transform instead of three (four), the last radix-RL pass (RL = N / 256)
+// evaluated only for the outputs the extraction reads.  Same inputs, same Tq out.
+//
+// Extraction in units: a unit is (wavelength of the pair, sample i <= 20, half h), h = 0 for the
+// bilinear neighbour p, h = 1 for p + 1.  With z the neighbour and -z its mirror the unit forms
+//   t = c (Z[z] +- conj Z[-z])     (c = half the bilinear weight; the sign / real-imaginary swap
+//                                   separates the two wavelengths of the complex transform)
+// and the two halves, in adjacent lanes, are added on the DPP path.  The table (K_XTAB, cached
+// per wavelength set) holds per unit: k = z mod 256 and (-z) mod 256 (positions in image 1), c,
+// and the factors of the merged pass,  Z[z] = img1[k] + sum_{q=1}^{RL-1} W_N^(q z) img1[k + 256 q].
+// 84 units per line: three rounds of a 32-lane line (87 % of the lanes busy; items of four outputs
+// kept 66 % busy), and all table loads of a transform are issued before its second pass.
+// ------------------------------------------------------------------------------------------
+#ifndef MPSFR_R16_KNOCK
+#define MPSFR_R16_KNOCK 0       // kernel experiments: 1 = no extraction, 2 = no exp
+#endif
+#ifndef MPSFR_R16_EARLY_TABLE
+#define MPSFR_R16_EARLY_TABLE 0
+#endif
+template <int RL>
+struct XUnit {
+    unsigned short kz, kmz;
+    float c;
+    cx<float> B[RL > 1 ? 2 * (RL - 1) : 1];     // z: q = 1..RL-1, then -z: q = 1..RL-1
+};
+template <>
+struct XUnit<1> {
+    unsigned short kz, kmz;
+    float c;
+};
+static_assert(sizeof(XUnit<1>) == 8 && sizeof(XUnit<2>) == 24 && sizeof(XUnit<4>) == 56, "8-byte pieces");
+
+template <int RL>
+__global__ void __launch_bounds__(256)
+k_xtab(int N, int nl, const int* __restrict__ samp_p, const float* __restrict__ samp_a,
+       const cx<double>* __restrict__ twg, XUnit<RL>* __restrict__ xtab) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nl * NSH * 2) return;
+    const int h = e & 1, li = e >> 1;
+    const int l = li / NSH, i = li - l * NSH;
+    const int p = samp_p[l * NS + i];
+    const int z = h ? (p + 1 == N ? 0 : p + 1) : p;
+    const int mz = z == 0 ? 0 : N - z;
+    const float w = samp_a[l * NS + i];
+    XUnit<RL> x;
+    x.kz = (unsigned short)(z & 255);
+    x.kmz = (unsigned short)(mz & 255);
+    x.c = 0.5f * (h ? w : 1.0f - w);
+    if constexpr (RL > 1) {
+        for (int q = 1; q < RL; ++q) {
+            const cx<double> a = twg[(int)(((long)q * z) % N)], b = twg[(int)(((long)q * mz) % N)];
+            x.B[q - 1] = {(float)a.x, (float)a.y};
+            x.B[RL - 1 + q - 1] = {(float)b.x, (float)b.y};
+        }
+    }
+    xtab[e] = x;
+}
+
+template <int N, int ND, bool FASTEXP>
+#ifndef MPSFR_R16_WAVES
+#define MPSFR_R16_WAVES 4
+#endif
+__global__ void __launch_bounds__(R16<N>::THREADS)
+__attribute__((amdgpu_waves_per_eu(MPSFR_R16_WAVES, MPSFR_R16_WAVES)))
+k_otf_r16(int ndir, int nl, const float* __restrict__ D0t, const float* __restrict__ telT,
+          const LamPar* __restrict__ lp, const XUnit<R16<N>::RL>* __restrict__ xtab,
+          cx<float>* __restrict__ Tq, const cx<double>* __restrict__ twg) {
+    using P = R16<N>;
+    using R = float;
+    constexpr int TPR = P::TPR, LINES = P::LINES, NPAD = P::NPAD, RL = P::RL;
+    constexpr int NU = 4 * NSH;                          // units per line
+    constexpr int ROUNDS = (NU + TPR - 1) / TPR;
+    constexpr int XW = sizeof(XUnit<RL>) / 8;            // 8-byte pieces per table entry
+    extern __shared__ __align__(16) unsigned char smem[];
+    cx<R>* bufs = reinterpret_cast<cx<R>*>(smem);
+    R* scl = reinterpret_cast<R*>(bufs + LINES * NPAD);           // [nl] exponent factors
+    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
+    const int v = blockIdx.x * LINES + slot;
+    const int task = blockIdx.y;
+    const bool valid = v <= N / 2;
+    const int vv = valid ? v : N / 2;
+    R16Tw<R, N> twr;
+    twr.init(twg, t);
+    for (int e = threadIdx.x; e < nl; e += P::THREADS) scl[e] = exp_scale<R, FASTEXP>((R)lp[e].c);
+    __syncthreads();
+    cx<R>* buf = bufs + slot * NPAD;
+    constexpr bool FOLD = FASTEXP && ND == 1;
+    R tel[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        tel[e] = telT[(size_t)vv * N + t + e * TPR];
+        if constexpr (FOLD) tel[e] = __builtin_amdgcn_logf(tel[e]);      // log2
+    }
+    const R* dline = D0t + ((size_t)task * ndir * (N / 2 + 1) + vv) * N;
+    const size_t dstride = (size_t)(N / 2 + 1) * N;
+    R dreg[ND == 1 ? 16 : 1];
+    if constexpr (ND == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dreg[e] = dline[t + e * TPR];
+    }
+    cx<R>* tq_line = Tq + (size_t)task * nl * tq_block<R>(N) + tq_index<R>(v, 0);
+    // the thread's units: u = r TPR + t -> (which wavelength of the pair, sample i, half)
+    int u_li[ROUNDS];                  // which * NSH + i, or -1 beyond the last unit
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int u = r * TPR + t;
+        u_li[r] = u < NU ? (u >> 1) : -1;
+    }
+    const int uh = t & 1;
+    const uint2* xt8 = reinterpret_cast<const uint2*>(xtab);
+    // two wavelengths per complex transform: z = otf(la) + i otf(lb), both real lines
+    for (int l = 0; l < nl; l += 2) {
+        const bool two = l + 1 < nl;
+        const R ca = scl[l], cb = scl[two ? l + 1 : l];
+        cx<R> x[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            R ra = (R)0, rb = (R)0;
+            if constexpr (FOLD) {
+                if (MPSFR_R16_KNOCK == 2) {      // experiment: no exp
+                    x[e] = {fmaf(ca, dreg[e], tel[e]), fmaf(cb, dreg[e], tel[e])};
+                    continue;
+                }
+                x[e] = {exp_sel<R, true>(fmaf(ca, dreg[e], tel[e])),
+                        two ? exp_sel<R, true>(fmaf(cb, dreg[e], tel[e])) : (R)0};
+                continue;
+            } else if constexpr (ND == 1) {
+                ra = exp_sel<R, FASTEXP>(ca * dreg[e]);
+                rb = exp_sel<R, FASTEXP>(cb * dreg[e]);
+            } else {
+                for (int d = 0; d < ndir; ++d) {
+                    const R dv = dline[d * dstride + t + e * TPR];
+                    ra += exp_sel<R, FASTEXP>(ca * dv);
+                    rb += exp_sel<R, FASTEXP>(cb * dv);
+                }
+            }
+            x[e] = {tel[e] * ra, two ? tel[e] * rb : (R)0};
+        }
+        r16_pass0<R, N>(x, buf, t);
+#if MPSFR_R16_EARLY_TABLE
+        // table entries of this transform's units, in flight behind the second pass
+        uint2 xe[ROUNDS][XW];
+        bool act[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int li = u_li[r];
+            act[r] = valid && li >= 0 && (two || li < NSH) && MPSFR_R16_KNOCK != 1;
+            const size_t e = ((size_t)l * NSH + (act[r] ? li : 0)) * 2 + uh;       // li runs into l + 1
+#pragma unroll
+            for (int k = 0; k < XW; ++k) xe[r][k] = xt8[e * XW + k];
+        }
+        r16_pass1<R, N>(buf, twr.w, t);
+#else
+        r16_pass1<R, N>(buf, twr.w, t);
+        // table entries of this transform's units: all rounds in flight at once (issued before the
+        // second pass they cost more in spilled registers than the hidden latency is worth)
+        uint2 xe[ROUNDS][XW];
+        bool act[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int li = u_li[r];
+            act[r] = valid && li >= 0 && (two || li < NSH) && MPSFR_R16_KNOCK != 1;
+            const size_t e = ((size_t)l * NSH + (act[r] ? li : 0)) * 2 + uh;       // li runs into l + 1
+#pragma unroll
+            for (int k = 0; k < XW; ++k) xe[r][k] = xt8[e * XW + k];
+        }
+#endif
+        if (MPSFR_R16_KNOCK == 1) {      // experiment: no extraction
+            if (valid && t < NSH) tq_line[(size_t)l * tq_block<R>(N) + t] = buf[t * 7];
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int kz = xe[r][0].x & 0xffff, kmz = xe[r][0].x >> 16;
+            const R c = __builtin_bit_cast(float, xe[r][0].y);
+            cx<R> zz = buf[kz], zm = buf[kmz];
+            auto mad = [](cx<R> e, uint2 b, cx<R> o) -> cx<R> {     // e + b o
+                const R bx = __builtin_bit_cast(float, b.x), by = __builtin_bit_cast(float, b.y);
+                return {fmaf(-by, o.y, fmaf(bx, o.x, e.x)), fmaf(by, o.x, fmaf(bx, o.y, e.y))};
+            };
+#pragma unroll
+            for (int q = 1; q < RL; ++q) {
+                zz = mad(zz, xe[r][q], buf[kz + 256 * q]);
+                zm = mad(zm, xe[r][RL - 1 + q], buf[kmz + 256 * q]);
+            }
+            // first wavelength: F = (Z[z] + conj Z[-z]) / 2; second: (Z[z] - conj Z[-z]) / 2i
+            const bool second = u_li[r] >= NSH;
+            R tx = second ? c * (zz.y + zm.y) : c * (zz.x + zm.x);
+            R ty = second ? -c * (zz.x - zm.x) : c * (zz.y - zm.y);
+            // the other half of the sample sits in the neighbouring lane (quad_perm [1, 0, 3, 2])
+            tx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                                                0, __builtin_bit_cast(int, tx), 0xB1, 0xf, 0xf, false));
+            ty += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                                                0, __builtin_bit_cast(int, ty), 0xB1, 0xf, 0xf, false));
+            if (act[r] && uh == 0) {
+                const int li = u_li[r];                 // which * NSH + i: runs into wavelength l + 1
+                const int which = li >= NSH ? 1 : 0;
+                tq_line[(size_t)(l + which) * tq_block<R>(N) + (li - which * NSH)] = {tx, ty};
+            }
+        }
+        fft_sync<true>();     // extraction reads done before the next transform overwrites
     }
 }
 
@@ -549,11 +755,68 @@ static void launch_otf_t(hipStream_t s, int ntask, int ndir, int nl, const void*
                                             d_samp_a, d_Tq, d_tw64);
 }
 
+template <int NN, int ND, bool FE>
+static void launch_otf_r16_t(hipStream_t s, int ntask, int ndir, int nl, const void* d_D0t,
+                             const void* d_tel, const LamPar* d_lp, const void* d_xtab, void* d_Tq,
+                             const void* d_tw64) {
+    using P = R16<NN>;
+    const size_t sm = (size_t)P::LINES * P::NPAD * sizeof(cx<float>) + (size_t)nl * sizeof(float);
+    allow_smem(k_otf_r16<NN, ND, FE>, sm);
+    dim3 grid((NN / 2 + 1 + P::LINES - 1) / P::LINES, ntask);
+    hipLaunchKernelGGL((k_otf_r16<NN, ND, FE>), grid, dim3(P::THREADS), sm, s, ndir, nl,
+                       (const float*)d_D0t, (const float*)d_tel, d_lp,
+                       (const XUnit<R16<NN>::RL>*)d_xtab, (cx<float>*)d_Tq, (const cx<double>*)d_tw64);
+}
+
+#ifndef MPSFR_OTF_R16
+#define MPSFR_OTF_R16 1
+#endif
+// Measured (MI355X, K_OTF time per 100 rows): 512^2 x 35 lambda 213 us against 221 us for the
+// radix-8 plan; 1024^2 x 70 lambda 1.58 ms against 3.07 ms (8.8.4.4 needs two wavefronts per line
+// and four crossings); 256^2 is slower with radix 16 (16 lanes per line: six extraction rounds) and
+// keeps the 8.8.4 plan; so does 512^2 with several directions (the kernel is then bound by the
+// nine exp per point, and the radix-8 kernel runs five waves per SIMD against four).
+bool otf_uses_r16(int N, bool f64, int nl, int ndir) {
+    return MPSFR_OTF_R16 && !f64 && ((N == 512 && ndir == 1) || N == 1024) && nl <= 4096;
+}
+
+// one table entry per (wavelength, sample, half) plus one wavelength of slack (the units of an
+// odd last wavelength read ahead)
+size_t xtab_bytes(int nl) { return (size_t)(nl + 1) * NSH * 2 * sizeof(XUnit<4>); }
+
+void launch_xtab(hipStream_t s, int N, int nl, const int* d_samp_p, const void* d_samp_a,
+                 const void* d_tw64, void* d_xtab) {
+    const dim3 grid((nl * NSH * 2 + 255) / 256);
+    if (N == 256)
+        hipLaunchKernelGGL(k_xtab<1>, grid, dim3(256), 0, s, N, nl, d_samp_p, (const float*)d_samp_a,
+                           (const cx<double>*)d_tw64, (XUnit<1>*)d_xtab);
+    else if (N == 512)
+        hipLaunchKernelGGL(k_xtab<2>, grid, dim3(256), 0, s, N, nl, d_samp_p, (const float*)d_samp_a,
+                           (const cx<double>*)d_tw64, (XUnit<2>*)d_xtab);
+    else
+        hipLaunchKernelGGL(k_xtab<4>, grid, dim3(256), 0, s, N, nl, d_samp_p, (const float*)d_samp_a,
+                           (const cx<double>*)d_tw64, (XUnit<4>*)d_xtab);
+}
+
 #define OTF_ARGS s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p, d_samp_a, d_Tq, d_tw64
+#define R16_ARGS s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_xtab, d_Tq, d_tw64
 void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
                        const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
-                       const void* d_samp_a, void* d_Tq, const void* d_tw64, bool f64,
-                       bool fast_exp) {
+                       const void* d_samp_a, const void* d_xtab, void* d_Tq, const void* d_tw64,
+                       bool f64, bool fast_exp) {
+    if (otf_uses_r16(N, f64, nl, ndir)) {
+#define R16_CASE(NN_)                                                                     \
+    if (fast_exp) {                                                                       \
+        if (ndir == 1) launch_otf_r16_t<NN_, 1, true>(R16_ARGS);                          \
+        else launch_otf_r16_t<NN_, 0, true>(R16_ARGS);                                    \
+    } else {                                                                              \
+        if (ndir == 1) launch_otf_r16_t<NN_, 1, false>(R16_ARGS);                         \
+        else launch_otf_r16_t<NN_, 0, false>(R16_ARGS);                                   \
+    }
+        if (N == 256) { R16_CASE(256) } else if (N == 512) { R16_CASE(512) } else { R16_CASE(1024) }
+#undef R16_CASE
+        return;
+    }
     DISPATCH_N(N, {
         if (f64) {
             if (ndir == 1) launch_otf_t<double, NN, 1, false>(OTF_ARGS);
@@ -568,6 +831,7 @@ void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const 
     })
 }
 #undef OTF_ARGS
+#undef R16_ARGS
 
 void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, const void* d_G,
                     void* d_pre, bool f64) {
