@@ -878,6 +878,14 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
             if (mu > mu_max) { status = 2; break; }
             continue;
         }
+        // A stamp narrower than the PSF core has no finite minimum in n: the valley runs to the
+        // Gaussian limit eta -> 0.  A step may cut eta to a fifth at most (the whole step is
+        // scaled), so the valley is descended geometrically instead of through rejected steps.
+        if (v[4] + dx[4] < (S)0.2 * v[4]) {
+            const S sc = (S)-0.8 * v[4] * fit_rcp<S>(dx[4]);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) dx[k] *= sc;
+        }
         S vn[5], rel = (S)0;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -907,6 +915,7 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) v[k] = vn[k];
             ne = nn;
+            if (v[4] < (S)1.5e-3) { status = 0; break; }      // n > 666: Gaussian to 1e-3, stop
             const S c = (S)2 * rho - (S)1;
             mu = fmax(mu * fmax((S)(1.0 / 3.0), (S)1 - c * c * c), (S)1.0e-14);
             nu = (S)2;
