@@ -251,8 +251,8 @@ def main():
             c0 = time.thread_time()
             for _ in range(nsteps):
                 step()
-            # host cost of queueing the steps: CPU time of this thread (the wall time of the loop
-            # is the GPU's pace once the command queue is full)
+            # wall time of the queueing loop: the GPU's pace once the host is four calls ahead (the
+            # host cost proper is host_library_ms_per_call, measured inside the library)
             t_enq = time.thread_time() - c0
             fence()
             dt = time.perf_counter() - t0
@@ -417,8 +417,10 @@ def main():
             'prime_steps': PRIME_STEPS,
             'contexts': max(1, a.inflight), 'lanes_per_context': a.streams or 2,
             'host_enqueue_ms_per_step': round(t_enq / a.steps * 1e3, 4),
-            'host_enqueue_note': 'CPU time of the Python thread per step (ctypes call + library); '
-                                 'host_library_ms_per_call = inside mpsfr_reconstruct (wall)',
+            'host_enqueue_note': 'host_enqueue_ms_per_step: CPU time of the Python thread per step, '
+                                 'which includes spinning while four calls ahead of the GPU; '
+                                 'host_library_ms_per_call: wall time inside mpsfr_reconstruct '
+                                 'without that wait = what queueing a call costs',
             'host_library_ms_per_call': round(host_lib_s * 1e3, 4),
             'build_id': load_lib().mpsfr_build_id().decode(),
         }

@@ -128,7 +128,8 @@ void* mpsfr_stream(mpsfr_ctx* ctx);
 int mpsfr_wait_event(mpsfr_ctx* ctx, void* hip_event);
 
 /* Host wall time spent inside mpsfr_reconstruct since the last mpsfr_profile_reset, and the
- * number of calls (what queueing a call costs the host thread). */
+ * number of calls: what queueing a call costs the host thread.  Time spent blocked because the
+ * host ran four calls ahead of the GPU (the ring of parameter blobs) is not counted. */
 int mpsfr_host_time(mpsfr_ctx* ctx, double* seconds, long* calls);
 
 /* Copy an intermediate of the most recent mpsfr_reconstruct pipeline pass (last chunk) to the

@@ -551,8 +551,11 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     const size_t o_ms = al16(o_mr + NAO * NAO);
     const size_t blob = al16(o_ms + NAO * NAO);
     mpsfr_ctx::Slot& sl = c->slot[c->stage_next++ % mpsfr_ctx::NSTAGE];
+    double t_blocked = 0.0;
     if (sl.staged_pending) {        // the copy that last used the pinned blob must have left it
-        HIPCHK(hipEventSynchronize(sl.staged));
+        const auto tb = std::chrono::steady_clock::now();
+        HIPCHK(hipEventSynchronize(sl.staged));      // only blocks once the host is NSTAGE calls ahead
+        t_blocked = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count();
         sl.staged_pending = false;
     }
     if (blob > sl.host_cap) {
@@ -670,7 +673,10 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     } else if (c->cache_ready_valid) {
         HIPCHK(hipStreamWaitEvent(s0, c->cache_ready, 0));
     }
-    {   // tip-tilt kernels of this call's tasks (psfrec.py:879-917)
+    {   // Tip-tilt kernels of this call's tasks (psfrec.py:879-917).  (Measured: moving this small
+        // launch to a side stream, off the head of the call's chain, and folding the DC sum into
+        // the column-transform kernel both LOWER the two-lane throughput, by 2-4 %: the short
+        // serial kernels keep the two lanes out of phase.)
         ProfScope ps(c, K_MOFFAT_KERNELS, s0);
         if (use_fft_conv) launch_khat(s0, ntask, d_gam, d_alp, sl.ktt.p);   // [n][33][64] complex
         else launch_moffat_kernels(s0, ntask, d_gam, d_alp, sl.ktt.p, c->f64);
@@ -806,7 +812,8 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
                                   hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     }
-    c->host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
+    // host cost of queueing the call: not the time spent waiting for the GPU to catch up
+    c->host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count() - t_blocked;
     c->host_calls += 1;
     return MPSFR_OK;
 }

@@ -24,7 +24,7 @@ for r in csv.DictReader(open(d + '/kernel_stats.csv')):
     m = re.search(r'k_\w+', r['Name'])
     if m and m.group(0) not in dur:
         dur[m.group(0)] = float(r['AverageNs']) * 1e-9
-print('# Per-kernel resource use (single lane: `bench.py --streams 1`, 100 rows x 35 lambda x 512^2)\n')
+print('# Per-kernel resource use (one lane: `bench.py --streams 1`, 100 rows x 35 lambda x 512^2)\n')
 print('Source: `scripts/prof_table.sh` -- rocprofv3 kernel trace (durations) and separate PMC passes.')
 print('VALU = SQ_INSTS_VALU x 2 issue cycles / (1024 SIMDs x kernel cycles at 2.4 GHz), a lower bound: fp64 '
       'and transcendental instructions take 4; LDS = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles); '
@@ -32,7 +32,7 @@ print('VALU = SQ_INSTS_VALU x 2 issue cycles / (1024 SIMDs x kernel cycles at 2.
 print('| kernel | avg us | VALU issue | LDS array busy | of which bank conflicts | HBM GB/s |')
 print('|---|---|---|---|---|---|')
 util = {}
-for k in ('k_otf_rowfft', 'k_fit', 'k_conv_fft', 'k_colpass_m', 'k_psd_rowfft', 'k_colfft_dphi',
+for k in ('k_otf_r16', 'k_otf_rowfft', 'k_fit', 'k_conv_fft', 'k_colpass_m', 'k_psd_rowfft', 'k_colfft_dphi',
           'k_khat', 'k_stamp_sum', 'k_dc_sum'):
     if k not in dur:
         continue
@@ -46,5 +46,13 @@ for k in ('k_otf_rowfft', 'k_fit', 'k_conv_fft', 'k_colpass_m', 'k_psd_rowfft', 
                                                                  conf * 100, hbm))
     util[k] = {'avg_us': round(t * 1e6, 1), 'valu_issue': round(valu, 3), 'lds_array_busy': round(lds, 3),
                'lds_conflict_share': round(conf, 3), 'hbm_GBps': round(hbm, 1)}
+    wc = get(k, 'SQ_WAVE_CYCLES')
+    if wc:      # where the wave cycles go (disjoint): issuing / issue stall (of which LDS) / waitcnt
+        util[k].update(wave_active=round(get(k, 'SQ_ACTIVE_INST_ANY') / wc, 3),
+                       wave_issue_stall=round(get(k, 'SQ_WAIT_INST_ANY') / wc, 3),
+                       wave_issue_stall_lds=round(get(k, 'SQ_WAIT_INST_LDS') / wc, 3),
+                       wave_waitcnt=round(get(k, 'SQ_WAIT_ANY') / wc, 3))
+    if k == 'k_otf_r16':     # the per-wavelength kernel under the name bench.py looks up
+        util['k_otf_rowfft'] = dict(util[k], kernel_symbol='k_otf_r16')
 if len(sys.argv) > 2:
     json.dump(util, open(sys.argv[2], 'w'), indent=1)
