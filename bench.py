@@ -119,6 +119,8 @@ def main():
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--fast-exp', type=int, default=1)
     ap.add_argument('--streams', type=int, default=0, help='pipeline lanes (0: library default)')
+    ap.add_argument('--prune-eps', type=float, default=-1.0,
+                    help='line pruning of the per-wavelength stage (-1: library default 1e-9, 0: off)')
     ap.add_argument('--inflight', type=int, default=1,
                     help='contexts fed in turn (each context already pipelines consecutive calls '
                          'over its two internal lanes)')
@@ -185,7 +187,7 @@ def main():
 
     from muse_psfr_amd.distributed import ShardExchange
 
-    def make_runner(precision, nctx):
+    def make_runner(precision, nctx, prune_eps=a.prune_eps):
         """Steps are independent batches, pipelined through `nctx` contexts (each with its own
         HIP stream and workspaces) fed in turn.  A step is still one mpsfr_reconstruct of the
         rank's rows; every step's outputs are produced."""
@@ -197,6 +199,8 @@ def main():
             c.set_option('fast_exp', a.fast_exp)
             if a.streams:
                 c.set_option('streams', a.streams)
+            if prune_eps >= 0 and precision == 'mixed':
+                c.set_option('prune_eps', prune_eps)
             ctxs.append(c)
         # Two sets of result buffers per context: consecutive calls of one context overlap on its
         # internal lanes, and calls that share an output buffer would be serialised.

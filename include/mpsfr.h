@@ -75,7 +75,10 @@ const char* mpsfr_last_error(void);
  * calls -- go to successive HIP streams with their own workspaces so that one chunk's tail
  * overlaps the next one's body; results are independent of it except for the summation order of
  * psf_sum_out in multi-chunk calls); "pipeline_calls" (default 1: asynchronous calls rotate over
- * the lanes; 0: every call starts on the first lane); "profile" (0/1: bracket every kernel launch
+ * the lanes; 0: every call starts on the first lane); "prune_eps" (mixed mode only, default 1e-9:
+ * lines of the OTF half plane whose elements are all below eps / (element count) of the PSF peak
+ * are neither transformed nor summed -- no stamp pixel changes by more than eps of the peak;
+ * 0 = transform every line); "profile" (0/1: bracket every kernel launch
  * with HIP events on the stream it is launched on -- the event packets cost ~8 % of a step);
  * "profile_only" (-1 = all kernels, else the kernel id of mpsfr_profile_name to time alone). */
 int mpsfr_set_option(mpsfr_ctx* ctx, const char* key, double value);
@@ -139,6 +142,8 @@ int mpsfr_host_time(mpsfr_ctx* ctx, double* seconds, long* calls);
  *   "dphi0"      [chunk tasks][ndir][dim/2+1][dim] structure function / lambda-factor,
  *                transposed half plane (psfrec.py:717-722)
  *   "pre"        [chunk tasks][nl][dimpsf][dimpsf] stamps before the convolutions (psfrec.py:685)
+ *   "vkeep"      [chunk tasks][(nl+1)/2] lines of the half plane transformed per wavelength pair
+ *                (option "prune_eps")
  * Returns the number of doubles written (<= capacity) or a negative error. */
 long mpsfr_debug_fetch(mpsfr_ctx* ctx, const char* what, double* out, size_t capacity);
 

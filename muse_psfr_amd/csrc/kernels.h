@@ -64,8 +64,13 @@ void launch_tel_otf(hipStream_t s, int N, const uint64_t* d_rows, int words, dou
 void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp,
                        const double* d_aotab, double cfit, void* d_C, const void* d_tw64);
 void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00);
+// d_dmin: [ntd][N/2+1] float line minima of D (or nullptr), input of launch_vkeep
 void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,
-                        double scale2, void* d_D0t, bool f64out, const void* d_tw64);
+                        double scale2, void* d_D0t, bool f64out, const void* d_tw64, float* d_dmin);
+// line pruning of the per-wavelength stage (stage_a.hip, "Line pruning")
+void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax);
+void launch_vkeep(hipStream_t s, int N, int ntask, int ndir, int nl, const LamPar* d_lp,
+                  const float* d_dmin, const float* d_tlmax, float thr_log2, int* d_vkeep);
 void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void* d_tw64,
                    int* d_samp_p, void* d_samp_a, void* d_G, bool f64);
 void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
@@ -74,14 +79,15 @@ void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const
 void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
                        const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
                        const void* d_samp_a, const void* d_xtab, void* d_Tq, const void* d_tw64,
-                       bool f64, bool fast_exp);
+                       bool f64, bool fast_exp, const int* d_vkeep);
 bool otf_uses_r16(int N, bool f64, int nl, int ndir);
 size_t xtab_bytes(int nl);
 void launch_xtab(hipStream_t s, int N, int nl, const int* d_samp_p, const void* d_samp_a,
                  const void* d_tw64, void* d_xtab);
 // d_pre: stamps before the convolutions, float (mixed) or double (f64)
+// d_vkeep: [ntask][(nl+1)/2] lines to read per (task, wavelength pair), or nullptr for all
 void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, const void* d_G,
-                    void* d_pre, bool f64);
+                    void* d_pre, bool f64, const int* d_vkeep);
 void launch_conv(hipStream_t s, int ntask, int nl, const void* d_pre, const void* d_ktt,
                  const void* d_kmuse, double* d_fin, bool f64);
 void launch_khat(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,

@@ -66,8 +66,9 @@ struct mpsfr_ctx {
     bool profile = false;
     int prof_only = -1;          // >= 0: time only this kernel id
     bool fft_conv = true;   // mixed mode: convolutions through 64-point FFTs
+    double prune_eps = 1.0e-9;   // mixed mode: line pruning of the per-wavelength stage (0 = off)
     // constant tables
-    DevBuf tw64, tel, rows;
+    DevBuf tw64, tel, rows, tlmax;
     // per-call tables
     DevBuf aotab, samp_p, samp_a, G, kmuse, xtab;
     // Pipeline lanes: each lane owns a HIP stream and a set of chunk workspaces.  Consecutive
@@ -78,7 +79,7 @@ struct mpsfr_ctx {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;       // after the lane's last chunk of the most recent call
         bool busy = false;               // `done` has been recorded
-        DevBuf C, s00, D0t, Tq, pre, fin;
+        DevBuf C, s00, D0t, Tq, pre, fin, dmin, vkeep;
         const void* outs[3] = {nullptr, nullptr, nullptr};   // device outputs of its latest call
     };
     static constexpr int MAX_LANES = 4;
@@ -301,6 +302,10 @@ int build_constant_tables(mpsfr_ctx* c) {
         launch_tel_otf(c->stream, N, (const uint64_t*)c->rows.p, words, (double)pupsum, c->tel.p,
                        c->f64);
     }
+    if (!c->f64) {      // log2 of the line maxima of the telescope OTF (line pruning, stage_a.hip)
+        if ((rc = ensure(c, c->tlmax, (size_t)(H + 1) * sizeof(float)))) return rc;
+        launch_tel_linemax(c->stream, N, c->tel.p, (float*)c->tlmax.p);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     return MPSFR_OK;
@@ -370,7 +375,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         mpsfr_ctx::Lane& ln = c->lane[k];
         if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
         if (ln.done) (void)hipEventDestroy(ln.done);
-        DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin};
+        DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.dmin, &ln.vkeep};
         for (auto b : lb) release(*b);
     }
     for (int k = 0; k < mpsfr_ctx::NSTAGE; ++k) {
@@ -381,7 +386,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         release(sl.params);
         release(sl.ktt);
     }
-    DevBuf* all[] = {&c->tw64, &c->tel, &c->rows, &c->aotab, &c->samp_p, &c->samp_a, &c->G,
+    DevBuf* all[] = {&c->tw64, &c->tel, &c->rows, &c->tlmax, &c->aotab, &c->samp_p, &c->samp_a, &c->G,
                      &c->xtab, &c->kmuse, &c->fit, &c->sum, &c->stage, &c->lsum};
     for (auto b : all) release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -399,6 +404,9 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         if (value < 0.0 || value > 4.0 || value != (int)value)
             return fail(MPSFR_E_INVALID, "streams must be 0 (automatic) or 1..4");
         c->nlanes = (int)value;
+    } else if (!strcmp(key, "prune_eps")) {
+        if (!(value >= 0.0) || value > 1.0e-3) return fail(MPSFR_E_INVALID, "prune_eps must be in [0, 1e-3]");
+        c->prune_eps = value;
     } else if (!strcmp(key, "pipeline_calls")) {
         c->pipeline_calls = value != 0.0;
     } else if (!strcmp(key, "fft_conv")) {
@@ -684,6 +692,11 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
 
     // ---- chunk workspaces
     const size_t per_stamp = (size_t)NS * NS;
+    // Line pruning of the per-wavelength stage (mixed mode): lines of the OTF half plane whose
+    // elements are all below eps / (number of elements) of the PSF peak are neither transformed
+    // nor read by the second pass (stage_a.hip, "Line pruning").
+    const bool prune = !c->f64 && c->prune_eps > 0.0;
+    const float thr_log2 = prune ? (float)std::log2(c->prune_eps / ((double)ndir * N * (N + 2.0))) : 0.f;
     for (int j = 0; j < NL; ++j) {
         mpsfr_ctx::Lane& ln = lane_of(j);
         // row FFTs of the PSD: only the N/2 + 40 distinct rows are stored (K_PSD_ROWFFT)
@@ -693,6 +706,10 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         if ((rc = ensure(c, ln.Tq, (size_t)TC * nl * H1 * NSH * 2 * rsize(c)))) return rc;
         if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * (c->f64 ? 8 : 4)))) return rc;
         if ((rc = ensure(c, ln.fin, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
+        if (prune) {
+            if ((rc = ensure(c, ln.dmin, (size_t)TC * ndir * H1 * sizeof(float)))) return rc;
+            if ((rc = ensure(c, ln.vkeep, (size_t)TC * ((nl + 1) / 2) * sizeof(int)))) return rc;
+        }
     }
     if (NL > 1 && (rc = ensure(c, c->lsum, (size_t)NL * nl * per_stamp * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->sum, (size_t)nl * per_stamp * sizeof(double)))) return rc;
@@ -738,17 +755,21 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         {
             ProfScope ps(c, K_COLFFT_DPHI, ls);
             launch_colfft_dphi(ls, N, ntd, ln.C.p, (const double*)ln.s00.p, scale2, ln.D0t.p,
-                               c->f64, c->tw64.p);
+                               c->f64, c->tw64.p, prune ? (float*)ln.dmin.p : nullptr);
+            if (prune)
+                launch_vkeep(ls, N, tc, ndir, nl, d_lp, (const float*)ln.dmin.p,
+                             (const float*)c->tlmax.p, thr_log2, (int*)ln.vkeep.p);
         }
+        const int* d_vkeep = prune ? (const int*)ln.vkeep.p : nullptr;
         {
             ProfScope ps(c, K_OTF_ROWFFT, ls);
             launch_otf_rowfft(ls, N, tc, ndir, nl, ln.D0t.p, c->tel.p, d_lp,
                               (const int*)c->samp_p.p, c->samp_a.p, c->xtab.p, ln.Tq.p, c->tw64.p,
-                              c->f64, c->fast_exp);
+                              c->f64, c->fast_exp, d_vkeep);
         }
         {
             ProfScope ps(c, K_COLPASS, ls);
-            launch_colpass(ls, N, tc, nl, ln.Tq.p, c->G.p, ln.pre.p, c->f64);
+            launch_colpass(ls, N, tc, nl, ln.Tq.p, c->G.p, ln.pre.p, c->f64, d_vkeep);
         }
         double* d_fin = d_fin_all ? d_fin_all + (size_t)t0 * nl * per_stamp : (double*)ln.fin.p;
         {
@@ -868,6 +889,14 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
         n = (size_t)c->last_chunk_tasks * c->last_nl * NS * NS;
         src = c->lane[c->last_lane].pre.p;
         is_real_r = true;
+    } else if (!strcmp(what, "vkeep")) {
+        if (c->f64 || !(c->prune_eps > 0.0)) return fail(MPSFR_E_INVALID, "line pruning is off");
+        n = (size_t)c->last_chunk_tasks * ((c->last_nl + 1) / 2);
+        if (n > capacity) return fail(MPSFR_E_INVALID, "capacity %zu < %zu", capacity, n);
+        std::vector<int> tmp(n);
+        HIPCHK(hipMemcpy(tmp.data(), c->lane[c->last_lane].vkeep.p, n * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) out[i] = (double)tmp[i];
+        return (long)n;
     } else {
         return fail(MPSFR_E_INVALID, "unknown buffer '%s'", what);
     }

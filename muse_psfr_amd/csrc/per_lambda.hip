@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(LineCfg<N>::THREADS)
 k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ telT,
              const LamPar* __restrict__ lp, const int* __restrict__ samp_p,
              const R* __restrict__ samp_a, cx<R>* __restrict__ Tq,
-             const cx<double>* __restrict__ twg) {
+             const cx<double>* __restrict__ twg, const int* __restrict__ vkeep) {
     using L = LineCfg<N>;
     constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
     constexpr int EPT = N / TPR;
@@ -116,6 +116,11 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
     cx<R>* twl = reinterpret_cast<cx<R>*>(smem);          // only used when !REGTW
     cx<R>* bufA = twl + (REGTW ? 0 : NPAD);
     cx<R>* bufB = bufA + SLOTS * NPAD;
+    // line pruning (stage_a.hip): the workgroup's lines start at v0; a wavelength pair whose
+    // vkeep is not above v0 needs none of them (decided per workgroup: barriers stay uniform)
+    const int* vk_task = vkeep != nullptr ? vkeep + (size_t)blockIdx.y * ((nl + 1) / 2) : nullptr;
+    const int v0 = blockIdx.x * SLOTS;
+    if (vk_task != nullptr && v0 >= vk_task[(nl - 1) / 2]) return;     // vkeep grows with the pair
     // after the line buffers: [nl][NSH] SampOff, [nl][NSH] weights, [nl] exponent factors
     SampOff* stab = reinterpret_cast<SampOff*>(bufA + fft_nbuf<N>() * SLOTS * NPAD);
     R* swt = reinterpret_cast<R*>(stab + (LTAB ? nl * NSH : 0));
@@ -175,6 +180,7 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
     cx<R>* tq_task = Tq + (size_t)task * nl * tq_block<R>(N);
     // two wavelengths per complex transform: z = otf(la) + i otf(lb), both real lines
     for (int l = 0; l < nl; l += 2) {
+        if (vk_task != nullptr && v0 >= vk_task[l >> 1]) continue;
         const bool two = l + 1 < nl;
         R ca, cb;
         if constexpr (LTAB) {
@@ -313,10 +319,15 @@ __global__ void __launch_bounds__(R16<N>::THREADS)
 __attribute__((amdgpu_waves_per_eu(MPSFR_R16_WAVES, MPSFR_R16_WAVES)))
 k_otf_r16(int ndir, int nl, const float* __restrict__ D0t, const float* __restrict__ telT,
           const LamPar* __restrict__ lp, const XUnit<R16<N>::RL>* __restrict__ xtab,
-          cx<float>* __restrict__ Tq, const cx<double>* __restrict__ twg) {
+          cx<float>* __restrict__ Tq, const cx<double>* __restrict__ twg,
+          const int* __restrict__ vkeep) {
     using P = R16<N>;
     using R = float;
     constexpr int TPR = P::TPR, LINES = P::LINES, NPAD = P::NPAD, RL = P::RL;
+    // line pruning (stage_a.hip), decided per workgroup as in K_OTF_ROWFFT
+    const int* vk_task = vkeep != nullptr ? vkeep + (size_t)blockIdx.y * ((nl + 1) / 2) : nullptr;
+    const int v0 = blockIdx.x * LINES;
+    if (vk_task != nullptr && v0 >= vk_task[(nl - 1) / 2]) return;
     constexpr int NU = 4 * NSH;                          // units per line
     constexpr int ROUNDS = (NU + TPR - 1) / TPR;
     constexpr int XW = sizeof(XUnit<RL>) / 8;            // 8-byte pieces per table entry
@@ -359,6 +370,7 @@ k_otf_r16(int ndir, int nl, const float* __restrict__ D0t, const float* __restri
     const uint2* xt8 = reinterpret_cast<const uint2*>(xtab);
     // two wavelengths per complex transform: z = otf(la) + i otf(lb), both real lines
     for (int l = 0; l < nl; l += 2) {
+        if (vk_task != nullptr && v0 >= vk_task[l >> 1]) continue;
         const bool two = l + 1 < nl;
         const R ca = scl[l], cb = scl[two ? l + 1 : l];
         cx<R> x[16];
@@ -593,7 +605,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int N>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MPSFR_COLPASS_WAVES)))
 k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>* __restrict__ G,
-            float* __restrict__ pre) {
+            float* __restrict__ pre, const int* __restrict__ vkeep) {
     constexpr int NV = N / 2 + 1, TPG = 3, MT = 4, NT = 3, NCOL = NT * 16;
     static_assert(TPG * NSH <= MT * 16 && NS <= NCOL, "tile map");
     __shared__ float red[2][MT * 16][NCOL];  // P, Q
@@ -604,6 +616,16 @@ k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>
     // wave w owns row tile w (all lines, all columns): no cross-wave reduction
     const int r = 16 * wave + lr, tl = r / NSH, i = r - tl * NSH;
     const bool aok = tl < TPG && tg * TPG + tl < ntask;
+    // Line pruning (stage_a.hip): lines at and beyond vkeep[task][pair] were never written; a row
+    // reads zeros there, and the loop ends at the largest vkeep of the group's tasks.
+    const int npair = (nl + 1) / 2;
+    const int nv_row = (vkeep != nullptr && aok) ? vkeep[(tg * TPG + tl) * npair + (l >> 1)] : NV;
+    int nv_grp = NV;
+    if (vkeep != nullptr) {
+        nv_grp = 0;
+        for (int k = 0; k < TPG; ++k)
+            if (tg * TPG + k < ntask) nv_grp = max(nv_grp, vkeep[(tg * TPG + k) * npair + (l >> 1)]);
+    }
     // rows without a task read the group's first task (valid memory); they are never used
     const cx<float>* ap = Tq + ((size_t)(aok ? tg * TPG + tl : tg * TPG) * nl + l) * tq_block<float>(N) +
                           (aok ? i : 0);
@@ -632,8 +654,8 @@ k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>
         const int v0 = 8 * sc + lk, v1 = v0 + 4;
         const cx<float> t0 = ap[(size_t)(v0 < NV ? v0 : NV - 1) * NSH];
         const cx<float> t1 = ap[(size_t)(v1 < NV ? v1 : NV - 1) * NSH];
-        o.a0 = (s < NG && v0 < NV) ? t0 : cx<float>{0.f, 0.f};     // line padding: A = 0
-        o.a1 = (s < NG && v1 < NV) ? t1 : cx<float>{0.f, 0.f};
+        o.a0 = (s < NG && v0 < nv_row) ? t0 : cx<float>{0.f, 0.f};     // padding / pruned: A = 0
+        o.a1 = (s < NG && v1 < nv_row) ? t1 : cx<float>{0.f, 0.f};
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) o.b[ct] = bp[ct][(size_t)sc * 4 * NS];
     };
@@ -654,7 +676,8 @@ k_colpass_m(int ntask, int nl, const cx<float>* __restrict__ Tq, const cx<float>
     // of four sets -- three double steps of loads in flight -- measured no faster.)
     Ops oa, ob;
     load(0, oa);
-    for (int s = 0; s < NG; s += 2) {
+    const int ng_used = min(NG, (nv_grp + 7) / 8);
+    for (int s = 0; s < ng_used; s += 2) {
         load(s + 1, ob);
         mma(oa);
         load(s + 2, oa);
@@ -726,7 +749,7 @@ void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void*
 template <typename R, int NN, int ND, bool FE, bool LTAB>
 static void launch_otf_tt(hipStream_t s, int ntask, int ndir, int nl, const void* d_D0t,
                           const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
-                          const void* d_samp_a, void* d_Tq, const void* d_tw64) {
+                          const void* d_samp_a, void* d_Tq, const void* d_tw64, const int* d_vkeep) {
     constexpr int SL = LineCfg<NN>::SLOTS;
 #ifndef MPSFR_OTF_EXTRA_LDS
 #define MPSFR_OTF_EXTRA_LDS 0
@@ -737,35 +760,36 @@ static void launch_otf_tt(hipStream_t s, int ntask, int ndir, int nl, const void
     dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntask);
     hipLaunchKernelGGL((k_otf_rowfft<R, NN, ND, FE, LTAB>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
                        ndir, nl, (const R*)d_D0t, (const R*)d_tel, d_lp, d_samp_p,
-                       (const R*)d_samp_a, (cx<R>*)d_Tq, (const cx<double>*)d_tw64);
+                       (const R*)d_samp_a, (cx<R>*)d_Tq, (const cx<double>*)d_tw64, d_vkeep);
 }
 
 template <typename R, int NN, int ND, bool FE>
 static void launch_otf_t(hipStream_t s, int ntask, int ndir, int nl, const void* d_D0t,
                          const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
-                         const void* d_samp_a, void* d_Tq, const void* d_tw64) {
+                         const void* d_samp_a, void* d_Tq, const void* d_tw64, const int* d_vkeep) {
 #ifndef MPSFR_OTF_LDSTAB
 #define MPSFR_OTF_LDSTAB 1
 #endif
     if (MPSFR_OTF_LDSTAB && nl <= kOtfLdsTabMaxNl)
         launch_otf_tt<R, NN, ND, FE, true>(s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p,
-                                           d_samp_a, d_Tq, d_tw64);
+                                           d_samp_a, d_Tq, d_tw64, d_vkeep);
     else
         launch_otf_tt<R, NN, ND, FE, false>(s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p,
-                                            d_samp_a, d_Tq, d_tw64);
+                                            d_samp_a, d_Tq, d_tw64, d_vkeep);
 }
 
 template <int NN, int ND, bool FE>
 static void launch_otf_r16_t(hipStream_t s, int ntask, int ndir, int nl, const void* d_D0t,
                              const void* d_tel, const LamPar* d_lp, const void* d_xtab, void* d_Tq,
-                             const void* d_tw64) {
+                             const void* d_tw64, const int* d_vkeep) {
     using P = R16<NN>;
     const size_t sm = (size_t)P::LINES * P::NPAD * sizeof(cx<float>) + (size_t)nl * sizeof(float);
     allow_smem(k_otf_r16<NN, ND, FE>, sm);
     dim3 grid((NN / 2 + 1 + P::LINES - 1) / P::LINES, ntask);
     hipLaunchKernelGGL((k_otf_r16<NN, ND, FE>), grid, dim3(P::THREADS), sm, s, ndir, nl,
                        (const float*)d_D0t, (const float*)d_tel, d_lp,
-                       (const XUnit<R16<NN>::RL>*)d_xtab, (cx<float>*)d_Tq, (const cx<double>*)d_tw64);
+                       (const XUnit<R16<NN>::RL>*)d_xtab, (cx<float>*)d_Tq, (const cx<double>*)d_tw64,
+                       d_vkeep);
 }
 
 #ifndef MPSFR_OTF_R16
@@ -798,12 +822,12 @@ void launch_xtab(hipStream_t s, int N, int nl, const int* d_samp_p, const void* 
                            (const cx<double>*)d_tw64, (XUnit<4>*)d_xtab);
 }
 
-#define OTF_ARGS s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p, d_samp_a, d_Tq, d_tw64
-#define R16_ARGS s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_xtab, d_Tq, d_tw64
+#define OTF_ARGS s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_samp_p, d_samp_a, d_Tq, d_tw64, d_vkeep
+#define R16_ARGS s, ntask, ndir, nl, d_D0t, d_tel, d_lp, d_xtab, d_Tq, d_tw64, d_vkeep
 void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
                        const void* d_tel, const LamPar* d_lp, const int* d_samp_p,
                        const void* d_samp_a, const void* d_xtab, void* d_Tq, const void* d_tw64,
-                       bool f64, bool fast_exp) {
+                       bool f64, bool fast_exp, const int* d_vkeep) {
     if (otf_uses_r16(N, f64, nl, ndir)) {
 #define R16_CASE(NN_)                                                                     \
     if (fast_exp) {                                                                       \
@@ -834,7 +858,7 @@ void launch_otf_rowfft(hipStream_t s, int N, int ntask, int ndir, int nl, const 
 #undef R16_ARGS
 
 void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, const void* d_G,
-                    void* d_pre, bool f64) {
+                    void* d_pre, bool f64, const int* d_vkeep) {
     dim3 grid(nl, ntask);
     DISPATCH_N(N, {
         if (f64)
@@ -842,7 +866,7 @@ void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, c
                                (const cx<double>*)d_Tq, (const cx<double>*)d_G, (double*)d_pre);
         else
             hipLaunchKernelGGL((k_colpass_m<NN>), dim3(nl, (ntask + 2) / 3), dim3(256), 0, s, ntask,
-                               nl, (const cx<float>*)d_Tq, (const cx<float>*)d_G, (float*)d_pre);
+                               nl, (const cx<float>*)d_Tq, (const cx<float>*)d_G, (float*)d_pre, d_vkeep);
     })
 }
 
