@@ -201,6 +201,8 @@ def main():
                 c.set_option('streams', a.streams)
             if prune_eps >= 0 and precision == 'mixed':
                 c.set_option('prune_eps', prune_eps)
+            if os.environ.get('MPSFR_PRUNE_FIXED') and precision == 'mixed':
+                c.set_option('prune_fixed', int(os.environ['MPSFR_PRUNE_FIXED']))
             ctxs.append(c)
         # Two sets of result buffers per context: consecutive calls of one context overlap on its
         # internal lanes, and calls that share an output buffer would be serialised.

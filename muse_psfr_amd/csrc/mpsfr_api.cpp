@@ -66,6 +66,7 @@ struct mpsfr_ctx {
     bool profile = false;
     int prof_only = -1;          // >= 0: time only this kernel id
     bool fft_conv = true;   // mixed mode: convolutions through 64-point FFTs
+    int prune_fixed = 0;         // experiments: transform exactly this many lines (wrong results)
     double prune_eps = 1.0e-9;   // mixed mode: line pruning of the per-wavelength stage (0 = off)
     // constant tables
     DevBuf tw64, tel, rows, tlmax;
@@ -404,6 +405,8 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         if (value < 0.0 || value > 4.0 || value != (int)value)
             return fail(MPSFR_E_INVALID, "streams must be 0 (automatic) or 1..4");
         c->nlanes = (int)value;
+    } else if (!strcmp(key, "prune_fixed")) {
+        c->prune_fixed = (int)value;
     } else if (!strcmp(key, "prune_eps")) {
         if (!(value >= 0.0) || value > 1.0e-3) return fail(MPSFR_E_INVALID, "prune_eps must be in [0, 1e-3]");
         c->prune_eps = value;
@@ -758,7 +761,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
                                c->f64, c->tw64.p, prune ? (float*)ln.dmin.p : nullptr);
             if (prune)
                 launch_vkeep(ls, N, tc, ndir, nl, d_lp, (const float*)ln.dmin.p,
-                             (const float*)c->tlmax.p, thr_log2, (int*)ln.vkeep.p);
+                             (const float*)c->tlmax.p, thr_log2, (int*)ln.vkeep.p, c->prune_fixed);
         }
         const int* d_vkeep = prune ? (const int*)ln.vkeep.p : nullptr;
         {

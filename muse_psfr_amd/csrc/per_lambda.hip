@@ -101,6 +101,18 @@ struct SampOff {
     unsigned short p, mp, q, mq;
 };
 constexpr int kOtfLdsTabMaxNl = 128;      // above this the table would crowd the line buffers
+// Groups of wavelength pairs (grid.z) of the per-wavelength kernels.  With line pruning the work
+// of a (task, line group) runs from 0 to all pairs, and the workgroups that need every pair set
+// the length of the kernel (18 transforms in a row: 55-70 us).  vkeep grows with the pair, so
+// with G groups only the line groups that the early pairs need are split.
+#ifndef MPSFR_OTF_PAIR_GROUPS
+#define MPSFR_OTF_PAIR_GROUPS 2
+#endif
+__host__ __device__ inline int otf_pairs_per_group(int nl, bool pruned) {
+    const int npair = (nl + 1) / 2;
+    const int g = pruned ? MPSFR_OTF_PAIR_GROUPS : 1;
+    return (npair + g - 1) / g;
+}
 
 template <typename R, int N, int ND, bool FASTEXP, bool LTAB>
 __global__ void __launch_bounds__(LineCfg<N>::THREADS)
@@ -120,7 +132,10 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
     // vkeep is not above v0 needs none of them (decided per workgroup: barriers stay uniform)
     const int* vk_task = vkeep != nullptr ? vkeep + (size_t)blockIdx.y * ((nl + 1) / 2) : nullptr;
     const int v0 = blockIdx.x * SLOTS;
-    if (vk_task != nullptr && v0 >= vk_task[(nl - 1) / 2]) return;     // vkeep grows with the pair
+    const int ppg = otf_pairs_per_group(nl, vkeep != nullptr);
+    const int l_beg = (int)blockIdx.z * 2 * ppg, l_end = min(nl, ((int)blockIdx.z + 1) * 2 * ppg);
+    // vkeep grows with the pair: nothing to do if the group's last pair does not need v0
+    if (vk_task != nullptr && v0 >= vk_task[(l_end - 1) >> 1]) return;
     // after the line buffers: [nl][NSH] SampOff, [nl][NSH] weights, [nl] exponent factors
     SampOff* stab = reinterpret_cast<SampOff*>(bufA + fft_nbuf<N>() * SLOTS * NPAD);
     R* swt = reinterpret_cast<R*>(stab + (LTAB ? nl * NSH : 0));
@@ -179,7 +194,7 @@ k_otf_rowfft(int ndir, int nl, const R* __restrict__ D0t, const R* __restrict__ 
     if constexpr (ND == 1 && LTAB) __builtin_amdgcn_s_waitcnt(0x0F70);
     cx<R>* tq_task = Tq + (size_t)task * nl * tq_block<R>(N);
     // two wavelengths per complex transform: z = otf(la) + i otf(lb), both real lines
-    for (int l = 0; l < nl; l += 2) {
+    for (int l = l_beg; l < l_end; l += 2) {
         if (vk_task != nullptr && v0 >= vk_task[l >> 1]) continue;
         const bool two = l + 1 < nl;
         R ca, cb;
@@ -327,7 +342,9 @@ k_otf_r16(int ndir, int nl, const float* __restrict__ D0t, const float* __restri
     // line pruning (stage_a.hip), decided per workgroup as in K_OTF_ROWFFT
     const int* vk_task = vkeep != nullptr ? vkeep + (size_t)blockIdx.y * ((nl + 1) / 2) : nullptr;
     const int v0 = blockIdx.x * LINES;
-    if (vk_task != nullptr && v0 >= vk_task[(nl - 1) / 2]) return;
+    const int ppg = otf_pairs_per_group(nl, vkeep != nullptr);
+    const int l_beg = (int)blockIdx.z * 2 * ppg, l_end = min(nl, ((int)blockIdx.z + 1) * 2 * ppg);
+    if (vk_task != nullptr && v0 >= vk_task[(l_end - 1) >> 1]) return;
     constexpr int NU = 4 * NSH;                          // units per line
     constexpr int ROUNDS = (NU + TPR - 1) / TPR;
     constexpr int XW = sizeof(XUnit<RL>) / 8;            // 8-byte pieces per table entry
@@ -369,7 +386,7 @@ k_otf_r16(int ndir, int nl, const float* __restrict__ D0t, const float* __restri
     const int uh = t & 1;
     const uint2* xt8 = reinterpret_cast<const uint2*>(xtab);
     // two wavelengths per complex transform: z = otf(la) + i otf(lb), both real lines
-    for (int l = 0; l < nl; l += 2) {
+    for (int l = l_beg; l < l_end; l += 2) {
         if (vk_task != nullptr && v0 >= vk_task[l >> 1]) continue;
         const bool two = l + 1 < nl;
         const R ca = scl[l], cb = scl[two ? l + 1 : l];
@@ -757,7 +774,8 @@ static void launch_otf_tt(hipStream_t s, int ntask, int ndir, int nl, const void
     const size_t sm = fft_smem<R, NN>(!use_reg_twiddles<NN>(), fft_nbuf<NN>()) + MPSFR_OTF_EXTRA_LDS +
                       (LTAB ? (size_t)nl * (NSH * (sizeof(SampOff) + sizeof(R)) + sizeof(R)) : 0);
     allow_smem(k_otf_rowfft<R, NN, ND, FE, LTAB>, sm);
-    dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntask);
+    const int ppg = otf_pairs_per_group(nl, d_vkeep != nullptr);
+    dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntask, ((nl + 1) / 2 + ppg - 1) / ppg);
     hipLaunchKernelGGL((k_otf_rowfft<R, NN, ND, FE, LTAB>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
                        ndir, nl, (const R*)d_D0t, (const R*)d_tel, d_lp, d_samp_p,
                        (const R*)d_samp_a, (cx<R>*)d_Tq, (const cx<double>*)d_tw64, d_vkeep);
@@ -785,7 +803,8 @@ static void launch_otf_r16_t(hipStream_t s, int ntask, int ndir, int nl, const v
     using P = R16<NN>;
     const size_t sm = (size_t)P::LINES * P::NPAD * sizeof(cx<float>) + (size_t)nl * sizeof(float);
     allow_smem(k_otf_r16<NN, ND, FE>, sm);
-    dim3 grid((NN / 2 + 1 + P::LINES - 1) / P::LINES, ntask);
+    const int ppg = otf_pairs_per_group(nl, d_vkeep != nullptr);
+    dim3 grid((NN / 2 + 1 + P::LINES - 1) / P::LINES, ntask, ((nl + 1) / 2 + ppg - 1) / ppg);
     hipLaunchKernelGGL((k_otf_r16<NN, ND, FE>), grid, dim3(P::THREADS), sm, s, ndir, nl,
                        (const float*)d_D0t, (const float*)d_tel, d_lp,
                        (const XUnit<R16<NN>::RL>*)d_xtab, (cx<float>*)d_Tq, (const cx<double>*)d_tw64,

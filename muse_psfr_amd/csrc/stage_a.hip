@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) k_tel_linemax(int N, const float* __restr
 __global__ void __launch_bounds__(256) k_vkeep(int H1, int ndir, int nl, const LamPar* __restrict__ lp,
                                                const float* __restrict__ dmin,
                                                const float* __restrict__ tlmax, float thr_log2,
-                                               int* __restrict__ vkeep) {
+                                               int* __restrict__ vkeep, int fixed) {
     constexpr int MAXP = 2048;                        // nl <= 4096
     __shared__ int vk[MAXP];
     const int task = blockIdx.x, npair = (nl + 1) / 2;
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(256) k_vkeep(int H1, int ndir, int nl, const L
         int m = 0;
         for (int pr = 0; pr < npair; ++pr) {
             m = max(m, vk[pr]);
-            vkeep[task * npair + pr] = m;
+            vkeep[task * npair + pr] = fixed > 0 ? min(fixed, H1) : m;      // fixed: experiments
         }
     }
 }
@@ -391,9 +391,9 @@ void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax)
 }
 
 void launch_vkeep(hipStream_t s, int N, int ntask, int ndir, int nl, const LamPar* d_lp,
-                  const float* d_dmin, const float* d_tlmax, float thr_log2, int* d_vkeep) {
+                  const float* d_dmin, const float* d_tlmax, float thr_log2, int* d_vkeep, int fixed) {
     hipLaunchKernelGGL(k_vkeep, dim3(ntask), dim3(256), 0, s, N / 2 + 1, ndir, nl, d_lp, d_dmin, d_tlmax,
-                       thr_log2, d_vkeep);
+                       thr_log2, d_vkeep, fixed);
 }
 
 void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,
