@@ -83,7 +83,7 @@ def fft_flops(dim):
     return 5.0 * dim * math.log2(dim)
 
 
-def hbm_model_bytes(dim, nl, rows, ndir, mixed):
+def hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac=1.0):
     """Algorithmic HBM bytes of one step of the RESTRUCTURED pipeline (DESIGN.md sections 3, 5):
     every intermediate written once and read once by the next kernel, inputs/outputs once."""
     H1, NR = dim // 2 + 1, dim // 2 + 40
@@ -94,7 +94,8 @@ def hbm_model_bytes(dim, nl, rows, ndir, mixed):
     b['C (fp64 row transforms of the PSD, write + read)'] = 2 * td * 16 * H1 * NR
     b['D_phi0 (write + read)'] = 2 * td * p * H1 * dim
     if PIPELINE_HAS_TQ:
-        b['Tq (sampled first-pass lines, write + read)'] = 2 * psf * 2 * p * 21 * H1
+        b['Tq (sampled first-pass lines that survive the pruning, write + read)'] = int(
+            2 * psf * 2 * p * 21 * H1 * kept_frac)
     b['stamps before the convolutions (write + read)'] = 2 * psf * 1600 * p
     b['final stamps (write, read by the fit, read by the stamp sum)'] = 3 * psf * 1600 * (4 if mixed else 8)
     b['fit table + stamp sum (write)'] = psf * 16 * 8 + nl * 1600 * 8
@@ -128,6 +129,8 @@ def main():
                     help='rows of the CPU-baseline sample (-1: automatic, 0: skip)')
     ap.add_argument('--f64-steps', type=int, default=-1,
                     help='steps of the fp64-mode leg (-1: steps/8, 0: skip)')
+    ap.add_argument('--unpruned-steps', type=int, default=-1,
+                    help='steps of the leg without line pruning (-1: steps/4, 0: skip)')
     ap.add_argument('--profile-steps', type=int, default=-1,
                     help='steps of the untimed per-kernel event pass (-1: min(steps, 40), 0: skip)')
     a = ap.parse_args()
@@ -326,7 +329,30 @@ def main():
     for c in ctxs:
         c.set_option('profile', 0)
     fitg = R['fits'][0].cpu().numpy()
+    # line pruning: lines of the OTF half plane transformed per (row, wavelength pair) in the last
+    # call (every call of the loop has the same inputs)
+    lines_kept = None
+    if mixed and a.prune_eps != 0 and a.chunk == 0 and not os.environ.get('MPSFR_PRUNE_FIXED'):
+        try:
+            lines_kept = ctxs[0].debug_fetch('vkeep', (rows, (nl + 1) // 2))
+        except Exception:       # pruning switched off in the library
+            lines_kept = None
     R['close']()
+
+    # ---- the same workload with every line of the half plane transformed (prune_eps = 0)
+    unpruned = None
+    nunp = (max(20, a.steps // 4) if a.unpruned_steps < 0 else a.unpruned_steps) if lines_kept is not None else 0
+    if nunp > 0:
+        R3 = make_runner('mixed', max(1, a.inflight), prune_eps=0.0)
+        for _ in range(8):
+            R3['step']()
+        dt3, _ = R3['timed'](nunp)
+        fit3 = R3['fits'][0].cpu().numpy()
+        R3['close']()
+        unpruned = {'value': round(world * rows * nl * nunp / dt3, 1), 'unit': 'PSFs/sec', 'steps': nunp,
+                    'ms_per_step': round(dt3 / nunp * 1e3, 4),
+                    'max_abs_diff_fwhm_px_vs_pruned': float(np.abs(fit3[:, :, 5] - fitg[:, :, 5]).max()),
+                    'max_abs_diff_beta_vs_pruned': float(np.abs(fit3[:, :, 4] - fitg[:, :, 4]).max())}
 
     # ---- the same workload at the reference's own precision (fp64 everywhere), fewer steps
     f64 = None
@@ -356,7 +382,11 @@ def main():
         # (N/2+1) lines per task (direction mean taken before the transform), two wavelengths per
         # complex transform, 5 N log2 N flops each.  exp, the bilinear extraction and the index
         # arithmetic are not counted, so `frac` is a lower bound of the VALU work done.
-        ntrans = tasks_per_launch * (dim // 2 + 1) * ((nl + 1) // 2)
+        # With line pruning only the transforms that were executed count: the lines below
+        # vkeep[row][pair] (rounded up to the kernel's line groups would be more; not counted).
+        ntrans_all = tasks_per_launch * (dim // 2 + 1) * ((nl + 1) // 2)
+        kept_frac = float(lines_kept.sum() / (rows * ((nl + 1) // 2) * (dim // 2 + 1))) if lines_kept is not None else 1.0
+        ntrans = ntrans_all * kept_frac
         flops = ntrans * fft_flops(dim)
         achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0
         peak = PEAK_FP32_TFLOPS if mixed else PEAK_FP32_TFLOPS / 2
@@ -372,7 +402,7 @@ def main():
                 traffic = per_unit * units_per_launch
             traffic_step = sum((v.get('fetch_kib', 0) + v.get('write_kib', 0)) * 1024.0
                                for v in tj['kernels'].values())
-        model = hbm_model_bytes(dim, nl, rows, ndir, mixed)
+        model = hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac)
         if tj and 'model_extra' in tj:          # e.g. an intermediate the current pipeline keeps
             model.update(tj['model_extra'])
         model_step = float(sum(model.values()))
@@ -398,8 +428,10 @@ def main():
                          'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'avg_launch_ms': round(avg_s * 1e3, 4), 'launches': nlaunch,
                          'nominal_flops_per_launch': flops,
-                         'model': '(N/2+1) lines x ceil(nl/2) complex N-point transforms per task '
-                                  'x 5 N log2 N flops; HIP events on the launch stream, timed region',
+                         'model': 'lines transformed (line pruning: vkeep per row and wavelength pair, '
+                                  'of (N/2+1) x ceil(nl/2) per row) x 5 N log2 N flops per complex '
+                                  'N-point transform; HIP events on the launch stream, timed region',
+                         'lines_transformed_fraction': round(kept_frac, 4),
                          'valu_issue': u and u.get('valu_issue'),
                          'lds_busy': u and u.get('lds_array_busy'),
                          'pmc_source': u and 'profiles/ kernel_util.json (scripts/prof_table.sh, '
@@ -433,6 +465,9 @@ def main():
         if f64 is not None:
             out['value_f64'] = f64['value']
             out['f64'] = f64
+        if unpruned is not None:
+            out['value_unpruned'] = unpruned['value']
+            out['unpruned'] = unpruned
         if cpu is not None:
             out['cpu_baseline'] = cpu
             out['parity'] = parity_block(fitg, cpu_fits.shape[0])

@@ -76,8 +76,8 @@ const char* mpsfr_last_error(void);
  * overlaps the next one's body; results are independent of it except for the summation order of
  * psf_sum_out in multi-chunk calls); "pipeline_calls" (default 1: asynchronous calls rotate over
  * the lanes; 0: every call starts on the first lane); "prune_eps" (mixed mode only, default 1e-9:
- * lines of the OTF half plane whose elements are all below eps / (element count) of the PSF peak
- * are neither transformed nor summed -- no stamp pixel changes by more than eps of the peak;
+ * the trailing lines of the OTF half plane that together weigh less than eps of the PSF peak are
+ * neither transformed nor summed -- no stamp pixel changes by more than eps of the peak;
  * 0 = transform every line); "profile" (0/1: bracket every kernel launch
  * with HIP events on the stream it is launched on -- the event packets cost ~8 % of a step);
  * "profile_only" (-1 = all kernels, else the kernel id of mpsfr_profile_name to time alone). */

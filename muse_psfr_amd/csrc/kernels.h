@@ -70,7 +70,7 @@ void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const do
 // line pruning of the per-wavelength stage (stage_a.hip, "Line pruning")
 void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax);
 void launch_vkeep(hipStream_t s, int N, int ntask, int ndir, int nl, const LamPar* d_lp,
-                  const float* d_dmin, const float* d_tlmax, float thr_log2, int* d_vkeep,
+                  const float* d_dmin, const float* d_tlmax, float thr_sum, int* d_vkeep,
                   int fixed);
 void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void* d_tw64,
                    int* d_samp_p, void* d_samp_a, void* d_G, bool f64);

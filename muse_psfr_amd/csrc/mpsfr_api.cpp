@@ -695,11 +695,11 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
 
     // ---- chunk workspaces
     const size_t per_stamp = (size_t)NS * NS;
-    // Line pruning of the per-wavelength stage (mixed mode): lines of the OTF half plane whose
-    // elements are all below eps / (number of elements) of the PSF peak are neither transformed
-    // nor read by the second pass (stage_a.hip, "Line pruning").
+    // Line pruning of the per-wavelength stage (mixed mode): the trailing lines of the OTF half
+    // plane that together weigh less than eps of the PSF peak are neither transformed nor read
+    // by the second pass (stage_a.hip, "Line pruning").
     const bool prune = !c->f64 && c->prune_eps > 0.0;
-    const float thr_log2 = prune ? (float)std::log2(c->prune_eps / ((double)ndir * N * (N + 2.0))) : 0.f;
+    const float thr_sum = prune ? (float)(c->prune_eps / (2.0 * N * ndir)) : 0.f;
     for (int j = 0; j < NL; ++j) {
         mpsfr_ctx::Lane& ln = lane_of(j);
         // row FFTs of the PSD: only the N/2 + 40 distinct rows are stored (K_PSD_ROWFFT)
@@ -761,7 +761,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
                                c->f64, c->tw64.p, prune ? (float*)ln.dmin.p : nullptr);
             if (prune)
                 launch_vkeep(ls, N, tc, ndir, nl, d_lp, (const float*)ln.dmin.p,
-                             (const float*)c->tlmax.p, thr_log2, (int*)ln.vkeep.p, c->prune_fixed);
+                             (const float*)c->tlmax.p, thr_sum, (int*)ln.vkeep.p, c->prune_fixed);
         }
         const int* d_vkeep = prune ? (const int*)ln.vkeep.p : nullptr;
         {

@@ -290,12 +290,13 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
 // Line pruning of the per-wavelength stage.  The OTF of a line is tel * sum_dir exp(c D) with
 // c < 0 and D >= 0, so with  A_v = min over directions and u of D[v][u]  (K_COLFFT_DPHI) and
 // B_v = log2 max_u tel[v][u]  (K_TEL_LINEMAX, once per context) every element of line v is at most
-// 2^(c' A_v + B_v)  (c' = c log2 e).  The PSF peak is the sum of the whole OTF >= OTF[0][0] = 1, so
-// dropping every line whose bound is below  eps / (ndir N (N + 2))  changes no stamp pixel by more
-// than eps of the peak.  The bound grows with the wavelength, so a pair of wavelengths uses its
-// longer one.  K_VKEEP: vkeep[task][pair] = 1 + the last line that must be transformed; with
-// seeing-limited PSFs most of the half plane is far below fp32 resolution (bench workload:
-// 37 % of the lines survive eps = 1e-9, 81 % are not identically zero in fp32).
+// 2^(c' A_v + B_v)  (c' = c log2 e), and the line (both half planes, all directions) weighs at
+// most 2 N ndir times that.  The PSF peak is the sum of the whole OTF >= OTF[0][0] = 1, so dropping
+// the lines v >= vkeep with  sum_{v >= vkeep} 2 N ndir 2^(c' A_v + B_v) <= eps  changes no stamp
+// pixel by more than eps of the peak.  The bound grows with the wavelength, so a pair of
+// wavelengths uses its longer one.  K_VKEEP: vkeep[task][pair] = the number of lines to transform;
+// with seeing-limited PSFs most of the half plane is far below fp32 resolution (bench workload:
+// 46 % of the lines survive eps = 1e-9; 81 % are not identically zero in fp32).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_tel_linemax(int N, const float* __restrict__ telT,
                                                      float* __restrict__ tlmax) {
@@ -313,39 +314,56 @@ __global__ void __launch_bounds__(256) k_tel_linemax(int N, const float* __restr
 
 __global__ void __launch_bounds__(256) k_vkeep(int H1, int ndir, int nl, const LamPar* __restrict__ lp,
                                                const float* __restrict__ dmin,
-                                               const float* __restrict__ tlmax, float thr_log2,
+                                               const float* __restrict__ tlmax, float thr_sum,
                                                int* __restrict__ vkeep, int fixed) {
-    constexpr int MAXP = 2048;                        // nl <= 4096
-    __shared__ int vk[MAXP];
+    constexpr int MAXH = 1280 / 2 + 1;
+    __shared__ float sa[MAXH], sb[MAXH];
     const int task = blockIdx.x, npair = (nl + 1) / 2;
-    for (int pr = threadIdx.x; pr < npair; pr += 256) vk[pr] = 0;
-    __syncthreads();
-    for (int vb = 0; vb < H1; vb += 256) {                 // every wave takes part in every ballot
-        const int v = vb + threadIdx.x;
-        float a = __builtin_inff(), b = -__builtin_inff();
-        if (v < H1) {
-            for (int d = 0; d < ndir; ++d) a = fminf(a, dmin[((size_t)task * ndir + d) * H1 + v]);
-            b = tlmax[v];
-        }
-        for (int pr = 0; pr < npair; ++pr) {
-            const int l = 2 * pr + 1 < nl ? 2 * pr + 1 : 2 * pr;      // the longer wavelength
-            const bool need = v < H1 && fmaf((float)lp[l].c * 1.44269504088896340736f, a, b) >= thr_log2;
-            // the last needed line of the wave's 64: one atomic per wave (an atomic per lane on the
-            // same LDS word serialises 64-fold: 42 us for this kernel)
-            const unsigned long long m = __ballot(need);
-            if (m != 0ull && (threadIdx.x & 63) == 0)
-                atomicMax(&vk[pr], vb + (int)(threadIdx.x & ~63u) + 64 - __clzll((long long)m));
-        }
+    for (int v = threadIdx.x; v < H1; v += 256) {
+        float a = __builtin_inff();
+        for (int d = 0; d < ndir; ++d) a = fminf(a, dmin[((size_t)task * ndir + d) * H1 + v]);
+        sa[v] = a;
+        sb[v] = tlmax[v];
     }
     __syncthreads();
-    // monotone in the pair index by construction of the bound; enforce it against rounding
-    if (threadIdx.x == 0) {
-        int m = 0;
-        for (int pr = 0; pr < npair; ++pr) {
-            m = max(m, vk[pr]);
-            vkeep[task * npair + pr] = fixed > 0 ? min(fixed, H1) : m;      // fixed: experiments
+    // Per wavelength pair: walk the lines from the top and stop where the summed bounds of
+    // everything above would exceed the allowance.  Eight threads per pair first sum eight
+    // segments of the half plane, so that the serial walk is one pass over the segment sums and
+    // one inside a segment (a single thread over all lines put 257 dependent steps on the chain
+    // of every call).
+    constexpr int SEG = 8, MAXP = 2048;
+    __shared__ float seg[32][SEG];                       // 32 pairs per sweep
+    const int slen = (H1 + SEG - 1) / SEG;
+    for (int p0 = 0; p0 < npair; p0 += 32) {
+        const int pr = p0 + (int)(threadIdx.x >> 3), sg = threadIdx.x & 7;
+        const bool on = pr < npair;
+        const int l = on ? (2 * pr + 1 < nl ? 2 * pr + 1 : 2 * pr) : 0;       // the longer wavelength
+        const float c2 = (float)lp[l].c * 1.44269504088896340736f;
+        float part = 0.f;
+        for (int v = min(H1, (sg + 1) * slen) - 1; v >= sg * slen; --v)
+            part += __builtin_amdgcn_exp2f(fmaf(c2, sa[v], sb[v]));
+        seg[threadIdx.x >> 3][sg] = part;
+        __syncthreads();
+        if (on && sg == 0) {
+            float sum = 0.f;
+            int vk = 0;
+            for (int k = SEG - 1; k >= 0 && vk == 0; --k) {
+                const float next = sum + seg[threadIdx.x >> 3][k];
+                if (next > thr_sum) {                   // the boundary is inside segment k
+                    for (int v = min(H1, (k + 1) * slen) - 1; v >= k * slen; --v) {
+                        sum += __builtin_amdgcn_exp2f(fmaf(c2, sa[v], sb[v]));
+                        if (sum > thr_sum) { vk = v + 1; break; }
+                    }
+                    if (vk == 0) vk = k * slen + 1;      // rounding of the two summation orders
+                }
+                sum = next;
+            }
+            vkeep[task * npair + pr] = fixed > 0 ? min(fixed, H1) : vk;   // fixed: experiments
         }
+        __syncthreads();
     }
+    (void)MAXP;
+    // (monotone in the pair index: c2 rises with the wavelength, so every term of the sum does)
 }
 
 }  // namespace
@@ -391,9 +409,9 @@ void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax)
 }
 
 void launch_vkeep(hipStream_t s, int N, int ntask, int ndir, int nl, const LamPar* d_lp,
-                  const float* d_dmin, const float* d_tlmax, float thr_log2, int* d_vkeep, int fixed) {
+                  const float* d_dmin, const float* d_tlmax, float thr_sum, int* d_vkeep, int fixed) {
     hipLaunchKernelGGL(k_vkeep, dim3(ntask), dim3(256), 0, s, N / 2 + 1, ndir, nl, d_lp, d_dmin, d_tlmax,
-                       thr_log2, d_vkeep, fixed);
+                       thr_sum, d_vkeep, fixed);
 }
 
 void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,

@@ -638,3 +638,49 @@ def test_config_high_resolution_1024(api, golden, ref_masks):
     assert rel_err(psf[150][li], ofin) < 2e-5
     assert np.abs(fit[150][li, 5] * ps - ofit[:, 3]).max() < 1e-4
     assert np.abs(fit[150][li, 4] - ofit[:, 4]).max() < 1e-4
+
+
+@pytest.mark.parametrize('dim,npl', [(512, 1), (256, 3), (1024, 1), (128, 1)])
+def test_line_pruning_changes_nothing_above_its_bound(api, dim, npl):
+    """Mixed mode skips the lines of the OTF half plane whose elements are all below
+    eps / (element count) of the PSF peak (option prune_eps, default 1e-9): against the same run
+    with every line transformed no stamp pixel may move by more than eps of the peak (fp32
+    rounding of the sums on top), the fits agree far inside the parity tolerance, and the number
+    of lines kept grows with the wavelength."""
+    see, gl, l0 = api.synthetic_rows(12)
+    see[0], gl[0], l0[0] = 0.4, 0.95, 29.0            # sharpest PSF of the distribution: least pruning
+    see[1], gl[1], l0[1] = 1.6, 0.30, 9.0             # broadest: most pruning
+    lb = np.linspace(465, 930, 7)
+    ps = api.grid_pixscale(dim)
+    three = (np.arange(12) % 5 == 2).astype(np.uint8)
+    out = {}
+    for key, eps in (('all', 0.0), ('pruned', None), ('loose', 1e-6)):
+        ctx = api.Context(dim=dim, pixscale=ps, precision='mixed')
+        if eps is not None:
+            ctx.set_option('prune_eps', eps)
+        out[key] = ctx.reconstruct(lb, see, gl, l0, three, H, npsflin=npl)
+        if key == 'pruned':
+            vk = ctx.debug_fetch('vkeep', (12, 4))
+        ctx.close()
+    a, b, c = out['all'], out['pruned'], out['loose']
+    peak = a['psf'].max(axis=(2, 3), keepdims=True)
+    assert (np.abs(b['psf'] - a['psf']) / peak).max() < 3e-7          # eps + fp32 summation order
+    assert (np.abs(c['psf'] - a['psf']) / peak).max() < 3e-6
+    well = a['fit'][:, :, 4] < 10
+    assert np.abs(b['fit'][:, :, 5] - a['fit'][:, :, 5])[well].max(initial=0) * ps < 2e-6
+    assert np.abs(b['fit'][:, :, 4] - a['fit'][:, :, 4])[well].max(initial=0) < 2e-5
+    nv = dim // 2 + 1
+    assert vk.min() >= 1 and vk.max() <= nv
+    assert np.all(np.diff(vk, axis=1) >= 0)              # grows with the wavelength pair
+    assert vk[1].max() < vk[0].max()                     # the broad PSF needs fewer lines
+    assert vk[1, 0] < 0.25 * nv                          # and most of its half plane is dropped
+
+
+def test_line_pruning_is_off_in_f64_mode(api):
+    ctx = api.Context(dim=128, pixscale=api.grid_pixscale(128), precision='f64')
+    ctx.reconstruct([700.0], [1.0], [0.7], [25.0], [0], H)
+    with pytest.raises(api.MpsfrError):
+        ctx.debug_fetch('vkeep', (1, 1))
+    with pytest.raises(api.MpsfrError):
+        ctx.set_option('prune_eps', 0.1)
+    ctx.close()
