@@ -332,9 +332,19 @@ def main():
     # line pruning: lines of the OTF half plane transformed per (row, wavelength pair) in the last
     # call (every call of the loop has the same inputs)
     lines_kept = None
-    if mixed and a.prune_eps != 0 and a.chunk == 0 and not os.environ.get('MPSFR_PRUNE_FIXED'):
+    if mixed and a.prune_eps != 0 and not os.environ.get('MPSFR_PRUNE_FIXED'):
+        # measured on one single-chunk call over the first rows of the workload
+        nprobe = min(rows, 4096 // nl if nl <= 512 else 8)
+        if a.chunk:
+            nprobe = min(nprobe, a.chunk)
+        pf = torch.zeros((nprobe, nl, NFIT), dtype=torch.float64, device=dev)
+        psm = torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev)
+        sp = slice(rank * rows, rank * rows + nprobe)
+        ctxs[0].reconstruct_device(lb, see[sp], gl[sp], l0[sp], three[:nprobe], h, 12.0, a.npsflin,
+                                   None, None, psm.data_ptr(), pf.data_ptr())
+        ctxs[0].sync()
         try:
-            lines_kept = ctxs[0].debug_fetch('vkeep', (rows, (nl + 1) // 2))
+            lines_kept = ctxs[0].debug_fetch('vkeep', (nprobe, (nl + 1) // 2))
         except Exception:       # pruning switched off in the library
             lines_kept = None
     R['close']()
@@ -385,7 +395,7 @@ def main():
         # With line pruning only the transforms that were executed count: the lines below
         # vkeep[row][pair] (rounded up to the kernel's line groups would be more; not counted).
         ntrans_all = tasks_per_launch * (dim // 2 + 1) * ((nl + 1) // 2)
-        kept_frac = float(lines_kept.sum() / (rows * ((nl + 1) // 2) * (dim // 2 + 1))) if lines_kept is not None else 1.0
+        kept_frac = float(lines_kept.mean() / (dim // 2 + 1)) if lines_kept is not None else 1.0
         ntrans = ntrans_all * kept_frac
         flops = ntrans * fft_flops(dim)
         achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0

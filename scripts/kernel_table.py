@@ -33,7 +33,7 @@ print('| kernel | avg us | VALU issue | LDS array busy | of which bank conflicts
 print('|---|---|---|---|---|---|')
 util = {}
 for k in ('k_otf_r16', 'k_otf_rowfft', 'k_fit', 'k_conv_fft', 'k_colpass_m', 'k_psd_rowfft', 'k_colfft_dphi',
-          'k_khat', 'k_stamp_sum', 'k_dc_sum'):
+          'k_khat', 'k_stamp_sum', 'k_dc_sum', 'k_vkeep'):
     if k not in dur:
         continue
     t = dur[k]
