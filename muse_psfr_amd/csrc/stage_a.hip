@@ -236,53 +236,68 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
               RO* __restrict__ D0t, const cx<double>* __restrict__ twg, float* __restrict__ dmin) {
     using L = LineCfg<N>;
     constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
+    constexpr int NR = psd_rows<N>(), NLD = (NR + TPR - 1) / TPR;
+    constexpr int NYG = (N / 2 + 1 + SLOTS - 1) / SLOTS;          // groups of SLOTS columns
     extern __shared__ __align__(16) unsigned char smem[];
     cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
     cx<double>* bufA = tw + NPAD;
     cx<double>* bufB = bufA + SLOTS * NPAD;
-    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
-    const int y0 = blockIdx.x * SLOTS;
-    const int td = blockIdx.y;
-    for (int i = threadIdx.x; i < N; i += THREADS) tw[lds_pad(i)] = twg[i];
     __shared__ int smin[SLOTS];          // line minimum, as the bits of a non-negative float
-    if (threadIdx.x < SLOTS) smin[threadIdx.x] = 0x7f800000;
-    constexpr int NR = psd_rows<N>();
+    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
+    const int td = blockIdx.y;
     const cx<double>* Ct = C + (size_t)td * (N / 2 + 1) * NR;
-    // column y0+slot: NR contiguous compact rows; rows su >= 40 also stand for row -1-su
-    {
-        const int y = y0 + slot;
+    // A workgroup walks the column groups blockIdx.x, blockIdx.x + gridDim.x, ...: the twiddle
+    // table is staged once, and the NR values of the next column are in flight (registers) behind
+    // the transform of the current one -- one workgroup per column group spent 47 % of its wave
+    // cycles waiting for its loads of C.
+    cx<double> pre[NLD];
+    auto fetch = [&](int yg) {
+        const int y = yg * SLOTS + slot;
         const cx<double>* col = Ct + (size_t)(y <= N / 2 ? y : 0) * NR;
-        cx<double>* dst = bufA + slot * NPAD;
-        for (int ci = t; ci < NR; ci += TPR) {
-            const cx<double> v = y <= N / 2 ? col[ci] : cx<double>{0.0, 0.0};
-            const int su = ci - NAO / 2;
-            dst[lds_pad(su < 0 ? su + N : su)] = v;
-            if (su >= NAO / 2) dst[lds_pad(N - 1 - su)] = v;
-        }
-    }
-    __syncthreads();
-    const cx<double>* res =
-        fft_forward<double, N, false>(bufA + slot * NPAD, bufB + slot * NPAD, tw, t);
-    const int y = y0 + slot;
-    if (y <= N / 2) {
-        const double dc = s00[td];
-        RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N;
-        float lo = __builtin_inff();
-        for (int x = t; x < N; x += TPR) {
-            const RO d = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
-            out[x] = d;
-            lo = fminf(lo, fmaxf((float)d, 0.f));
-        }
-        if (dmin != nullptr) {      // line minimum: shuffles within the line's lanes, then one atomic
 #pragma unroll
-            for (int o = (TPR < 64 ? TPR : 64) / 2; o > 0; o >>= 1) lo = fminf(lo, __shfl_xor(lo, o, 64));
-            if ((t & 63) == 0) atomicMin(&smin[slot], __float_as_int(lo));
+        for (int k = 0; k < NLD; ++k) {
+            const int ci = t + k * TPR;
+            pre[k] = (ci < NR && y <= N / 2) ? col[ci] : cx<double>{0.0, 0.0};
         }
-    }
-    if (dmin != nullptr) {
+    };
+    fetch(blockIdx.x);
+    for (int i = threadIdx.x; i < N; i += THREADS) tw[lds_pad(i)] = twg[i];
+    const double dc = s00[td];
+    for (int yg = blockIdx.x; yg < NYG; yg += gridDim.x) {
+        // column y: NR contiguous compact rows; rows su >= 40 also stand for row -1-su
+        cx<double>* dst = bufA + slot * NPAD;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int ci = t + k * TPR;
+            if (ci < NR) {
+                const int su = ci - NAO / 2;
+                dst[lds_pad(su < 0 ? su + N : su)] = pre[k];
+                if (su >= NAO / 2) dst[lds_pad(N - 1 - su)] = pre[k];
+            }
+        }
+        if (threadIdx.x < SLOTS) smin[threadIdx.x] = 0x7f800000;
         __syncthreads();
-        if (threadIdx.x < SLOTS && y0 + (int)threadIdx.x <= N / 2)
-            dmin[(size_t)td * (N / 2 + 1) + y0 + threadIdx.x] = __int_as_float(smin[threadIdx.x]);
+        if (yg + (int)gridDim.x < NYG) fetch(yg + gridDim.x);
+        const cx<double>* res =
+            fft_forward<double, N, false>(bufA + slot * NPAD, bufB + slot * NPAD, tw, t);
+        const int y = yg * SLOTS + slot;
+        if (y <= N / 2) {
+            RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N;
+            float lo = __builtin_inff();
+            for (int x = t; x < N; x += TPR) {
+                const RO d = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
+                out[x] = d;
+                lo = fminf(lo, fmaxf((float)d, 0.f));
+            }
+            if (dmin != nullptr) {      // line minimum: shuffles within the line's lanes, then one atomic
+#pragma unroll
+                for (int o = (TPR < 64 ? TPR : 64) / 2; o > 0; o >>= 1) lo = fminf(lo, __shfl_xor(lo, o, 64));
+                if ((t & 63) == 0) atomicMin(&smin[slot], __float_as_int(lo));
+            }
+        }
+        __syncthreads();            // all reads of the result are done: the buffers may be restaged
+        if (dmin != nullptr && threadIdx.x < SLOTS && yg * SLOTS + (int)threadIdx.x <= N / 2)
+            dmin[(size_t)td * (N / 2 + 1) + yg * SLOTS + threadIdx.x] = __int_as_float(smin[threadIdx.x]);
     }
 }
 
@@ -419,7 +434,11 @@ void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const do
     DISPATCH_N(N, {
         constexpr int SL = LineCfg<NN>::SLOTS;
         constexpr size_t sm = fft_smem<double, NN>(true, fft_nbuf<NN>());
-        dim3 grid((NN / 2 + 1 + SL - 1) / SL, ntd);
+#ifndef MPSFR_COLFFT_ITERS
+#define MPSFR_COLFFT_ITERS 5
+#endif
+        constexpr int NYG = (NN / 2 + 1 + SL - 1) / SL;
+        dim3 grid((NYG + MPSFR_COLFFT_ITERS - 1) / MPSFR_COLFFT_ITERS, ntd);     // column groups per workgroup
         if (f64out) {
             allow_smem(k_colfft_dphi<NN, double>, sm);
             hipLaunchKernelGGL((k_colfft_dphi<NN, double>), grid, dim3(LineCfg<NN>::THREADS), sm, s,

@@ -29,7 +29,9 @@ k_moffat_kernels(const double* __restrict__ gam, const double* __restrict__ alp,
         double v = 0.0;
         if (e < KS * KS) {
             const int dy = e / KS - KS / 2, dx = e % KS - KS / 2;
-            v = pow(1.0 + (double)(dx * dx + dy * dy) / g2, -al);
+            const double x1 = 1.0 + (double)(dx * dx + dy * dy) / g2;
+            // the tip-tilt kernel has beta = 2 exactly (psfrec.py:879): no pow
+            v = al == 2.0 ? 1.0 / (x1 * x1) : pow(x1, -al);
         }
         vals[m] = v;
         s += v;
@@ -384,7 +386,9 @@ k_khat(const double* __restrict__ gam, const double* __restrict__ alp,
         double v = 0.0;
         if (e < KS * KS) {
             const int dy = e / KS - KS / 2, dx = e % KS - KS / 2;
-            v = pow(1.0 + (double)(dx * dx + dy * dy) / g2, -al);
+            const double x1 = 1.0 + (double)(dx * dx + dy * dy) / g2;
+            // the tip-tilt kernel has beta = 2 exactly (psfrec.py:879): no pow
+            v = al == 2.0 ? 1.0 / (x1 * x1) : pow(x1, -al);
         }
         vals[m] = v;
         s += v;
