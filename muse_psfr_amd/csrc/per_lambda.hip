@@ -801,7 +801,11 @@ static void launch_otf_r16_t(hipStream_t s, int ntask, int ndir, int nl, const v
                              const void* d_tel, const LamPar* d_lp, const void* d_xtab, void* d_Tq,
                              const void* d_tw64, const int* d_vkeep) {
     using P = R16<NN>;
-    const size_t sm = (size_t)P::LINES * P::NPAD * sizeof(cx<float>) + (size_t)nl * sizeof(float);
+#ifndef MPSFR_R16_EXTRA_LDS
+#define MPSFR_R16_EXTRA_LDS 0
+#endif
+    const size_t sm = (size_t)P::LINES * P::NPAD * sizeof(cx<float>) + (size_t)nl * sizeof(float) +
+                      MPSFR_R16_EXTRA_LDS;
     allow_smem(k_otf_r16<NN, ND, FE>, sm);
     const int ppg = otf_pairs_per_group(nl, d_vkeep != nullptr);
     dim3 grid((NN / 2 + 1 + P::LINES - 1) / P::LINES, ntask, ((nl + 1) / 2 + ppg - 1) / ppg);
