@@ -93,10 +93,12 @@ void launch_conv(hipStream_t s, int ntask, int nl, const void* d_pre, const void
                  const void* d_kmuse, double* d_fin, bool f64);
 void launch_khat(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
                  void* d_khat);
+// fin_f32 / stamps_f32: the final stamps are float (inside the pipeline) instead of double
 void launch_conv_fft(hipStream_t s, int ntask, int nl, const void* d_pre, const void* d_khat_tt,
-                     const void* d_khat_muse, double* d_fin);
-void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit, bool f64);
-void launch_stamp_sum(hipStream_t s, int ntask, int nl, const double* d_fin, double* d_sum,
+                     const void* d_khat_muse, void* d_fin, bool fin_f32);
+void launch_fit(hipStream_t s, int nstamp, const void* d_stamps, bool stamps_f32, double* d_fit,
+                bool f64);
+void launch_stamp_sum(hipStream_t s, int ntask, int nl, const void* d_fin, bool fin_f32, double* d_sum,
                       int accumulate);
 
 }  // namespace mpsfr

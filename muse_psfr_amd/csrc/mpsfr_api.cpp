@@ -774,26 +774,29 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
             ProfScope ps(c, K_COLPASS, ls);
             launch_colpass(ls, N, tc, nl, ln.Tq.p, c->G.p, ln.pre.p, c->f64, d_vkeep);
         }
-        double* d_fin = d_fin_all ? d_fin_all + (size_t)t0 * nl * per_stamp : (double*)ln.fin.p;
+        // final stamps: straight into the caller's device buffer (double), else a lane workspace --
+        // float when the FFT convolution produces them and nobody outside reads them
+        const bool fin_f32 = use_fft_conv && !d_fin_all && !(psf_out && !dev_out);
+        void* d_fin = d_fin_all ? (void*)(d_fin_all + (size_t)t0 * nl * per_stamp) : ln.fin.p;
         {
             ProfScope ps(c, K_CONV, ls);
             const size_t koff = (size_t)t0 * ksz;
             if (use_fft_conv)
                 launch_conv_fft(ls, tc, nl, ln.pre.p, (const char*)sl.ktt.p + koff,
-                                c->kmuse.p, d_fin);
+                                c->kmuse.p, d_fin, fin_f32);
             else
                 launch_conv(ls, tc, nl, ln.pre.p, (const char*)sl.ktt.p + koff,
-                            c->kmuse.p, d_fin, c->f64);
+                            c->kmuse.p, (double*)d_fin, c->f64);
         }
         if (fit_out) {
             ProfScope ps(c, K_FIT, ls);
-            launch_fit(ls, tc * nl, d_fin, d_fit_all + (size_t)t0 * nl * NFIT, c->f64);
+            launch_fit(ls, tc * nl, d_fin, fin_f32, d_fit_all + (size_t)t0 * nl * NFIT, c->f64);
         }
         if (psf_sum_out) {
             // per-lane partial sums in chunk order; combined below in lane order (deterministic)
             ProfScope ps(c, K_STAMP_SUM, ls);
             double* lsum = NL > 1 ? (double*)c->lsum.p + (size_t)j * nl * per_stamp : d_sum;
-            launch_stamp_sum(ls, tc, nl, d_fin, lsum, nchunk_lane[j] > 0 ? 1 : 0);
+            launch_stamp_sum(ls, tc, nl, d_fin, fin_f32, lsum, nchunk_lane[j] > 0 ? 1 : 0);
         }
         HIPCHK(hipGetLastError());
         if (!dev_out && psf_out) {
@@ -817,7 +820,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     if (psf_sum_out && NL > 1) {       // add the per-lane sums in lane order
         {
             ProfScope ps(c, K_STAMP_SUM);
-            launch_stamp_sum(s, NL, nl, (const double*)c->lsum.p, d_sum, 0);
+            launch_stamp_sum(s, NL, nl, c->lsum.p, false, d_sum, 0);
         }
         if (!c->lsum_done) HIPCHK(hipEventCreateWithFlags(&c->lsum_done, hipEventDisableTiming));
         HIPCHK(hipEventRecord(c->lsum_done, s));
@@ -850,7 +853,7 @@ int mpsfr_fit_stamps(mpsfr_ctx* c, int nstamp, const double* stamps, double* fit
     const size_t per = (size_t)NS * NS;
     if (on_device) {
         ProfScope ps(c, K_FIT);
-        launch_fit(s, nstamp, stamps, fit_out, c->f64);
+        launch_fit(s, nstamp, stamps, false, fit_out, c->f64);
         HIPCHK(hipGetLastError());
         return MPSFR_OK;
     }
@@ -861,7 +864,7 @@ int mpsfr_fit_stamps(mpsfr_ctx* c, int nstamp, const double* stamps, double* fit
     HIPCHK(hipMemcpyAsync(d_st, stamps, (size_t)nstamp * per * sizeof(double), hipMemcpyHostToDevice, s));
     {
         ProfScope ps(c, K_FIT);
-        launch_fit(s, nstamp, d_st, d_ft, c->f64);
+        launch_fit(s, nstamp, d_st, false, d_ft, c->f64);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(fit_out, d_ft, (size_t)nstamp * NFIT * sizeof(double), hipMemcpyDeviceToHost, s));

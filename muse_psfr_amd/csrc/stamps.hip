@@ -254,9 +254,12 @@ __device__ __forceinline__ void cf_split0(const cx<float>* res, int kx, cx<float
     a32 = {0.5f * (p.y + pm.y), -0.5f * (p.x - pm.x)};
 }
 
+// TF: type of the final stamps -- float inside the pipeline (their values are float anyway: the fit
+// and the stamp sum read half the bytes), double when they go straight into the caller's psf_out.
+template <typename TF>
 __global__ void __launch_bounds__(256)
 k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ khat_tt,
-           const cx<float>* __restrict__ khat_muse, double* __restrict__ fin) {
+           const cx<float>* __restrict__ khat_muse, TF* __restrict__ fin) {
     __shared__ cx<float> F[CF][CFP];
     __shared__ cx<float> bufs[CFH][CFB];
     const int l = blockIdx.x, task = blockIdx.y;
@@ -344,9 +347,9 @@ k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ 
                     const cx<float> v = res[lds_out<CF, 8>(c)];
                     const int i = 2 * slot, j = c - KS / 2;
                     if (pass == 1) {
-                        double* out = fin + ((size_t)task * nl + l) * NS * NS;
-                        out[i * NS + j] = (double)v.x;
-                        out[(i + 1) * NS + j] = (double)(-v.y);
+                        TF* out = fin + ((size_t)task * nl + l) * NS * NS;
+                        out[i * NS + j] = (TF)v.x;
+                        out[(i + 1) * NS + j] = (TF)(-v.y);
                     }
                 }
             }
@@ -657,7 +660,8 @@ __device__ __forceinline__ double sgpr(double x) {
     return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
 }
 
-__device__ __forceinline__ void moffat_gradient(const double* __restrict__ src, int lane,
+template <typename TS>
+__device__ __forceinline__ void moffat_gradient(const TS* __restrict__ src, int lane,
                                                 const double* v, double* gout, double* chi2out) {
     // Only the residual r = model - data needs fp64: a systematic 1e-6 error of the float
     // log/exp model is what biases the fit.  The Jacobian multiplies r, which is ~1e-3 of the
@@ -681,7 +685,7 @@ __device__ __forceinline__ void moffat_gradient(const double* __restrict__ src, 
         const double lg = lean_log(gg);
         const double e = lean_exp(-n * lg);
         const double mo = I * e;
-        const float r = (float)(mo - src[o]);
+        const float r = (float)(mo - (double)src[o]);
         c2sum += r * r;
         const float mof = (float)mo, uf = (float)u;
         const float cm = mof * nf * __builtin_amdgcn_rcpf((float)gg);
@@ -814,16 +818,16 @@ __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][
 template <typename RE>
 constexpr int fit_min_waves() { return sizeof(RE) == 4 ? MPSFR_FIT_WAVES : 2; }
 
-template <typename RE>
+template <typename RE, typename TS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fit_min_waves<RE>())))
-k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
+k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit) {
     constexpr int NPX = NS * NS / 64;                     // 25 pixels per lane
     static_assert(NPX * 64 == NS * NS, "the lane map assumes 1600 pixels");
     using S = RE;                                         // type of the LM state
     const int lane = threadIdx.x & 63;
     const int st = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (st >= nstamp) return;                             // the whole wave exits together
-    const double* src = stamps + (size_t)st * NS * NS;
+    const TS* src = stamps + (size_t)st * NS * NS;
     // the stamp in the evaluation type, LDS-resident for the LM evaluations (25 fewer VGPRs than
     // register-resident pixels: with the gradient-only polish this reaches 4 waves per SIMD, so
     // all 3500 stamps of the bench step are resident at once instead of in two rounds)
@@ -834,7 +838,7 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
 #pragma unroll
     for (int m = 0; m < NPX; ++m) {
         const int o = lane + m * 64;
-        const double d = src[o];
+        const double d = (double)src[o];
         sp[o] = (RE)d;
         if (d > best) { best = d; besto = o; }
     }
@@ -1007,7 +1011,8 @@ k_fit(int nstamp, const double* __restrict__ stamps, double* __restrict__ fit) {
 // K_STAMP_SUM: deterministic sum of the final stamps over the tasks of a chunk (PSF_MEAN numerator,
 // psfrec.py:1104).  64 outputs per workgroup; wave w adds tasks w, w+4, ... and the four partial
 // sums are combined in a fixed order.
-__global__ void __launch_bounds__(256) k_stamp_sum(int ntask, int nl, const double* __restrict__ fin,
+template <typename TF>
+__global__ void __launch_bounds__(256) k_stamp_sum(int ntask, int nl, const TF* __restrict__ fin,
                                                    double* __restrict__ sum, int accumulate) {
     __shared__ double part[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1015,7 +1020,7 @@ __global__ void __launch_bounds__(256) k_stamp_sum(int ntask, int nl, const doub
     const size_t per = (size_t)nl * NS * NS;
     double s = 0.0;
     if (e < per)
-        for (int t = wave; t < ntask; t += 4) s += fin[(size_t)t * per + e];
+        for (int t = wave; t < ntask; t += 4) s += (double)fin[(size_t)t * per + e];
     part[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && e < per) {
@@ -1061,28 +1066,43 @@ void launch_khat(hipStream_t s, int nker, const double* d_gamma, const double* d
 }
 
 void launch_conv_fft(hipStream_t s, int ntask, int nl, const void* d_pre, const void* d_khat_tt,
-                     const void* d_khat_muse, double* d_fin) {
-    hipLaunchKernelGGL(k_conv_fft, dim3(nl, ntask), dim3(256), 0, s, nl, (const float*)d_pre,
-                       (const cx<float>*)d_khat_tt, (const cx<float>*)d_khat_muse, d_fin);
+                     const void* d_khat_muse, void* d_fin, bool fin_f32) {
+    if (fin_f32)
+        hipLaunchKernelGGL(k_conv_fft<float>, dim3(nl, ntask), dim3(256), 0, s, nl, (const float*)d_pre,
+                           (const cx<float>*)d_khat_tt, (const cx<float>*)d_khat_muse, (float*)d_fin);
+    else
+        hipLaunchKernelGGL(k_conv_fft<double>, dim3(nl, ntask), dim3(256), 0, s, nl, (const float*)d_pre,
+                           (const cx<float>*)d_khat_tt, (const cx<float>*)d_khat_muse, (double*)d_fin);
 }
 
-void launch_fit(hipStream_t s, int nstamp, const double* d_stamps, double* d_fit, bool f64) {
+void launch_fit(hipStream_t s, int nstamp, const void* d_stamps, bool stamps_f32, double* d_fit,
+                bool f64) {
     if (nstamp <= 0) return;
     // One wavefront per stamp, four stamps per workgroup.  (A whole workgroup per stamp with the
     // wave sums meeting in LDS measured 1.8x slower at 3500 stamps: every wave repeats the 5x5
     // solves and the iterations serialise on barriers.)
     const dim3 grid((nstamp + 3) / 4);
     if (f64)
-        hipLaunchKernelGGL(k_fit<double>, grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
+        hipLaunchKernelGGL((k_fit<double, double>), grid, dim3(256), 0, s, nstamp,
+                           (const double*)d_stamps, d_fit);
+    else if (stamps_f32)
+        hipLaunchKernelGGL((k_fit<float, float>), grid, dim3(256), 0, s, nstamp, (const float*)d_stamps,
+                           d_fit);
     else
-        hipLaunchKernelGGL(k_fit<float>, grid, dim3(256), 0, s, nstamp, d_stamps, d_fit);
+        hipLaunchKernelGGL((k_fit<float, double>), grid, dim3(256), 0, s, nstamp,
+                           (const double*)d_stamps, d_fit);
 }
 
-void launch_stamp_sum(hipStream_t s, int ntask, int nl, const double* d_fin, double* d_sum,
+void launch_stamp_sum(hipStream_t s, int ntask, int nl, const void* d_fin, bool fin_f32, double* d_sum,
                       int accumulate) {
     const size_t per = (size_t)nl * NS * NS;
-    hipLaunchKernelGGL(k_stamp_sum, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, ntask, nl,
-                       d_fin, d_sum, accumulate);
+    const dim3 grid((unsigned)((per + 63) / 64));
+    if (fin_f32)
+        hipLaunchKernelGGL(k_stamp_sum<float>, grid, dim3(256), 0, s, ntask, nl, (const float*)d_fin,
+                           d_sum, accumulate);
+    else
+        hipLaunchKernelGGL(k_stamp_sum<double>, grid, dim3(256), 0, s, ntask, nl, (const double*)d_fin,
+                           d_sum, accumulate);
 }
 
 
