@@ -204,6 +204,8 @@ def main():
                 c.set_option('streams', a.streams)
             if prune_eps >= 0 and precision == 'mixed':
                 c.set_option('prune_eps', prune_eps)
+            if os.environ.get('MPSFR_OTF_MFMA') and precision == 'mixed':     # experiments: 0 = FFT path
+                c.set_option('otf_mfma', int(os.environ['MPSFR_OTF_MFMA']))
             if os.environ.get('MPSFR_PRUNE_FIXED') and precision == 'mixed':
                 c.set_option('prune_fixed', int(os.environ['MPSFR_PRUNE_FIXED']))
             ctxs.append(c)

@@ -68,10 +68,14 @@ struct mpsfr_ctx {
     bool fft_conv = true;   // mixed mode: convolutions through 64-point FFTs
     int prune_fixed = 0;         // experiments: transform exactly this many lines (wrong results)
     double prune_eps = 1.0e-9;   // mixed mode: line pruning of the per-wavelength stage (0 = off)
+    bool otf_mfma = true;        // mixed mode: per-wavelength stage on the matrix cores (otf_mfma.hip)
+    bool otf_mfma_ndir = false;  // ... also with several directions (generic kernel)
+    bool mf_clock = false;       // experiments: phase time stamps of the matrix-core kernel
+    DevBuf mfclk;
     // constant tables
-    DevBuf tw64, tel, rows, tlmax;
+    DevBuf tw64, tel, rows, tlmax, tl2, tlb;
     // per-call tables
-    DevBuf aotab, samp_p, samp_a, G, kmuse, xtab;
+    DevBuf aotab, samp_p, samp_a, G, kmuse, xtab, etab, gtab;
     // Pipeline lanes: each lane owns a HIP stream and a set of chunk workspaces.  Consecutive
     // chunks -- of one call or of consecutive asynchronous calls -- go to successive lanes, so one
     // chunk's low-occupancy tail (convolutions, fit) overlaps the next chunk's transforms.
@@ -80,7 +84,7 @@ struct mpsfr_ctx {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;       // after the lane's last chunk of the most recent call
         bool busy = false;               // `done` has been recorded
-        DevBuf C, s00, D0t, Tq, pre, fin, dmin, vkeep;
+        DevBuf C, s00, D0t, Tq, pre, fin, dmin, vkeep, dminb;
         const void* outs[3] = {nullptr, nullptr, nullptr};   // device outputs of its latest call
     };
     static constexpr int MAX_LANES = 4;
@@ -119,6 +123,9 @@ struct mpsfr_ctx {
     const void* cache_kmuse_ptr = nullptr;
     const void* cache_xtab_ptr = nullptr;
     bool cache_xtab_valid = false;
+    const void* cache_etab_ptr = nullptr;
+    const void* cache_gtab_ptr = nullptr;
+    bool cache_mf_valid = false;
     std::vector<unsigned char> cache_geom;
     const void* cache_ao_ptr = nullptr;
     // bookkeeping for debug_fetch
@@ -306,6 +313,10 @@ int build_constant_tables(mpsfr_ctx* c) {
     if (!c->f64) {      // log2 of the line maxima of the telescope OTF (line pruning, stage_a.hip)
         if ((rc = ensure(c, c->tlmax, (size_t)(H + 1) * sizeof(float)))) return rc;
         launch_tel_linemax(c->stream, N, c->tel.p, (float*)c->tlmax.p);
+        // log2 of the telescope OTF and of its block maxima (otf_mfma.hip)
+        if ((rc = ensure(c, c->tl2, mf_tl2_bytes(N)))) return rc;
+        if ((rc = ensure(c, c->tlb, mf_tlb_bytes(N)))) return rc;
+        launch_mf_tel(c->stream, N, c->tel.p, (float*)c->tl2.p, (float*)c->tlb.p);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -376,7 +387,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         mpsfr_ctx::Lane& ln = c->lane[k];
         if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
         if (ln.done) (void)hipEventDestroy(ln.done);
-        DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.dmin, &ln.vkeep};
+        DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.dmin, &ln.vkeep, &ln.dminb};
         for (auto b : lb) release(*b);
     }
     for (int k = 0; k < mpsfr_ctx::NSTAGE; ++k) {
@@ -387,8 +398,9 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         release(sl.params);
         release(sl.ktt);
     }
-    DevBuf* all[] = {&c->tw64, &c->tel, &c->rows, &c->tlmax, &c->aotab, &c->samp_p, &c->samp_a, &c->G,
-                     &c->xtab, &c->kmuse, &c->fit, &c->sum, &c->stage, &c->lsum};
+    DevBuf* all[] = {&c->tw64, &c->tel, &c->rows, &c->tlmax, &c->tl2, &c->tlb, &c->aotab, &c->samp_p,
+                     &c->samp_a, &c->G, &c->xtab, &c->etab, &c->gtab, &c->kmuse, &c->fit, &c->sum,
+                     &c->stage, &c->lsum, &c->mfclk};
     for (auto b : all) release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -410,6 +422,17 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
     } else if (!strcmp(key, "prune_eps")) {
         if (!(value >= 0.0) || value > 1.0e-3) return fail(MPSFR_E_INVALID, "prune_eps must be in [0, 1e-3]");
         c->prune_eps = value;
+    } else if (!strcmp(key, "otf_mfma")) {
+        c->otf_mfma = value != 0.0;
+    } else if (!strcmp(key, "otf_mfma_ndir")) {
+        c->otf_mfma_ndir = value != 0.0;
+    } else if (!strcmp(key, "mf_clock")) {
+        c->mf_clock = value != 0.0;
+        if (c->mf_clock) {
+            const int rc = ensure(c, c->mfclk, (size_t)65536 * 8 * 8 * sizeof(unsigned long long));
+            if (rc) return rc;
+            HIPCHK(hipMemset(c->mfclk.p, 0, c->mfclk.cap));
+        }
     } else if (!strcmp(key, "pipeline_calls")) {
         c->pipeline_calls = value != 0.0;
     } else if (!strcmp(key, "fft_conv")) {
@@ -636,8 +659,16 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     // G rows are padded to a multiple of 8 lines (paired-line layout of the fp32 second pass)
     if ((rc = ensure(c, c->G, (size_t)nl * ((H1 + 7) / 8 * 8) * NS * 2 * rsize(c)))) return rc;
     if ((rc = ensure(c, c->kmuse, (size_t)nl * ksz))) return rc;
-    const bool r16 = otf_uses_r16(N, c->f64, nl, ndir);
+    // per-wavelength stage on the matrix cores: single direction (with several directions the OTF
+    // tile costs ndir exponentials per element and the FFT kernels, which keep D in registers
+    // over all wavelengths, measure 8 % faster at 256^2 x 9 directions)
+    const bool mf = !c->f64 && c->otf_mfma && (ndir == 1 || c->otf_mfma_ndir);
+    const bool r16 = !mf && otf_uses_r16(N, c->f64, nl, ndir);
     if (r16 && (rc = ensure(c, c->xtab, xtab_bytes(nl)))) return rc;
+    if (mf) {
+        if ((rc = ensure(c, c->etab, mf_etab_bytes(N, nl)))) return rc;
+        if ((rc = ensure(c, c->gtab, mf_gtab_bytes(N, nl)))) return rc;
+    }
     std::vector<unsigned char> key(sizeof(AoGeom) + 1 + (mask_rec ? 2 * NAO * NAO : 0));
     memcpy(key.data(), &g, sizeof(AoGeom));
     key[sizeof(AoGeom)] = mask_rec ? 1 : 0;
@@ -649,7 +680,9 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     const std::vector<double> lb_key(lbda_nm, lbda_nm + nl);
     const bool lam_cached = lb_key == c->cache_lbda && c->cache_lbda_mode == (use_fft_conv ? 1 : 0) &&
                             c->cache_G_ptr == c->G.p && c->cache_kmuse_ptr == c->kmuse.p &&
-                            (!r16 || (c->cache_xtab_valid && c->cache_xtab_ptr == c->xtab.p));
+                            (!r16 || (c->cache_xtab_valid && c->cache_xtab_ptr == c->xtab.p)) &&
+                            (!mf || (c->cache_mf_valid && c->cache_etab_ptr == c->etab.p &&
+                                     c->cache_gtab_ptr == c->gtab.p));
     if (!ao_cached || !lam_cached) {
         for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
             if (c->lane[k].busy && c->lane[k].stream != s0)
@@ -667,6 +700,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
                               c->f64);
                 if (r16)
                     launch_xtab(s0, N, nl, (const int*)c->samp_p.p, c->samp_a.p, c->tw64.p, c->xtab.p);
+                if (mf) launch_mf_tables(s0, N, nl, d_lp, c->tw64.p, c->etab.p, c->gtab.p);
             }
             ProfScope ps(c, K_MOFFAT_KERNELS, s0);
             if (use_fft_conv) launch_khat(s0, nl, d_gam + ntask, d_alp + ntask, c->kmuse.p);
@@ -677,6 +711,9 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
             c->cache_kmuse_ptr = c->kmuse.p;
             c->cache_xtab_ptr = c->xtab.p;
             c->cache_xtab_valid = r16;
+            c->cache_etab_ptr = c->etab.p;
+            c->cache_gtab_ptr = c->gtab.p;
+            c->cache_mf_valid = mf;
         }
         if (!c->cache_ready) HIPCHK(hipEventCreateWithFlags(&c->cache_ready, hipEventDisableTiming));
         HIPCHK(hipEventRecord(c->cache_ready, s0));
@@ -699,18 +736,29 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     // plane that together weigh less than eps of the PSF peak are neither transformed nor read
     // by the second pass (stage_a.hip, "Line pruning").
     const bool prune = !c->f64 && c->prune_eps > 0.0;
-    const float thr_sum = prune ? (float)(c->prune_eps / (2.0 * N * ndir)) : 0.f;
+    // matrix-core path: half of eps for the lines, half for the 16 x 32 blocks inside them (every
+    // element of a dropped block is below 2^thr_blk; both half planes, all directions)
+    const float thr_sum = prune ? (float)((mf ? 0.5 : 1.0) * c->prune_eps / (2.0 * N * ndir)) : 0.f;
+    const float thr_blk = (prune && mf)
+        ? (float)std::log2(0.5 * c->prune_eps / (2.0 * ndir * 16 * 32 * mf_block_count(N))) : 0.f;
     for (int j = 0; j < NL; ++j) {
         mpsfr_ctx::Lane& ln = lane_of(j);
         // row FFTs of the PSD: only the N/2 + 40 distinct rows are stored (K_PSD_ROWFFT)
         if ((rc = ensure(c, ln.C, (size_t)TC * ndir * (N / 2 + NAO / 2) * H1 * 2 * sizeof(double)))) return rc;
         if ((rc = ensure(c, ln.s00, (size_t)TC * ndir * sizeof(double)))) return rc;
-        if ((rc = ensure(c, ln.D0t, (size_t)TC * ndir * H1 * N * rsize(c)))) return rc;
-        if ((rc = ensure(c, ln.Tq, (size_t)TC * nl * H1 * NSH * 2 * rsize(c)))) return rc;
+        {   // 16 lines of padding behind D: the last m-tile of the matrix-core kernel reads past line
+            // N/2 (where its telescope table is -inf); fresh memory is zeroed so that what it reads
+            // there is always a finite number
+            const void* before = ln.D0t.p;
+            if ((rc = ensure(c, ln.D0t, ((size_t)TC * ndir * H1 + 16) * N * rsize(c)))) return rc;
+            if (ln.D0t.p != before) HIPCHK(hipMemset(ln.D0t.p, 0, ln.D0t.cap));
+        }
+        if (!mf && (rc = ensure(c, ln.Tq, (size_t)TC * nl * H1 * NSH * 2 * rsize(c)))) return rc;
         if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * (c->f64 ? 8 : 4)))) return rc;
         if ((rc = ensure(c, ln.fin, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
         if (prune) {
-            if ((rc = ensure(c, ln.dmin, (size_t)TC * ndir * H1 * sizeof(float)))) return rc;
+            if ((rc = ensure(c, ln.dmin, (size_t)TC * ndir * H1 * (N / 32) * sizeof(float)))) return rc;
+            if (mf && (rc = ensure(c, ln.dminb, mf_dminb_bytes(N, TC)))) return rc;
             if ((rc = ensure(c, ln.vkeep, (size_t)TC * ((nl + 1) / 2) * sizeof(int)))) return rc;
         }
     }
@@ -761,16 +809,22 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
                                c->f64, c->tw64.p, prune ? (float*)ln.dmin.p : nullptr);
             if (prune)
                 launch_vkeep(ls, N, tc, ndir, nl, d_lp, (const float*)ln.dmin.p,
-                             (const float*)c->tlmax.p, thr_sum, (int*)ln.vkeep.p, c->prune_fixed);
+                             (const float*)c->tlmax.p, thr_sum, (int*)ln.vkeep.p, c->prune_fixed,
+                             mf ? (float*)ln.dminb.p : nullptr);
         }
         const int* d_vkeep = prune ? (const int*)ln.vkeep.p : nullptr;
-        {
+        if (mf) {
             ProfScope ps(c, K_OTF_ROWFFT, ls);
-            launch_otf_rowfft(ls, N, tc, ndir, nl, ln.D0t.p, c->tel.p, d_lp,
-                              (const int*)c->samp_p.p, c->samp_a.p, c->xtab.p, ln.Tq.p, c->tw64.p,
-                              c->f64, c->fast_exp, d_vkeep);
-        }
-        {
+            launch_otf_mfma(ls, N, tc, ndir, nl, ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
+                            c->gtab.p, d_vkeep, prune ? (const float*)ln.dminb.p : nullptr,
+                            (const float*)c->tlb.p, thr_blk, ln.pre.p, c->mf_clock ? c->mfclk.p : nullptr);
+        } else {
+            {
+                ProfScope ps(c, K_OTF_ROWFFT, ls);
+                launch_otf_rowfft(ls, N, tc, ndir, nl, ln.D0t.p, c->tel.p, d_lp,
+                                  (const int*)c->samp_p.p, c->samp_a.p, c->xtab.p, ln.Tq.p, c->tw64.p,
+                                  c->f64, c->fast_exp, d_vkeep);
+            }
             ProfScope ps(c, K_COLPASS, ls);
             launch_colpass(ls, N, tc, nl, ln.Tq.p, c->G.p, ln.pre.p, c->f64, d_vkeep);
         }
@@ -895,6 +949,13 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
         n = (size_t)c->last_chunk_tasks * c->last_nl * NS * NS;
         src = c->lane[c->last_lane].pre.p;
         is_real_r = true;
+    } else if (!strcmp(what, "mf_clock")) {
+        if (!c->mfclk.p) return fail(MPSFR_E_INVALID, "mf_clock is off");
+        n = capacity < (size_t)65536 * 64 ? capacity : (size_t)65536 * 64;
+        std::vector<unsigned long long> tmp(n);
+        HIPCHK(hipMemcpy(tmp.data(), c->mfclk.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) out[i] = (double)tmp[i];
+        return (long)n;
     } else if (!strcmp(what, "vkeep")) {
         if (c->f64 || !(c->prune_eps > 0.0)) return fail(MPSFR_E_INVALID, "line pruning is off");
         n = (size_t)c->last_chunk_tasks * ((c->last_nl + 1) / 2);

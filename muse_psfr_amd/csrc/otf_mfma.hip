@@ -1,0 +1,763 @@
+// Per-wavelength stage of the mixed-precision path on the matrix cores (gfx950, wave64).
+// Reference citations are to /root/reference/muse_psfr/psfrec.py.
+//
+// What the stage computes: for every (task, wavelength) the 40 x 40 stamp
+//     stamp[i][j] = sum_v sum_u  G[v][j] * OTF[v][u] * E[u][i]              (psfrec.py:672-685, 793-801)
+// with OTF[v][u] = tel[v][u] sum_dir 2^(c D[v][u]) on the transposed half plane, E the bilinear-
+// weighted DFT kernel of the 21 distinct sample positions along a line and G the same along the
+// columns.  psf_muse only ever reads the four bilinear neighbours of 40 x 40 sample points of the
+// N x N transform, so the "2-D FFT" is two small dense contractions with the OTF in the middle:
+//     first pass  Tq[v][c] = sum_u OTF[v][u] E[u][c]       (lines x 42 real columns, K = N)
+//     second pass P/Q[i][j] = sum_v Tq[v][i] G[v][j]        (21 x 21, K = lines kept)
+// Both run on v_mfma_f32_16x16x32_f16 / 16x16x16_f16 with every operand split into two halves
+// (x = hi + lo, three products hi*hi + lo*hi + hi*lo, fp32 accumulation): 22 significant bits per
+// operand, i.e. the rounding of an fp32 product, at 16/3 of the fp32 matrix (= vector) rate.  The
+// LDS-resident line FFTs this replaces ran at 0.3 of the fp32 vector peak, bound by the LDS
+// store path; a dense contraction also prunes in BOTH directions (blocks of 16 lines x 32 columns
+// whose elements are all below the bound are never generated), which an FFT cannot.
+//
+// One wavefront owns one (task, wavelength): no LDS, no barrier, no inter-wave reduction; the
+// result is bit-identical for any chunking or lane count.  The OTF tile is generated in registers
+// in the A-operand layout (one fma + v_exp_f32 per element), the E / G tables are pre-split fp16 in
+// the B-operand layout (cached per wavelength set), and the accumulator tile of the first pass
+// is, as it stands, the A operand of the second (its rows are the contraction index).
+#include "device_common.h"
+
+namespace mpsfr {
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int MTL = 16;      // lines per m-tile
+constexpr int KBL = 32;      // columns (u) per k-step
+constexpr int NCT = 3;       // column tiles of the first pass: 48 >= 42 real columns
+constexpr int NJT = 2;       // column tiles of the second pass: 32 >= 21
+// The OTF (<= 1, times the number of directions) is generated times 2^kShift: the low half of an
+// element stays a normal fp16 number down to 2^-14 / 2^-12 of 2^kShift, i.e. elements down to
+// 1.2e-4 keep 22 bits, smaller ones an absolute 3e-11.  The stamp is normalised to sum 1 at the end
+// (psfrec.py:685), so the factor drops out.
+constexpr float kShift = 11.0f;
+
+__host__ __device__ constexpr int mf_nks(int N) { return N / KBL; }
+__host__ __device__ constexpr int mf_nmt(int N) { return (N / 2 + 1 + MTL - 1) / MTL; }
+
+// Column c of the first pass -> (sample i, real / imaginary part); -1 = padding.
+//   tile 0: Re i = 0..15      tile 1: Im i = 0..15      tile 2: c-32 = 0..4 Re 16..20, 8..12 Im 16..20
+__host__ __device__ inline int col_sample(int c, bool* imag) {
+    if (c < 16) { *imag = false; return c; }
+    if (c < 32) { *imag = true; return c - 16; }
+    const int r = c - 32;
+    if (r < 5) { *imag = false; return 16 + r; }
+    if (r >= 8 && r < 13) { *imag = true; return 16 + r - 8; }
+    return -1;
+}
+
+__device__ __forceinline__ void split16(float x, _Float16* hi, _Float16* lo) {
+    const _Float16 h = (_Float16)x;
+    *hi = h;
+    *lo = (_Float16)(x - (float)h);
+}
+
+// ------------------------------------------------------------------------------------------
+// K_MF_TABLES: per-wavelength operand tables, cached per wavelength set.
+//   E[l][ks][ct][hl][lane] (8 fp16): B operand of the first pass.  Lane supplies column
+//     c = 16 ct + (lane & 15) for u = 32 ks + 8 (lane >> 4) + 0..7;
+//     E_i(u) = (1-a_i) W^(u p_i) + a_i W^(u (p_i+1)),  W = exp(-2 pi i / N)   (forward transform
+//     of the line sampled at the bilinear neighbours p_i, p_i + 1 of psfrec.py:672-683).
+//   G[l][mt][jt][xy][hl][lane] (4 fp16): B operand of the second pass.  Lane supplies column
+//     j = 16 jt + (lane & 15) for v = 16 mt + 4 (lane >> 4) + 0..3;
+//     G[v][j] = w_v conj((1-a_j) W^(v p_j) + a_j W^(v (p_j+1))),  w_v = 1 for v in {0, N/2}, 2
+//     otherwise (the other half plane), 0 for padding lines.
+// Sample i of the 40-pixel stamp sits at i npixc / 40 of the centred crop: left neighbour
+// p_i = (floor(i npixc / 40) - npixc / 2) mod N with weight 1 - a_i, a_i = frac.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_mf_tables(int N, int nl, const LamPar* __restrict__ lp, const cx<double>* __restrict__ twg,
+            h8* __restrict__ E, h4* __restrict__ G) {
+    const int l = blockIdx.y;
+    const int npixc = lp[l].npixc;
+    const int nks = mf_nks(N), nmt = mf_nmt(N);
+    const int nE = nks * NCT * 64, nG = nmt * NJT * 2 * 64;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    auto sample = [&](int i, int* p, double* a) {
+        const int q = i * npixc;
+        *p = ((q / NS - npixc / 2) % N + N) % N;
+        *a = (double)(q % NS) / NS;
+    };
+    if (idx < nE) {
+        const int lane = idx & 63, ct = (idx >> 6) % NCT, ks = (idx >> 6) / NCT;
+        bool imag;
+        const int i = col_sample(16 * ct + (lane & 15), &imag);
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float val = 0.f;
+            if (i >= 0) {
+                const int u = KBL * ks + 8 * (lane >> 4) + e;
+                int p;
+                double a;
+                sample(i, &p, &a);
+                const cx<double> w0 = twg[(int)(((long)u * p) % N)];
+                const cx<double> w1 = twg[(int)(((long)u * (p + 1)) % N)];
+                val = (float)(imag ? (1.0 - a) * w0.y + a * w1.y : (1.0 - a) * w0.x + a * w1.x);
+            }
+            _Float16 h, q;
+            split16(val, &h, &q);
+            hi[e] = h;
+            lo[e] = q;
+        }
+        h8* dst = E + ((size_t)(l * nks + ks) * NCT + ct) * 2 * 64;
+        dst[lane] = hi;
+        dst[64 + lane] = lo;
+    }
+    if (idx < nG) {
+        const int lane = idx & 63, xy = (idx >> 6) & 1, jt = (idx >> 7) % NJT, mt = (idx >> 7) / NJT;
+        const int j = 16 * jt + (lane & 15);
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int v = MTL * mt + 4 * (lane >> 4) + e;
+            float val = 0.f;
+            if (j < NSH && v <= N / 2) {
+                int p;
+                double a;
+                sample(j, &p, &a);
+                const cx<double> w0 = twg[(int)(((long)v * p) % N)];
+                const cx<double> w1 = twg[(int)(((long)v * (p + 1)) % N)];
+                const double wv = (v == 0 || v == N / 2) ? 1.0 : 2.0;
+                // conj(W^(v p)): the imaginary part changes sign
+                val = (float)(xy ? -wv * ((1.0 - a) * w0.y + a * w1.y) : wv * ((1.0 - a) * w0.x + a * w1.x));
+            }
+            _Float16 h, q;
+            split16(val, &h, &q);
+            hi[e] = h;
+            lo[e] = q;
+        }
+        h4* dst = G + (((size_t)(l * nmt + mt) * NJT + jt) * 2 + xy) * 2 * 64;
+        dst[lane] = hi;
+        dst[64 + lane] = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K_MF_TEL: constant tables of the telescope OTF (once per context).
+//   tl2[v][u] = log2 tel[v][u] + kShift  (-inf where tel = 0 and on the padding lines v > N/2):
+//               the telescope OTF goes into the exponent, tel 2^(c D) = 2^(c D + log2 tel)
+//   tlb[mt][ks] = log2 of the block maximum of tel (block pruning, see K_OTF_MFMA)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_mf_tel(int N, const float* __restrict__ telT, float* __restrict__ tl2, float* __restrict__ tlb) {
+    const int mt = blockIdx.x, nks = mf_nks(N);
+    __shared__ float bmax[64];
+    if (threadIdx.x < 64) bmax[threadIdx.x] = 0.f;
+    __syncthreads();
+    for (int e = threadIdx.x; e < MTL * N; e += 256) {
+        const int v = MTL * mt + e / N, u = e % N;
+        const float t = v <= N / 2 ? telT[(size_t)v * N + u] : 0.f;
+        tl2[(size_t)v * N + u] = __builtin_amdgcn_logf(t) + kShift;        // log2(0) = -inf
+        atomicMax(reinterpret_cast<int*>(&bmax[u / KBL]), __float_as_int(t));   // t >= 0: int order
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nks) tlb[mt * nks + threadIdx.x] = __builtin_amdgcn_logf(bmax[threadIdx.x]);
+}
+
+// three fp16 products for one fp32-grade product: c += a b with a = ahi + alo, b = bhi + blo
+__device__ __forceinline__ f4 mm16(f4 c, h4 ahi, h4 alo, h4 bhi, h4 blo) {
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(alo, bhi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(ahi, blo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(ahi, bhi, c, 0, 0, 0);
+}
+
+// Epilogue of the per-wavelength kernels: the second-pass tiles of one wave -> the 40 x 40 stamp.
+__device__ __forceinline__ void write_stamp(const f4* P0, const f4* Q0, const f4* R2x, const f4* R2y,
+                                            int lr, int lk, float* __restrict__ out) {
+    // Epilogue.  Result tiles: column j = 16 jt + lr on the lane, row 4 lk + r in register r.
+    //   P0 / Q0: rows = samples i = 0..15;  R2x rows 0..4 = P of i = 16..20;  R2y rows 8..12 = Q of
+    //   i = 16..20 (32 lanes away).  stamp[i][j] = P + Q, and with Tq[v][40-i] = conj Tq[v][i],
+    //   G[v][40-j] = conj G[v][j]:  stamp[40-i][j] = stamp[i][40-j] = P - Q,  stamp[40-i][40-j] = P + Q.
+    // Clamp (psfrec.py:680), normalise to sum 1 (:685).
+    float va[2 * NJT * 4], vb[2 * NJT * 4];     // P + Q, P - Q (clamped); first the 0..15 rows
+    float part = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        const int jj = 16 * jt + lr;
+        const bool jok = jj < NSH;
+        const float mj = (jj >= 1 && jj <= NS / 2 - 1) ? 1.f : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float qhi = __shfl_xor(R2y[jt][r], 32, 64);
+#pragma unroll
+            for (int top = 0; top < 2; ++top) {
+                const int row = 4 * lk + r;
+                const int ii = top ? 16 + row : row;
+                const bool ok = jok && (top ? row < 5 : true);
+                const float Pv = top ? R2x[jt][r] : P0[jt][r];
+                const float Qv = top ? qhi : Q0[jt][r];
+                const float pa = ok ? fmaxf(Pv + Qv, 0.f) : 0.f;
+                const float pb = ok ? fmaxf(Pv - Qv, 0.f) : 0.f;
+                const float mi = (ii >= 1 && ii <= NS / 2 - 1) ? 1.f : 0.f;
+                part += pa * (1.f + mi * mj) + pb * (mi + mj);
+                va[(top * NJT + jt) * 4 + r] = pa;
+                vb[(top * NJT + jt) * 4 + r] = pb;
+            }
+        }
+    }
+    const double tot = wave_sum((double)part);
+    const float inv = (float)(1.0 / tot);
+#pragma unroll
+    for (int top = 0; top < 2; ++top)
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * lk + r, ii = top ? 16 + row : row, jj = 16 * jt + lr;
+                if (jj >= NSH || (top && row >= 5)) continue;
+                const float pa = va[(top * NJT + jt) * 4 + r] * inv, pb = vb[(top * NJT + jt) * 4 + r] * inv;
+                const bool mi = ii >= 1 && ii <= NS / 2 - 1, mj = jj >= 1 && jj <= NS / 2 - 1;
+                out[ii * NS + jj] = pa;
+                if (mi) out[(NS - ii) * NS + jj] = pb;
+                if (mj) out[ii * NS + NS - jj] = pb;
+                if (mi && mj) out[(NS - ii) * NS + NS - jj] = pa;
+            }
+}
+
+// ------------------------------------------------------------------------------------------
+// K_OTF_MFMA.  One wavefront per (task, wavelength); a workgroup is four tasks at one wavelength
+// (their E / G table reads meet in the L1), and the workgroups of one task follow each other on
+// the same XCD (its D lines stay in that L2).
+//
+// Pruning.  vkeep[task][pair] (K_VKEEP, stage_a.hip) bounds the lines; inside them a block of
+// 16 lines x 32 columns is generated only if  2^(c' dminb + tlb) > 2^thr,  dminb the block minimum
+// of D over lines, columns and directions (K_VKEEP) and tlb the block maximum of log2 tel: every
+// element of a dropped block is below 2^thr, and the host sets thr so that all blocks together
+// weigh less than eps / 2 of the PSF peak (>= OTF[0][0] = 1).
+// ------------------------------------------------------------------------------------------
+#ifndef MPSFR_MF_GROUP
+#define MPSFR_MF_GROUP 8        // m-tiles accumulated per sweep over the k-steps
+#endif
+#ifndef MPSFR_MF_WAVES
+#define MPSFR_MF_WAVES 2
+#endif
+
+struct MfArgs {
+    int N, ntask, ndir, nl;
+    const float* D0t;        // [ntask ndir][N/2+1][N]
+    const float* tl2;        // [nmt 16][N]
+    const LamPar* lp;
+    const h8* E;
+    const h4* G;
+    const int* vkeep;        // [ntask][(nl+1)/2] or nullptr
+    const float* dminb;      // [ntask][nmt][nks] or nullptr
+    const float* tlb;        // [nmt][nks]
+    float thr;               // log2 of the block threshold
+    float tq_scale;          // 2^-ceil(log2 N): first-pass sums back into the fp16 range
+    float* pre;              // [ntask][nl][40][40]
+    unsigned long long* clk; // experiments: per-wave phase time stamps (or nullptr)
+};
+
+template <bool ONE_DIR>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MPSFR_MF_WAVES, MPSFR_MF_WAVES)))
+k_otf_mfma(const MfArgs a) {
+    constexpr int GRP = MPSFR_MF_GROUP;
+    const int N = a.N, H1 = N / 2 + 1, nks = mf_nks(N), nmt_all = mf_nmt(N);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    // workgroup -> (task quad, wavelength): consecutive blockIdx go round the 8 XCDs, so the
+    // logical index runs through one XCD's share before the next one's
+    const int nwg = gridDim.x, per_xcd = (nwg + 7) / 8;
+    const int q = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int ntq = (a.ntask + 3) / 4;
+    if (q >= ntq * a.nl) return;
+    const int l = q % a.nl, task = (q / a.nl) * 4 + wave;
+    if (task >= a.ntask) return;
+    const float c2 = (float)a.lp[l].c * 1.44269504088896340736f;
+    const int nv = a.vkeep != nullptr ? a.vkeep[(size_t)task * ((a.nl + 1) / 2) + (l >> 1)] : H1;
+    const int nmt = (nv + MTL - 1) / MTL;
+
+    f4 P0[NJT], Q0[NJT], R2x[NJT], R2y[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        P0[jt] = f4{0.f, 0.f, 0.f, 0.f};
+        Q0[jt] = f4{0.f, 0.f, 0.f, 0.f};
+        R2x[jt] = f4{0.f, 0.f, 0.f, 0.f};
+        R2y[jt] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    const size_t dstride = (size_t)H1 * N;
+    const float* Dtask = a.D0t + (size_t)task * a.ndir * dstride + 8 * lk;
+    const float* Tl = a.tl2 + 8 * lk;
+    const h8* El = a.E + (size_t)l * nks * NCT * 2 * 64 + lane;
+    const h4* Gl = a.G + (size_t)l * nmt_all * NJT * 2 * 2 * 64 + lane;
+
+    for (int g0 = 0; g0 < nmt; g0 += GRP) {
+        // which k-steps each m-tile of the group needs
+        unsigned long long mask[GRP], uni = 0;
+#pragma unroll
+        for (int g = 0; g < GRP; ++g) {
+            const int mt = g0 + g;
+            bool on = mt < nmt && lane < nks;
+            if (a.dminb != nullptr && on) {
+                const float dm = a.dminb[((size_t)task * nmt_all + mt) * nks + lane];
+                on = fmaf(c2, dm, a.tlb[mt * nks + lane]) > a.thr;
+            }
+            mask[g] = __ballot(on);
+            uni |= mask[g];
+        }
+        f4 acc[GRP][NCT];
+#pragma unroll
+        for (int g = 0; g < GRP; ++g)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[g][ct] = f4{0.f, 0.f, 0.f, 0.f};
+
+        while (uni != 0) {
+            const int ks = __builtin_ctzll(uni);
+            uni &= uni - 1;
+            h8 bh[NCT], bl[NCT];
+            const h8* Ek = El + (size_t)ks * NCT * 2 * 64;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                bh[ct] = Ek[(ct * 2) * 64];
+                bl[ct] = Ek[(ct * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int g = 0; g < GRP; ++g) {
+                if (!((mask[g] >> ks) & 1)) continue;
+                const int v = MTL * (g0 + g) + lr;
+                const int vc = v < H1 ? v : H1 - 1;          // padding lines: tl2 = -inf there
+                const float* dp = Dtask + (size_t)vc * N + KBL * ks;
+                const float* tp = Tl + (size_t)v * N + KBL * ks;
+                const f4 t0 = *reinterpret_cast<const f4*>(tp), t1 = *reinterpret_cast<const f4*>(tp + 4);
+                float x[8];
+                if constexpr (ONE_DIR) {
+                    const f4 d0 = *reinterpret_cast<const f4*>(dp), d1 = *reinterpret_cast<const f4*>(dp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = __builtin_amdgcn_exp2f(fmaf(c2, d0[e], t0[e]));
+                        x[4 + e] = __builtin_amdgcn_exp2f(fmaf(c2, d1[e], t1[e]));
+                    }
+                } else {
+                    float s[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+                    for (int d = 0; d < a.ndir; ++d) {
+                        const f4 d0 = *reinterpret_cast<const f4*>(dp + d * dstride);
+                        const f4 d1 = *reinterpret_cast<const f4*>(dp + d * dstride + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            s[e] += __builtin_amdgcn_exp2f(c2 * d0[e]);
+                            s[4 + e] += __builtin_amdgcn_exp2f(c2 * d1[e]);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = s[e] * __builtin_amdgcn_exp2f(t0[e]);
+                        x[4 + e] = s[4 + e] * __builtin_amdgcn_exp2f(t1[e]);
+                    }
+                }
+                h8 ah, al;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 h, w;
+                    split16(x[e], &h, &w);
+                    ah[e] = h;
+                    al[e] = w;
+                }
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ct], acc[g][ct], 0, 0, 0);
+                    acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ct], acc[g][ct], 0, 0, 0);
+                    acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ct], acc[g][ct], 0, 0, 0);
+                }
+            }
+        }
+        // second pass: the accumulator tile (rows = lines on registers / lane groups, column on
+        // the lane) is the A operand of a 16x16x16 product that sums over its rows
+#pragma unroll
+        for (int g = 0; g < GRP; ++g) {
+            if (mask[g] == 0) continue;
+            const h4* Gm = Gl + (size_t)(g0 + g) * NJT * 2 * 2 * 64;
+            h4 th[NCT], tw[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    _Float16 h, w;
+                    split16(acc[g][ct][r] * a.tq_scale, &h, &w);
+                    th[ct][r] = h;
+                    tw[ct][r] = w;
+                }
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                const h4 gxh = Gm[((jt * 2 + 0) * 2 + 0) * 64], gxl = Gm[((jt * 2 + 0) * 2 + 1) * 64];
+                const h4 gyh = Gm[((jt * 2 + 1) * 2 + 0) * 64], gyl = Gm[((jt * 2 + 1) * 2 + 1) * 64];
+                P0[jt] = mm16(P0[jt], th[0], tw[0], gxh, gxl);
+                Q0[jt] = mm16(Q0[jt], th[1], tw[1], gyh, gyl);
+                R2x[jt] = mm16(R2x[jt], th[2], tw[2], gxh, gxl);
+                R2y[jt] = mm16(R2y[jt], th[2], tw[2], gyh, gyl);
+            }
+        }
+    }
+
+    write_stamp(P0, Q0, R2x, R2y, lr, lk, a.pre + ((size_t)task * a.nl + l) * NS * NS);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// K_OTF_MFMA1: the single-direction kernel.
+//
+// What bounds the stage is not the matrix pipe but the vector-memory path of a CU (about 30 B/clk
+// from the L2 in gather-shaped loads): a tile step consumes 4 KB of D and log2 tel and shares a
+// 6 KB slab of E with the other tile steps of its k-step.  The kernel is therefore blocked like a
+// matrix product over (m-tiles of one task) x (wavelengths):
+//   * a workgroup is ONE task and a group of up to eight wavelengths, one wavelength per wave;
+//   * the D | log2 tel tiles of a k-step (eight m-tiles, 32 KB) are staged in LDS ONCE per
+//     workgroup by LDS-DMA (global_load_lds_dwordx4, wave w fetches tile w) and read by every
+//     wave, each applying its own wavelength: 4 KB from the L2 feed up to eight tile steps;
+//   * a wave keeps the accumulators of eight m-tiles (96 registers), so its E slab of the k-step
+//     (private: it depends on the wavelength) feeds up to eight tile steps too;
+//   * per k-step that is 32 + 48 KB of loads for 64 tile steps instead of 64 x 7 KB.
+// The staging buffer is double buffered: the loads of the next k-step are in flight behind the
+// tile steps of this one, and one s_barrier per k-step hands the buffers over (raw s_barrier with
+// explicit waits: hipcc does not count asm memory operations).  The wavelengths of a group prune
+// differently -- the bound grows with the wavelength -- so the workgroup stages what its longest
+// wavelength needs and every wave skips the tile steps its own mask drops.
+// A wave owns its stamp from the OTF to the normalised 40 x 40 pixels: no inter-wave reduction,
+// results bit-identical for any chunking or lane count.
+// ------------------------------------------------------------------------------------------
+#ifndef MPSFR_MF_KNOCK
+#define MPSFR_MF_KNOCK 0         // kernel experiments: 1 = no loads, 2 = loads only
+#endif
+constexpr int kMfTiles = 8;                         // m-tiles per sweep over the k-steps
+constexpr int kMfStage = kMfTiles * 4096;           // one staging buffer: 8 x (D 2 KB | log2 tel 2 KB)
+constexpr int kMfLds = 2 * kMfStage + 8 * 6 * 1024; // two staging buffers + one E slab per wave
+
+// one LDS-DMA load: 16 bytes per lane from sbase + voff to lds_dst + 16 lane
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+// the four loads of a tile: D (two halves of the lane's 8 columns), log2 tel (likewise)
+__device__ __forceinline__ void glds_tile(const void* dbase, const void* tbase, unsigned voff,
+                                          unsigned voff16, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "v"(voff16), "s"(dbase), "s"(tbase), "s"(lds_dst)
+        : "memory", "scc");
+}
+// x = 2^(c d + t) for two elements, split into fp16 halves: hi = rne(x), lo = rne(x - hi)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void otf_pair(f2 cc, f2 d, f2 t, unsigned* hi, unsigned* lo) {
+    f2 y;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(cc), "v"(d), "v"(t));
+    const float x0 = __builtin_amdgcn_exp2f(y[0]), x1 = __builtin_amdgcn_exp2f(y[1]);
+    unsigned h;
+    float l0, l1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h), "v"(x1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(*lo) : "v"(l0), "v"(l1));
+    *hi = h;
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_otf_mfma1(const MfArgs a, int per, int ngr) {
+    constexpr int GRP = kMfTiles;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = a.N, H1 = N / 2 + 1, nks = mf_nks(N), nmt_all = mf_nmt(N);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    // workgroup -> (task, wavelength group): consecutive blockIdx go round the 8 XCDs, so the
+    // logical index runs through one XCD's share before the next one's: the groups of a task
+    // follow each other on one XCD and read its D from that L2
+    const int per_xcd = ((int)gridDim.x + 7) / 8;
+    const int q = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (q >= a.ntask * ngr) return;                      // whole workgroup
+    const int task = q / ngr, grp = q % ngr;
+    unsigned long long* clk = a.clk != nullptr && lane == 0 ? a.clk + ((size_t)blockIdx.x * 8 + wave) * 8 : nullptr;
+#define MF_STAMP(i_) if (clk != nullptr) clk[i_] = __builtin_readcyclecounter()
+    MF_STAMP(0);
+    const int lmax = min(a.nl - 1, grp * per + per - 1);  // the group's longest wavelength
+    const bool lv = wave < per && grp * per + wave < a.nl;
+    const int l = lv ? grp * per + wave : lmax;
+    const float kLog2e = 1.44269504088896340736f;
+    const float c2 = (float)a.lp[l].c * kLog2e, c2u = (float)a.lp[lmax].c * kLog2e;
+    const f2 cc = {c2, c2};
+    const int npair = (a.nl + 1) / 2;
+    const int nv = a.vkeep != nullptr ? a.vkeep[(size_t)task * npair + (l >> 1)] : H1;
+    const int nvu = a.vkeep != nullptr ? a.vkeep[(size_t)task * npair + (lmax >> 1)] : H1;
+    const int nmt = lv ? (nv + MTL - 1) / MTL : 0, nmtu = (nvu + MTL - 1) / MTL;
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned char* slab = smem + 2 * kMfStage + wave * 6 * 1024;
+    const unsigned slab_lds = lds0 + 2 * kMfStage + (unsigned)wave * 6 * 1024;
+
+    f4 P0[NJT], Q0[NJT], R2x[NJT], R2y[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        P0[jt] = f4{0.f, 0.f, 0.f, 0.f};
+        Q0[jt] = f4{0.f, 0.f, 0.f, 0.f};
+        R2x[jt] = f4{0.f, 0.f, 0.f, 0.f};
+        R2y[jt] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    // lane part of a tile's addresses (bytes); the rest is wave-uniform.  Lines beyond N/2 of
+    // the last m-tile read the zeroed padding behind D (log2 tel = -inf there).
+    const unsigned voff = (unsigned)(((size_t)lr * N + 8 * lk) * sizeof(float)), voff16 = voff + 16;
+    const unsigned voffb = (unsigned)lane * 16;
+    const char* dtask = reinterpret_cast<const char*>(a.D0t + (size_t)task * H1 * N);
+    const char* ttab = reinterpret_cast<const char*>(a.tl2);
+    const char* etab = reinterpret_cast<const char*>(a.E + (size_t)l * nks * NCT * 2 * 64);
+    const h4* Gl = a.G + (size_t)l * nmt_all * NJT * 2 * 2 * 64 + lane;
+
+    unsigned long long t_kloop = 0, t_pass2 = 0;
+    unsigned mytiles = 0;                  // the tiles of a sweep this wave fetches
+    for (int g = wave; g < GRP; g += per) mytiles |= 1u << g;
+    for (int g0 = 0; g0 < nmtu; g0 += GRP) {
+        // which k-steps each m-tile needs: for this wave's wavelength and for the group's longest
+        unsigned long long own[GRP], uni[GRP], kown = 0, kuni = 0;
+        float dm[GRP], tb[GRP];
+        if (a.dminb != nullptr) {          // all loads in flight before the first ballot waits
+#pragma unroll
+            for (int g = 0; g < GRP; ++g) {
+                const int mt = min(g0 + g, nmt_all - 1), kk = min(lane, nks - 1);
+                dm[g] = a.dminb[((size_t)task * nmt_all + mt) * nks + kk];
+                tb[g] = a.tlb[mt * nks + kk];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GRP; ++g) {
+            const int mt = g0 + g;
+            bool ou = mt < nmtu && lane < nks, oo = mt < nmt && lane < nks;
+            if (a.dminb != nullptr) {
+                ou = ou && fmaf(c2u, dm[g], tb[g]) > a.thr;
+                oo = oo && fmaf(c2, dm[g], tb[g]) > a.thr;
+            }
+            uni[g] = __ballot(ou);
+            own[g] = __ballot(oo) & uni[g];
+            kuni |= uni[g];
+            kown |= own[g];
+        }
+        f4 acc[GRP][NCT];
+#pragma unroll
+        for (int g = 0; g < GRP; ++g)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[g][ct] = f4{0.f, 0.f, 0.f, 0.f};
+
+        // stage the tiles of k-step ks (wave w fetches tiles w, w + per, ...) and this wave's E slab
+        auto stage = [&](int ks, int buf) {
+            if (MPSFR_MF_KNOCK == 1) return;
+#pragma unroll
+            for (int g = 0; g < GRP; ++g) {
+                if (!((mytiles >> g) & 1) || !((uni[g] >> ks) & 1)) continue;
+                const size_t off = ((size_t)(MTL * (g0 + g)) * N + (size_t)KBL * ks) * sizeof(float);
+                glds_tile(dtask + off, ttab + off, voff, voff16, lds0 + buf * kMfStage + g * 4096);
+            }
+            if ((kown >> ks) & 1) {
+                const char* Ek = etab + (size_t)ks * NCT * 2 * 1024;
+#pragma unroll
+                for (int i = 0; i < 2 * NCT; ++i) glds16s(Ek + i * 1024, voffb, slab_lds + i * 1024);
+            }
+        };
+        unsigned long long rest = kuni;
+        int buf = 0;
+        const unsigned long long tk0 = clk != nullptr ? __builtin_readcyclecounter() : 0;
+        if (g0 == 0) MF_STAMP(1);
+        if (rest != 0) stage(__builtin_ctzll(rest), 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (g0 == 0) MF_STAMP(2);
+        while (rest != 0) {
+            const int ks = __builtin_ctzll(rest);
+            rest &= rest - 1;
+            const bool mine = (kown >> ks) & 1;
+            h8 bh[NCT], bl[NCT];
+            if (mine) {
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    bh[ct] = *reinterpret_cast<const h8*>(slab + (ct * 2) * 1024 + lane * 16);
+                    bl[ct] = *reinterpret_cast<const h8*>(slab + (ct * 2 + 1) * 1024 + lane * 16);
+                }
+                // the slab is in registers before the next one may land on it
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (rest != 0) stage(__builtin_ctzll(rest), buf ^ 1);
+            if (mine) {
+                // The tile steps of the k-step, software pipelined inside the wave: the operands of
+                // the NEXT tile the wave needs are read from LDS and turned into the fp16 halves of
+                // its OTF tile in the same basic block as the nine products of the current tile, so
+                // the scheduler puts the vector work into the shadow of the MFMAs.  The m-tile of
+                // the products is a compile-time index (the accumulators stay where they are); the
+                // tile that is prepared is a run-time one.  The last tile prepares itself again.
+                const unsigned char* tbuf = smem + buf * kMfStage + lane * 16;
+                unsigned gbits = 0;
+#pragma unroll
+                for (int g = 0; g < GRP; ++g) gbits |= (unsigned)((own[g] >> ks) & 1) << g;
+                h8 ah, al;
+                auto prepare = [&](int g) {
+                    const unsigned char* tp = tbuf + g * 4096;
+                    const f4 d0 = *reinterpret_cast<const f4*>(tp);
+                    const f4 d1 = *reinterpret_cast<const f4*>(tp + 1024);
+                    const f4 t0 = *reinterpret_cast<const f4*>(tp + 2048);
+                    const f4 t1 = *reinterpret_cast<const f4*>(tp + 3072);
+                    unsigned hi[4], lo[4];
+                    otf_pair(cc, f2{d0[0], d0[1]}, f2{t0[0], t0[1]}, &hi[0], &lo[0]);
+                    otf_pair(cc, f2{d0[2], d0[3]}, f2{t0[2], t0[3]}, &hi[1], &lo[1]);
+                    otf_pair(cc, f2{d1[0], d1[1]}, f2{t1[0], t1[1]}, &hi[2], &lo[2]);
+                    otf_pair(cc, f2{d1[2], d1[3]}, f2{t1[2], t1[3]}, &hi[3], &lo[3]);
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    ah = __builtin_bit_cast(h8, u4{hi[0], hi[1], hi[2], hi[3]});
+                    al = __builtin_bit_cast(h8, u4{lo[0], lo[1], lo[2], lo[3]});
+                };
+                prepare(__builtin_ctz(gbits));
+#pragma unroll
+                for (int g = 0; g < GRP; ++g) {
+                    if (!((gbits >> g) & 1)) continue;
+                    const h8 ch = ah, cl = al;
+                    const unsigned later = gbits & ~((2u << g) - 1u);
+                    prepare(later != 0 ? __builtin_ctz(later) : g);
+                    if (MPSFR_MF_KNOCK == 2) {          // experiment: loads only
+                        acc[g][0][0] += (float)ch[0] + (float)cl[0];
+                        continue;
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+                        acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, bh[ct], acc[g][ct], 0, 0, 0);
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+                        acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, bl[ct], acc[g][ct], 0, 0, 0);
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+                        acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, bh[ct], acc[g][ct], 0, 0, 0);
+                }
+            }
+            // the next k-step's tiles have landed, and nobody reads this k-step's any more
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            buf ^= 1;
+        }
+        const unsigned long long tk1 = clk != nullptr ? __builtin_readcyclecounter() : 0;
+        if (g0 == 0) MF_STAMP(3);
+        // second pass: the accumulator tile (rows = lines on registers / lane groups, column on
+        // the lane) is the A operand of a 16x16x16 product that sums over its rows
+        // (the G fragments of the next tile the wave needs are in flight behind the products of
+        // the current one: tile index at run time, accumulator index at compile time, as above)
+        unsigned tbits = 0;
+#pragma unroll
+        for (int g = 0; g < GRP; ++g) tbits |= (unsigned)(own[g] != 0) << g;
+        h4 gq[NJT][2][2];
+        auto fetch_g = [&](int g) {
+            const h4* Gm = Gl + (size_t)(g0 + g) * NJT * 2 * 2 * 64;
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+                    for (int hl = 0; hl < 2; ++hl) gq[jt][xy][hl] = Gm[((jt * 2 + xy) * 2 + hl) * 64];
+        };
+        if (tbits != 0) fetch_g(__builtin_ctz(tbits));
+#pragma unroll
+        for (int g2 = 0; g2 < GRP; ++g2) {
+            if (!((tbits >> g2) & 1)) continue;
+            h4 gc[NJT][2][2];
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+                    for (int hl = 0; hl < 2; ++hl) gc[jt][xy][hl] = gq[jt][xy][hl];
+            const unsigned later = tbits & ~((2u << g2) - 1u);
+            fetch_g(later != 0 ? __builtin_ctz(later) : g2);
+            h4 th[NCT], tw[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    _Float16 h, w;
+                    split16(acc[g2][ct][r] * a.tq_scale, &h, &w);
+                    th[ct][r] = h;
+                    tw[ct][r] = w;
+                }
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                P0[jt] = mm16(P0[jt], th[0], tw[0], gc[jt][0][0], gc[jt][0][1]);
+                Q0[jt] = mm16(Q0[jt], th[1], tw[1], gc[jt][1][0], gc[jt][1][1]);
+                R2x[jt] = mm16(R2x[jt], th[2], tw[2], gc[jt][0][0], gc[jt][0][1]);
+                R2y[jt] = mm16(R2y[jt], th[2], tw[2], gc[jt][1][0], gc[jt][1][1]);
+            }
+        }
+        if (clk != nullptr) {
+            t_kloop += tk1 - tk0;
+            t_pass2 += __builtin_readcyclecounter() - tk1;
+        }
+    }
+    MF_STAMP(4);
+    if (clk != nullptr) { clk[6] = t_kloop; clk[7] = t_pass2; }
+    if (lv) write_stamp(P0, Q0, R2x, R2y, lr, lk, a.pre + ((size_t)task * a.nl + l) * NS * NS);
+    MF_STAMP(5);
+#undef MF_STAMP
+}
+
+}  // namespace
+
+size_t mf_etab_bytes(int N, int nl) { return (size_t)nl * mf_nks(N) * NCT * 2 * 64 * sizeof(h8); }
+size_t mf_gtab_bytes(int N, int nl) { return (size_t)nl * mf_nmt(N) * NJT * 2 * 2 * 64 * sizeof(h4); }
+size_t mf_tl2_bytes(int N) { return (size_t)mf_nmt(N) * MTL * N * sizeof(float); }
+size_t mf_tlb_bytes(int N) { return (size_t)mf_nmt(N) * mf_nks(N) * sizeof(float); }
+size_t mf_dminb_bytes(int N, int ntask) { return (size_t)ntask * mf_nmt(N) * mf_nks(N) * sizeof(float); }
+int mf_block_count(int N) { return mf_nmt(N) * mf_nks(N); }
+
+void launch_mf_tables(hipStream_t s, int N, int nl, const LamPar* d_lp, const void* d_tw64,
+                      void* d_E, void* d_G) {
+    const int nE = mf_nks(N) * NCT * 64, nG = mf_nmt(N) * NJT * 2 * 64;
+    const int n = nE > nG ? nE : nG;
+    hipLaunchKernelGGL(k_mf_tables, dim3((n + 255) / 256, nl), dim3(256), 0, s, N, nl, d_lp,
+                       (const cx<double>*)d_tw64, (h8*)d_E, (h4*)d_G);
+}
+
+void launch_mf_tel(hipStream_t s, int N, const void* d_tel, float* d_tl2, float* d_tlb) {
+    hipLaunchKernelGGL(k_mf_tel, dim3(mf_nmt(N)), dim3(256), 0, s, N, (const float*)d_tel, d_tl2, d_tlb);
+}
+
+void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
+                     const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,
+                     const int* d_vkeep, const float* d_dminb, const float* d_tlb, float thr,
+                     void* d_pre, void* d_clk) {
+    MfArgs a;
+    a.N = N; a.ntask = ntask; a.ndir = ndir; a.nl = nl;
+    a.D0t = (const float*)d_D0t; a.tl2 = d_tl2; a.lp = d_lp;
+    a.E = (const h8*)d_E; a.G = (const h4*)d_G;
+    a.vkeep = d_vkeep; a.dminb = d_dminb; a.tlb = d_tlb; a.thr = thr;
+    int lg = 0;
+    while ((1 << lg) < N) ++lg;
+    a.tq_scale = 1.0f / (float)(1 << lg);
+    a.pre = (float*)d_pre;
+    a.clk = (unsigned long long*)d_clk;
+#ifndef MPSFR_MF_DMA
+#define MPSFR_MF_DMA 1
+#endif
+    if (ndir == 1 && MPSFR_MF_DMA) {
+        // wavelength groups of at most eight, as even as possible: one wave per wavelength
+        const int ngr = (nl + 7) / 8, per = (nl + ngr - 1) / ngr;
+        allow_smem(k_otf_mfma1, (size_t)kMfLds);
+        hipLaunchKernelGGL(k_otf_mfma1, dim3((ntask * ngr + 7) / 8 * 8), dim3(64 * per), kMfLds, s, a, per, ngr);
+        return;
+    }
+    const int nwg = ((ntask + 3) / 4) * nl;
+    const int grid = (nwg + 7) / 8 * 8;
+    if (ndir == 1) hipLaunchKernelGGL(k_otf_mfma<true>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_otf_mfma<false>, dim3(grid), dim3(256), 0, s, a);
+}
+
+}  // namespace mpsfr

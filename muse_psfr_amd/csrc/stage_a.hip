@@ -229,7 +229,23 @@ __global__ void __launch_bounds__(256) k_dc_sum(const cx<double>* __restrict__ C
 // K_COLFFT_DPHI: column FFTs of C and the structure function (psfrec.py:717-722 without the
 // wavelength factor): D0t[td][y][x] = 2 scale (S00 - Re S[x][y]), y in [0, N/2], x in [0, N).
 // ------------------------------------------------------------------------------------------
-// dmin[td][y] (optional): the minimum of the line, >= 0, as float -- input of K_VKEEP.
+// dmin[td][y][N/32] (optional): the minima of the line's blocks of 32 columns, >= 0, as float --
+// input of K_VKEEP (line pruning and block pruning of the per-wavelength stage).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_self(float v) {     // lanes outside ROW_MASK keep their own value
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, CTRL, ROW_MASK, 0xf, false));
+}
+// minimum over the aligned group of 32 lanes (16 if HALF): valid in the group's last lane
+template <bool HALF>
+__device__ __forceinline__ float group_min(float v) {
+    v = fminf(v, dpp_self<0xB1, 0xf>(v));      // quad_perm [1,0,3,2]
+    v = fminf(v, dpp_self<0x4E, 0xf>(v));      // quad_perm [2,3,0,1]
+    v = fminf(v, dpp_self<0x141, 0xf>(v));     // row_half_mirror
+    v = fminf(v, dpp_self<0x140, 0xf>(v));     // row_mirror: every lane holds its row's minimum
+    if constexpr (!HALF) v = fminf(v, dpp_self<0x142, 0xa>(v));   // row_bcast15 into rows 1 and 3
+    return v;
+}
 template <int N, typename RO>
 __global__ void __launch_bounds__(LineCfg<N>::THREADS)
 k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, double scale2,
@@ -242,7 +258,8 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
     cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
     cx<double>* bufA = tw + NPAD;
     cx<double>* bufB = bufA + SLOTS * NPAD;
-    __shared__ int smin[SLOTS];          // line minimum, as the bits of a non-negative float
+    constexpr int NKS = N / 32;          // blocks of 32 columns per line
+    __shared__ float sminb[SLOTS][NKS];
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
     const int td = blockIdx.y;
     const cx<double>* Ct = C + (size_t)td * (N / 2 + 1) * NR;
@@ -275,7 +292,6 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
                 if (su >= NAO / 2) dst[lds_pad(N - 1 - su)] = pre[k];
             }
         }
-        if (threadIdx.x < SLOTS) smin[threadIdx.x] = 0x7f800000;
         __syncthreads();
         if (yg + (int)gridDim.x < NYG) fetch(yg + gridDim.x);
         const cx<double>* res =
@@ -283,21 +299,39 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
         const int y = yg * SLOTS + slot;
         if (y <= N / 2) {
             RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N;
-            float lo = __builtin_inff();
-            for (int x = t; x < N; x += TPR) {
-                const RO d = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
-                out[x] = d;
-                lo = fminf(lo, fmaxf((float)d, 0.f));
-            }
-            if (dmin != nullptr) {      // line minimum: shuffles within the line's lanes, then one atomic
+            if (dmin == nullptr) {
+                for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
+            } else if constexpr (TPR >= 32) {
+                // a block of 32 columns = one aligned group of 32 lanes of one sweep
 #pragma unroll
-                for (int o = (TPR < 64 ? TPR : 64) / 2; o > 0; o >>= 1) lo = fminf(lo, __shfl_xor(lo, o, 64));
-                if ((t & 63) == 0) atomicMin(&smin[slot], __float_as_int(lo));
+                for (int k = 0; k < N / TPR; ++k) {
+                    const int x = t + k * TPR;
+                    const RO d = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
+                    out[x] = d;
+                    const float lo = group_min<false>(fmaxf((float)d, 0.f));
+                    if ((t & 31) == 31) sminb[slot][x >> 5] = lo;
+                }
+            } else {
+                // 16 lanes per line: a block is two sweeps of the line's lanes
+                static_assert(TPR == 16 || TPR >= 32, "lanes per line");
+#pragma unroll
+                for (int k = 0; k < N / TPR; k += 2) {
+                    const int x = t + k * TPR;
+                    const RO d0 = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
+                    const RO d1 = (RO)(scale2 * (dc - res[lds_out<N, 16>(x + TPR)].x));
+                    out[x] = d0;
+                    out[x + TPR] = d1;
+                    const float lo = group_min<true>(fmaxf(fminf((float)d0, (float)d1), 0.f));
+                    if ((t & 15) == 15) sminb[slot][x >> 5] = lo;
+                }
             }
         }
         __syncthreads();            // all reads of the result are done: the buffers may be restaged
-        if (dmin != nullptr && threadIdx.x < SLOTS && yg * SLOTS + (int)threadIdx.x <= N / 2)
-            dmin[(size_t)td * (N / 2 + 1) + yg * SLOTS + threadIdx.x] = __int_as_float(smin[threadIdx.x]);
+        if (dmin != nullptr && threadIdx.x < SLOTS * NKS) {
+            const int sl = threadIdx.x / NKS, kb = threadIdx.x % NKS;
+            if (yg * SLOTS + sl <= N / 2)
+                dmin[((size_t)td * (N / 2 + 1) + yg * SLOTS + sl) * NKS + kb] = sminb[sl][kb];
+        }
     }
 }
 
@@ -327,18 +361,37 @@ __global__ void __launch_bounds__(256) k_tel_linemax(int N, const float* __restr
         tlmax[v] = __builtin_amdgcn_logf(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
 }
 
-__global__ void __launch_bounds__(256) k_vkeep(int H1, int ndir, int nl, const LamPar* __restrict__ lp,
+// dmin: [ntask ndir][H1][nks] block minima of the lines (K_COLFFT_DPHI).  dminb (optional):
+// [ntask][nmt][nks] minima over directions and the 16 lines of an m-tile (block pruning of
+// K_OTF_MFMA, otf_mfma.hip).
+__global__ void __launch_bounds__(256) k_vkeep(int H1, int nks, int ndir, int nl,
+                                               const LamPar* __restrict__ lp,
                                                const float* __restrict__ dmin,
                                                const float* __restrict__ tlmax, float thr_sum,
-                                               int* __restrict__ vkeep, int fixed) {
+                                               int* __restrict__ vkeep, int fixed,
+                                               float* __restrict__ dminb) {
     constexpr int MAXH = 1280 / 2 + 1;
     __shared__ float sa[MAXH], sb[MAXH];
     const int task = blockIdx.x, npair = (nl + 1) / 2;
     for (int v = threadIdx.x; v < H1; v += 256) {
         float a = __builtin_inff();
-        for (int d = 0; d < ndir; ++d) a = fminf(a, dmin[((size_t)task * ndir + d) * H1 + v]);
+        for (int d = 0; d < ndir; ++d) {
+            const float* row = dmin + (((size_t)task * ndir + d) * H1 + v) * nks;
+            for (int k = 0; k < nks; ++k) a = fminf(a, row[k]);
+        }
         sa[v] = a;
         sb[v] = tlmax[v];
+    }
+    if (dminb != nullptr) {
+        const int nmt = (H1 + 15) / 16;
+        for (int e = threadIdx.x; e < nmt * nks; e += 256) {
+            const int mt = e / nks, k = e - mt * nks;
+            float a = __builtin_inff();
+            for (int d = 0; d < ndir; ++d)
+                for (int v = 16 * mt; v < min(H1, 16 * mt + 16); ++v)
+                    a = fminf(a, dmin[(((size_t)task * ndir + d) * H1 + v) * nks + k]);
+            dminb[((size_t)task * nmt + mt) * nks + k] = a;
+        }
     }
     __syncthreads();
     // Per wavelength pair: walk the lines from the top and stop where the summed bounds of
@@ -424,9 +477,10 @@ void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax)
 }
 
 void launch_vkeep(hipStream_t s, int N, int ntask, int ndir, int nl, const LamPar* d_lp,
-                  const float* d_dmin, const float* d_tlmax, float thr_sum, int* d_vkeep, int fixed) {
-    hipLaunchKernelGGL(k_vkeep, dim3(ntask), dim3(256), 0, s, N / 2 + 1, ndir, nl, d_lp, d_dmin, d_tlmax,
-                       thr_sum, d_vkeep, fixed);
+                  const float* d_dmin, const float* d_tlmax, float thr_sum, int* d_vkeep, int fixed,
+                  float* d_dminb) {
+    hipLaunchKernelGGL(k_vkeep, dim3(ntask), dim3(256), 0, s, N / 2 + 1, N / 32, ndir, nl, d_lp, d_dmin,
+                       d_tlmax, thr_sum, d_vkeep, fixed, d_dminb);
 }
 
 void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,

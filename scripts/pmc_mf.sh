@@ -1,0 +1,23 @@
+#!/bin/bash
+# usage: scripts/pmc_mf.sh <tag> [bench args]: SQ counter passes + trace for the matrix-core kernel, one lane
+export TMPDIR=/tmp
+R=$PWD
+OUT=$R/gpurun_out/pmcmf_$1; shift
+mkdir -p $OUT/trace
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 2 --cpu-rows 0 --f64-steps 0 --profile-steps 0 --unpruned-steps 0 --streams 1 "$@" > $OUT/trace.log 2>&1 || exit 1
+i=0
+while read -r P; do
+  i=$((i+1)); D=$OUT/pmc$i; mkdir -p $D
+  timeout -k 10 300 rocprofv3 --pmc $P --output-format csv -d $D -- python3 bench.py --steps 3 --warmup 1 --cpu-rows 0 --f64-steps 0 --profile-steps 0 --unpruned-steps 0 --streams 1 "$@" > $D/log.txt 2>&1 || exit 1
+done <<'LIST'
+SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA
+SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES
+SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F16
+GRBM_GUI_ACTIVE
+FETCH_SIZE
+TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum
+LIST
+python3 scripts/pmc_summary.py $OUT > $OUT/pmc_summary.txt
+cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+grep -A 40 "^k_otf" $OUT/pmc_summary.txt
+grep "k_otf" $OUT/kernel_stats.csv | cut -c1-200
