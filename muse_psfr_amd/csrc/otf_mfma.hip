@@ -40,6 +40,10 @@ constexpr int NJT = 2;       // column tiles of the second pass: 32 >= 21
 // 1.2e-4 keep 22 bits, smaller ones an absolute 3e-11.  The stamp is normalised to sum 1 at the end
 // (psfrec.py:685), so the factor drops out.
 constexpr float kShift = 11.0f;
+// The E and G tables (|E| <= 1, |G| <= 2) are stored times 2^kTabShift for the same reason: the low
+// half of an entry (<= 2^-12 of it) would otherwise sit in the fp16 subnormal range, which the
+// matrix cores flush.
+constexpr int kTabShift = 9;
 
 __host__ __device__ constexpr int mf_nks(int N) { return N / KBL; }
 __host__ __device__ constexpr int mf_nmt(int N) { return (N / 2 + 1 + MTL - 1) / MTL; }
@@ -102,7 +106,8 @@ k_mf_tables(int N, int nl, const LamPar* __restrict__ lp, const cx<double>* __re
                 sample(i, &p, &a);
                 const cx<double> w0 = twg[(int)(((long)u * p) % N)];
                 const cx<double> w1 = twg[(int)(((long)u * (p + 1)) % N)];
-                val = (float)(imag ? (1.0 - a) * w0.y + a * w1.y : (1.0 - a) * w0.x + a * w1.x);
+                val = (float)((imag ? (1.0 - a) * w0.y + a * w1.y : (1.0 - a) * w0.x + a * w1.x) *
+                              (double)(1 << kTabShift));
             }
             _Float16 h, q;
             split16(val, &h, &q);
@@ -129,7 +134,8 @@ k_mf_tables(int N, int nl, const LamPar* __restrict__ lp, const cx<double>* __re
                 const cx<double> w1 = twg[(int)(((long)v * (p + 1)) % N)];
                 const double wv = (v == 0 || v == N / 2) ? 1.0 : 2.0;
                 // conj(W^(v p)): the imaginary part changes sign
-                val = (float)(xy ? -wv * ((1.0 - a) * w0.y + a * w1.y) : wv * ((1.0 - a) * w0.x + a * w1.x));
+                val = (float)((xy ? -wv * ((1.0 - a) * w0.y + a * w1.y) : wv * ((1.0 - a) * w0.x + a * w1.x)) *
+                              (double)(1 << kTabShift));
             }
             _Float16 h, q;
             split16(val, &h, &q);
@@ -741,7 +747,7 @@ void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const vo
     a.vkeep = d_vkeep; a.dminb = d_dminb; a.tlb = d_tlb; a.thr = thr;
     int lg = 0;
     while ((1 << lg) < N) ++lg;
-    a.tq_scale = 1.0f / (float)(1 << lg);
+    a.tq_scale = 1.0f / ((float)(1 << lg) * (float)(1 << kTabShift));    // first-pass sums -> <= 2^kShift ndir
     a.pre = (float*)d_pre;
     a.clk = (unsigned long long*)d_clk;
 #ifndef MPSFR_MF_DMA
