@@ -54,6 +54,7 @@ enum KernelId {
     K_CONV,
     K_FIT,
     K_STAMP_SUM,
+    K_VKEEP,
     K_COUNT
 };
 
@@ -64,15 +65,18 @@ void launch_tel_otf(hipStream_t s, int N, const uint64_t* d_rows, int words, dou
 void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp,
                        const double* d_aotab, double cfit, void* d_C, const void* d_tw64);
 void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00);
-// d_dmin: [ntd][N/2+1][N/32] float minima of the 32-column blocks of D's lines (or nullptr), input
-// of launch_vkeep
 void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,
-                        double scale2, void* d_D0t, bool f64out, const void* d_tw64, float* d_dmin);
-// line pruning of the per-wavelength stage (stage_a.hip, "Line pruning")
+                        double scale2, void* d_D0t, bool f64out, const void* d_tw64);
+// Pruning of the per-wavelength stage (stage_a.hip, "Line pruning"): minima of D per line
+// ([ntd][N/2+1]) and per block of 16 lines x 32 columns ([ntd][nmt][N/32]), then the lines to keep
+// per (task, wavelength pair) and the block minima over the directions
+void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk);
 void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax);
 void launch_vkeep(hipStream_t s, int N, int ntask, int ndir, int nl, const LamPar* d_lp,
-                  const float* d_dmin, const float* d_tlmax, float thr_sum, int* d_vkeep,
-                  int fixed, float* d_dminb);
+                  const float* d_dline, const float* d_dblk, const float* d_tlmax, float thr_sum,
+                  int* d_vkeep, int fixed, float* d_dminb);
+// d_order: [ntask] the tasks by descending work (dispatch order of launch_otf_mfma)
+void launch_task_order(hipStream_t s, int ntask, int nl, const int* d_vkeep, int* d_order);
 // Per-wavelength stage of the mixed-precision path on the matrix cores (otf_mfma.hip): operand
 // tables per wavelength set, constant telescope tables, and the fused kernel D -> stamps.
 size_t mf_etab_bytes(int N, int nl);
@@ -84,11 +88,12 @@ int mf_block_count(int N);
 void launch_mf_tables(hipStream_t s, int N, int nl, const LamPar* d_lp, const void* d_tw64,
                       void* d_E, void* d_G);
 void launch_mf_tel(hipStream_t s, int N, const void* d_tel, float* d_tl2, float* d_tlb);
-// d_vkeep / d_dminb: nullptr = no line / block pruning; thr: log2 of the block threshold
+// d_vkeep / d_dminb: nullptr = no line / block pruning; thr: log2 of the block threshold;
+// d_order: dispatch order of the tasks (or nullptr)
 void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
                      const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,
                      const int* d_vkeep, const float* d_dminb, const float* d_tlb, float thr,
-                     void* d_pre, void* d_clk = nullptr);
+                     void* d_pre, const int* d_order = nullptr, void* d_clk = nullptr);
 void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void* d_tw64,
                    int* d_samp_p, void* d_samp_a, void* d_G, bool f64);
 void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,

@@ -41,7 +41,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* kKernelNames[K_COUNT] = {
     "ao_tables", "tel_otf", "psd_rowfft", "dc_sum", "colfft_dphi", "gtable",
-    "moffat_kernels", "otf_rowfft", "colpass", "conv", "fit", "stamp_sum"};
+    "moffat_kernels", "otf_rowfft", "colpass", "conv", "fit", "stamp_sum", "vkeep"};
 
 struct DevBuf {
     void* p = nullptr;
@@ -84,7 +84,7 @@ struct mpsfr_ctx {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;       // after the lane's last chunk of the most recent call
         bool busy = false;               // `done` has been recorded
-        DevBuf C, s00, D0t, Tq, pre, fin, dmin, vkeep, dminb;
+        DevBuf C, s00, D0t, Tq, pre, fin, dmin, dblk, vkeep, dminb, order;
         const void* outs[3] = {nullptr, nullptr, nullptr};   // device outputs of its latest call
     };
     static constexpr int MAX_LANES = 4;
@@ -387,7 +387,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         mpsfr_ctx::Lane& ln = c->lane[k];
         if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
         if (ln.done) (void)hipEventDestroy(ln.done);
-        DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.dmin, &ln.vkeep, &ln.dminb};
+        DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.dmin, &ln.dblk, &ln.vkeep, &ln.dminb, &ln.order};
         for (auto b : lb) release(*b);
     }
     for (int k = 0; k < mpsfr_ctx::NSTAGE; ++k) {
@@ -757,8 +757,10 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * (c->f64 ? 8 : 4)))) return rc;
         if ((rc = ensure(c, ln.fin, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
         if (prune) {
-            if ((rc = ensure(c, ln.dmin, (size_t)TC * ndir * H1 * (N / 32) * sizeof(float)))) return rc;
+            if ((rc = ensure(c, ln.dmin, (size_t)TC * ndir * H1 * sizeof(float)))) return rc;
+            if ((rc = ensure(c, ln.dblk, (size_t)ndir * mf_dminb_bytes(N, TC)))) return rc;
             if (mf && (rc = ensure(c, ln.dminb, mf_dminb_bytes(N, TC)))) return rc;
+            if (mf && (rc = ensure(c, ln.order, (size_t)TC * sizeof(int)))) return rc;
             if ((rc = ensure(c, ln.vkeep, (size_t)TC * ((nl + 1) / 2) * sizeof(int)))) return rc;
         }
     }
@@ -806,18 +808,23 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         {
             ProfScope ps(c, K_COLFFT_DPHI, ls);
             launch_colfft_dphi(ls, N, ntd, ln.C.p, (const double*)ln.s00.p, scale2, ln.D0t.p,
-                               c->f64, c->tw64.p, prune ? (float*)ln.dmin.p : nullptr);
-            if (prune)
-                launch_vkeep(ls, N, tc, ndir, nl, d_lp, (const float*)ln.dmin.p,
-                             (const float*)c->tlmax.p, thr_sum, (int*)ln.vkeep.p, c->prune_fixed,
-                             mf ? (float*)ln.dminb.p : nullptr);
+                               c->f64, c->tw64.p);
+        }
+        if (prune) {
+            ProfScope ps(c, K_VKEEP, ls);
+            launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p);
+            launch_vkeep(ls, N, tc, ndir, nl, d_lp, (const float*)ln.dmin.p, (const float*)ln.dblk.p,
+                         (const float*)c->tlmax.p, thr_sum, (int*)ln.vkeep.p, c->prune_fixed,
+                         mf ? (float*)ln.dminb.p : nullptr);
+            if (mf) launch_task_order(ls, tc, nl, (const int*)ln.vkeep.p, (int*)ln.order.p);
         }
         const int* d_vkeep = prune ? (const int*)ln.vkeep.p : nullptr;
         if (mf) {
             ProfScope ps(c, K_OTF_ROWFFT, ls);
             launch_otf_mfma(ls, N, tc, ndir, nl, ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
                             c->gtab.p, d_vkeep, prune ? (const float*)ln.dminb.p : nullptr,
-                            (const float*)c->tlb.p, thr_blk, ln.pre.p, c->mf_clock ? c->mfclk.p : nullptr);
+                            (const float*)c->tlb.p, thr_blk, ln.pre.p,
+                            prune ? (const int*)ln.order.p : nullptr, c->mf_clock ? c->mfclk.p : nullptr);
         } else {
             {
                 ProfScope ps(c, K_OTF_ROWFFT, ls);

@@ -261,6 +261,7 @@ struct MfArgs {
     float thr;               // log2 of the block threshold
     float tq_scale;          // 2^-ceil(log2 N): first-pass sums back into the fp16 range
     float* pre;              // [ntask][nl][40][40]
+    const int* order;        // [ntask] dispatch order of the tasks, or nullptr
     unsigned long long* clk; // experiments: per-wave phase time stamps (or nullptr)
 };
 
@@ -485,13 +486,14 @@ k_otf_mfma1(const MfArgs a, int per, int ngr) {
     const int N = a.N, H1 = N / 2 + 1, nks = mf_nks(N), nmt_all = mf_nmt(N);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int lr = lane & 15, lk = lane >> 4;
-    // workgroup -> (task, wavelength group): consecutive blockIdx go round the 8 XCDs, so the
-    // logical index runs through one XCD's share before the next one's: the groups of a task
-    // follow each other on one XCD and read its D from that L2
-    const int per_xcd = ((int)gridDim.x + 7) / 8;
-    const int q = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (q >= a.ntask * ngr) return;                      // whole workgroup
-    const int task = q / ngr, grp = q % ngr;
+    // workgroup -> (task, wavelength group).  Consecutive blockIdx go round the 8 XCDs (each with
+    // its own L2): XCD x takes the tasks of rank x, x + 8, ... in dispatch order (heaviest first),
+    // all wavelength groups of a task one after the other (they read its D from that L2), longest
+    // wavelengths first.
+    const int xcd = blockIdx.x & 7, ql = blockIdx.x >> 3;
+    const int rank = (ql / ngr) * 8 + xcd, grp = ngr - 1 - ql % ngr;
+    if (rank >= a.ntask) return;                         // whole workgroup
+    const int task = a.order != nullptr ? a.order[rank] : rank;
     unsigned long long* clk = a.clk != nullptr && lane == 0 ? a.clk + ((size_t)blockIdx.x * 8 + wave) * 8 : nullptr;
 #define MF_STAMP(i_) if (clk != nullptr) clk[i_] = __builtin_readcyclecounter()
     MF_STAMP(0);
@@ -739,7 +741,7 @@ void launch_mf_tel(hipStream_t s, int N, const void* d_tel, float* d_tl2, float*
 void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
                      const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,
                      const int* d_vkeep, const float* d_dminb, const float* d_tlb, float thr,
-                     void* d_pre, void* d_clk) {
+                     void* d_pre, const int* d_order, void* d_clk) {
     MfArgs a;
     a.N = N; a.ntask = ntask; a.ndir = ndir; a.nl = nl;
     a.D0t = (const float*)d_D0t; a.tl2 = d_tl2; a.lp = d_lp;
@@ -750,6 +752,7 @@ void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const vo
     a.tq_scale = 1.0f / ((float)(1 << lg) * (float)(1 << kTabShift));    // first-pass sums -> <= 2^kShift ndir
     a.pre = (float*)d_pre;
     a.clk = (unsigned long long*)d_clk;
+    a.order = d_order;
 #ifndef MPSFR_MF_DMA
 #define MPSFR_MF_DMA 1
 #endif
@@ -757,7 +760,7 @@ void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const vo
         // wavelength groups of at most eight, as even as possible: one wave per wavelength
         const int ngr = (nl + 7) / 8, per = (nl + ngr - 1) / ngr;
         allow_smem(k_otf_mfma1, (size_t)kMfLds);
-        hipLaunchKernelGGL(k_otf_mfma1, dim3((ntask * ngr + 7) / 8 * 8), dim3(64 * per), kMfLds, s, a, per, ngr);
+        hipLaunchKernelGGL(k_otf_mfma1, dim3(8 * ((ntask + 7) / 8) * ngr), dim3(64 * per), kMfLds, s, a, per, ngr);
         return;
     }
     const int nwg = ((ntask + 3) / 4) * nl;

@@ -229,27 +229,10 @@ __global__ void __launch_bounds__(256) k_dc_sum(const cx<double>* __restrict__ C
 // K_COLFFT_DPHI: column FFTs of C and the structure function (psfrec.py:717-722 without the
 // wavelength factor): D0t[td][y][x] = 2 scale (S00 - Re S[x][y]), y in [0, N/2], x in [0, N).
 // ------------------------------------------------------------------------------------------
-// dmin[td][y][N/32] (optional): the minima of the line's blocks of 32 columns, >= 0, as float --
-// input of K_VKEEP (line pruning and block pruning of the per-wavelength stage).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_self(float v) {     // lanes outside ROW_MASK keep their own value
-    const int b = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, CTRL, ROW_MASK, 0xf, false));
-}
-// minimum over the aligned group of 32 lanes (16 if HALF): valid in the group's last lane
-template <bool HALF>
-__device__ __forceinline__ float group_min(float v) {
-    v = fminf(v, dpp_self<0xB1, 0xf>(v));      // quad_perm [1,0,3,2]
-    v = fminf(v, dpp_self<0x4E, 0xf>(v));      // quad_perm [2,3,0,1]
-    v = fminf(v, dpp_self<0x141, 0xf>(v));     // row_half_mirror
-    v = fminf(v, dpp_self<0x140, 0xf>(v));     // row_mirror: every lane holds its row's minimum
-    if constexpr (!HALF) v = fminf(v, dpp_self<0x142, 0xa>(v));   // row_bcast15 into rows 1 and 3
-    return v;
-}
 template <int N, typename RO>
 __global__ void __launch_bounds__(LineCfg<N>::THREADS)
 k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, double scale2,
-              RO* __restrict__ D0t, const cx<double>* __restrict__ twg, float* __restrict__ dmin) {
+              RO* __restrict__ D0t, const cx<double>* __restrict__ twg) {
     using L = LineCfg<N>;
     constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
     constexpr int NR = psd_rows<N>(), NLD = (NR + TPR - 1) / TPR;
@@ -258,8 +241,6 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
     cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
     cx<double>* bufA = tw + NPAD;
     cx<double>* bufB = bufA + SLOTS * NPAD;
-    constexpr int NKS = N / 32;          // blocks of 32 columns per line
-    __shared__ float sminb[SLOTS][NKS];
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
     const int td = blockIdx.y;
     const cx<double>* Ct = C + (size_t)td * (N / 2 + 1) * NR;
@@ -299,40 +280,47 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
         const int y = yg * SLOTS + slot;
         if (y <= N / 2) {
             RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N;
-            if (dmin == nullptr) {
-                for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
-            } else if constexpr (TPR >= 32) {
-                // a block of 32 columns = one aligned group of 32 lanes of one sweep
-#pragma unroll
-                for (int k = 0; k < N / TPR; ++k) {
-                    const int x = t + k * TPR;
-                    const RO d = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
-                    out[x] = d;
-                    const float lo = group_min<false>(fmaxf((float)d, 0.f));
-                    if ((t & 31) == 31) sminb[slot][x >> 5] = lo;
-                }
-            } else {
-                // 16 lanes per line: a block is two sweeps of the line's lanes
-                static_assert(TPR == 16 || TPR >= 32, "lanes per line");
-#pragma unroll
-                for (int k = 0; k < N / TPR; k += 2) {
-                    const int x = t + k * TPR;
-                    const RO d0 = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
-                    const RO d1 = (RO)(scale2 * (dc - res[lds_out<N, 16>(x + TPR)].x));
-                    out[x] = d0;
-                    out[x + TPR] = d1;
-                    const float lo = group_min<true>(fmaxf(fminf((float)d0, (float)d1), 0.f));
-                    if ((t & 15) == 15) sminb[slot][x >> 5] = lo;
-                }
-            }
+            for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
         }
         __syncthreads();            // all reads of the result are done: the buffers may be restaged
-        if (dmin != nullptr && threadIdx.x < SLOTS * NKS) {
-            const int sl = threadIdx.x / NKS, kb = threadIdx.x % NKS;
-            if (yg * SLOTS + sl <= N / 2)
-                dmin[((size_t)td * (N / 2 + 1) + yg * SLOTS + sl) * NKS + kb] = sminb[sl][kb];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K_DMIN: minima of D for the pruning of the per-wavelength stage, one workgroup per (td, group of
+// 16 lines): dline[td][v] = min_u max(D[v][u], 0) and dblk[td][v / 16][u / 32] = the minimum over
+// the 16 x 32 block (the blocks of K_OTF_MFMA, otf_mfma.hip).  A separate pass over D (just
+// written, read back from the cache hierarchy at ~10 us per 52 MB) costs a third of what the same
+// minima cost inside K_COLFFT_DPHI, whose column transforms then wait for the reductions.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_dmin(int N, const float* __restrict__ D0t,
+                                              float* __restrict__ dline, float* __restrict__ dblk) {
+    constexpr int MAXKS = 1280 / 32;
+    __shared__ int sblk[MAXKS], sline[16];          // bits of non-negative floats: integer order
+    const int H1 = N / 2 + 1, nks = N / 32, nmt = (H1 + 15) / 16;
+    const int mt = blockIdx.x, td = blockIdx.y;
+    if (threadIdx.x < MAXKS) sblk[threadIdx.x] = 0x7f800000;
+    if (threadIdx.x < 16) sline[threadIdx.x] = 0x7f800000;
+    __syncthreads();
+    const int nq = N / 4;                            // float4 per line
+    const float4* src = reinterpret_cast<const float4*>(D0t + ((size_t)td * H1 + 16 * mt) * N);
+    const int nline = min(16, H1 - 16 * mt);
+    for (int f = threadIdx.x; f < nline * nq; f += 256) {
+        const float4 d = src[f];
+        float m = fmaxf(fminf(fminf(d.x, d.y), fminf(d.z, d.w)), 0.f);
+        // eight consecutive float4 are one block of 32 columns (nq is a multiple of 8)
+        m = fminf(m, __shfl_xor(m, 1, 64));
+        m = fminf(m, __shfl_xor(m, 2, 64));
+        m = fminf(m, __shfl_xor(m, 4, 64));
+        if ((threadIdx.x & 7) == 0) {
+            const int line = f / nq, kb = (f - line * nq) >> 3;
+            atomicMin(&sblk[kb], __float_as_int(m));
+            atomicMin(&sline[line], __float_as_int(m));
         }
     }
+    __syncthreads();
+    if ((int)threadIdx.x < nks) dblk[((size_t)td * nmt + mt) * nks + threadIdx.x] = __int_as_float(sblk[threadIdx.x]);
+    if ((int)threadIdx.x < nline) dline[(size_t)td * H1 + 16 * mt + threadIdx.x] = __int_as_float(sline[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -361,12 +349,12 @@ __global__ void __launch_bounds__(256) k_tel_linemax(int N, const float* __restr
         tlmax[v] = __builtin_amdgcn_logf(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
 }
 
-// dmin: [ntask ndir][H1][nks] block minima of the lines (K_COLFFT_DPHI).  dminb (optional):
-// [ntask][nmt][nks] minima over directions and the 16 lines of an m-tile (block pruning of
-// K_OTF_MFMA, otf_mfma.hip).
+// dline / dblk: the minima of K_DMIN per (task, direction).  dminb (optional): [ntask][nmt][nks]
+// block minima over the directions (block pruning of K_OTF_MFMA, otf_mfma.hip).
 __global__ void __launch_bounds__(256) k_vkeep(int H1, int nks, int ndir, int nl,
                                                const LamPar* __restrict__ lp,
-                                               const float* __restrict__ dmin,
+                                               const float* __restrict__ dline,
+                                               const float* __restrict__ dblk,
                                                const float* __restrict__ tlmax, float thr_sum,
                                                int* __restrict__ vkeep, int fixed,
                                                float* __restrict__ dminb) {
@@ -375,22 +363,16 @@ __global__ void __launch_bounds__(256) k_vkeep(int H1, int nks, int ndir, int nl
     const int task = blockIdx.x, npair = (nl + 1) / 2;
     for (int v = threadIdx.x; v < H1; v += 256) {
         float a = __builtin_inff();
-        for (int d = 0; d < ndir; ++d) {
-            const float* row = dmin + (((size_t)task * ndir + d) * H1 + v) * nks;
-            for (int k = 0; k < nks; ++k) a = fminf(a, row[k]);
-        }
+        for (int d = 0; d < ndir; ++d) a = fminf(a, dline[((size_t)task * ndir + d) * H1 + v]);
         sa[v] = a;
         sb[v] = tlmax[v];
     }
     if (dminb != nullptr) {
-        const int nmt = (H1 + 15) / 16;
-        for (int e = threadIdx.x; e < nmt * nks; e += 256) {
-            const int mt = e / nks, k = e - mt * nks;
+        const int nb = ((H1 + 15) / 16) * nks;
+        for (int e = threadIdx.x; e < nb; e += 256) {
             float a = __builtin_inff();
-            for (int d = 0; d < ndir; ++d)
-                for (int v = 16 * mt; v < min(H1, 16 * mt + 16); ++v)
-                    a = fminf(a, dmin[(((size_t)task * ndir + d) * H1 + v) * nks + k]);
-            dminb[((size_t)task * nmt + mt) * nks + k] = a;
+            for (int d = 0; d < ndir; ++d) a = fminf(a, dblk[((size_t)task * ndir + d) * nb + e]);
+            dminb[(size_t)task * nb + e] = a;
         }
     }
     __syncthreads();
@@ -432,6 +414,23 @@ __global__ void __launch_bounds__(256) k_vkeep(int H1, int nks, int ndir, int nl
     }
     (void)MAXP;
     // (monotone in the pair index: c2 rises with the wavelength, so every term of the sum does)
+}
+
+// K_TASK_ORDER: the tasks of a chunk by descending lines kept at the longest wavelength (ties by
+// index).  The per-wavelength kernel dispatches its workgroups in this order: the tasks with the
+// sharpest PSFs keep four times the tiles of the broadest, and a launch that meets them last ends
+// on them (longest-processing-time-first list scheduling).
+__global__ void __launch_bounds__(256) k_task_order(int ntask, int npair, const int* __restrict__ vkeep,
+                                                    int* __restrict__ order) {
+    for (int t = threadIdx.x; t < ntask; t += 256) {
+        const int key = vkeep[(size_t)t * npair + npair - 1];
+        int rank = 0;
+        for (int o = 0; o < ntask; ++o) {
+            const int ko = vkeep[(size_t)o * npair + npair - 1];
+            rank += (ko > key) || (ko == key && o < t);
+        }
+        order[rank] = t;
+    }
 }
 
 }  // namespace
@@ -476,15 +475,24 @@ void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax)
     hipLaunchKernelGGL(k_tel_linemax, dim3(N / 2 + 1), dim3(256), 0, s, N, (const float*)d_tel, d_tlmax);
 }
 
+void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk) {
+    hipLaunchKernelGGL(k_dmin, dim3((N / 2 + 1 + 15) / 16, ntd), dim3(256), 0, s, N, (const float*)d_D0t,
+                       d_dline, d_dblk);
+}
+
+void launch_task_order(hipStream_t s, int ntask, int nl, const int* d_vkeep, int* d_order) {
+    hipLaunchKernelGGL(k_task_order, dim3(1), dim3(256), 0, s, ntask, (nl + 1) / 2, d_vkeep, d_order);
+}
+
 void launch_vkeep(hipStream_t s, int N, int ntask, int ndir, int nl, const LamPar* d_lp,
-                  const float* d_dmin, const float* d_tlmax, float thr_sum, int* d_vkeep, int fixed,
-                  float* d_dminb) {
-    hipLaunchKernelGGL(k_vkeep, dim3(ntask), dim3(256), 0, s, N / 2 + 1, N / 32, ndir, nl, d_lp, d_dmin,
-                       d_tlmax, thr_sum, d_vkeep, fixed, d_dminb);
+                  const float* d_dline, const float* d_dblk, const float* d_tlmax, float thr_sum,
+                  int* d_vkeep, int fixed, float* d_dminb) {
+    hipLaunchKernelGGL(k_vkeep, dim3(ntask), dim3(256), 0, s, N / 2 + 1, N / 32, ndir, nl, d_lp, d_dline,
+                       d_dblk, d_tlmax, thr_sum, d_vkeep, fixed, d_dminb);
 }
 
 void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,
-                        double scale2, void* d_D0t, bool f64out, const void* d_tw64, float* d_dmin) {
+                        double scale2, void* d_D0t, bool f64out, const void* d_tw64) {
     DISPATCH_N(N, {
         constexpr int SL = LineCfg<NN>::SLOTS;
         constexpr size_t sm = fft_smem<double, NN>(true, fft_nbuf<NN>());
@@ -497,12 +505,12 @@ void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const do
             allow_smem(k_colfft_dphi<NN, double>, sm);
             hipLaunchKernelGGL((k_colfft_dphi<NN, double>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
                                (const cx<double>*)d_C, d_s00, scale2, (double*)d_D0t,
-                               (const cx<double>*)d_tw64, d_dmin);
+                               (const cx<double>*)d_tw64);
         } else {
             allow_smem(k_colfft_dphi<NN, float>, sm);
             hipLaunchKernelGGL((k_colfft_dphi<NN, float>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
                                (const cx<double>*)d_C, d_s00, scale2, (float*)d_D0t,
-                               (const cx<double>*)d_tw64, d_dmin);
+                               (const cx<double>*)d_tw64);
         }
     })
 }

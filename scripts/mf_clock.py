@@ -15,7 +15,7 @@ if eps is not None:
     ctx.set_option('prune_eps', eps)
 for _ in range(3):
     r = ctx.reconstruct(lb, see, gl, l0, np.zeros(rows, np.uint8), (100, 10000))
-nwg = 504
+nwg = 520
 c = ctx.debug_fetch('mf_clock', (nwg, 8, 8))
 cc = c[:, :7, :]
 c = cc[:, :, :6]
