@@ -27,7 +27,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 DOMINANT = 'otf_rowfft'      # the kernel the roofline object describes
 PRIME_STEPS = 64             # untimed, before the warm-up steps
-PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector peak (MI355X_MICROARCH.md)
+PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector / fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak (same guide)
 PEAK_HBM_GBPS = 8000.0
 PIPELINE_HAS_TQ = True       # the sampled first-pass lines go through HBM between two kernels
 sys.path.insert(0, ROOT)
@@ -83,7 +84,7 @@ def fft_flops(dim):
     return 5.0 * dim * math.log2(dim)
 
 
-def hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac=1.0):
+def hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac=1.0, has_tq=True):
     """Algorithmic HBM bytes of one step of the RESTRUCTURED pipeline (DESIGN.md sections 3, 5):
     every intermediate written once and read once by the next kernel, inputs/outputs once."""
     H1, NR = dim // 2 + 1, dim // 2 + 40
@@ -93,7 +94,9 @@ def hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac=1.0):
     b = {}
     b['C (fp64 row transforms of the PSD, write + read)'] = 2 * td * 16 * H1 * NR
     b['D_phi0 (write + read)'] = 2 * td * p * H1 * dim
-    if PIPELINE_HAS_TQ:
+    if mixed and not has_tq:
+        b['D_phi0 (read once more: minima for the pruning)'] = td * p * H1 * dim
+    if PIPELINE_HAS_TQ and has_tq:
         b['Tq (sampled first-pass lines that survive the pruning, write + read)'] = int(
             2 * psf * 2 * p * 21 * H1 * kept_frac)
     b['stamps before the convolutions (write + read)'] = 2 * psf * 1600 * p
@@ -349,6 +352,24 @@ def main():
             lines_kept = ctxs[0].debug_fetch('vkeep', (nprobe, (nl + 1) // 2))
         except Exception:       # pruning switched off in the library
             lines_kept = None
+    # matrix-core per-wavelength kernel: tile steps it executes per row (same probe call, or one
+    # call over the first rows when pruning is off)
+    mf_work = None
+    if mixed:
+        try:
+            if lines_kept is None:
+                nprobe = min(rows, 4096 // nl if nl <= 512 else 8)
+                pf = torch.zeros((nprobe, nl, NFIT), dtype=torch.float64, device=dev)
+                psm = torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev)
+                sp = slice(rank * rows, rank * rows + nprobe)
+                ctxs[0].reconstruct_device(lb, see[sp], gl[sp], l0[sp], three[:nprobe], h, 12.0, a.npsflin,
+                                           None, None, psm.data_ptr(), pf.data_ptr())
+                ctxs[0].sync()
+            w = ctxs[0].debug_fetch('mf_work', (3,))
+            mf_work = {'tile_steps_per_row': w[0] / nprobe, 'tiles_per_row': w[1] / nprobe,
+                       'tile_steps_unpruned_per_row': w[2] / nprobe}
+        except Exception:       # the FFT kernels ran (several directions, or otf_mfma = 0)
+            mf_work = None
     R['close']()
 
     # ---- the same workload with every line of the half plane transformed (prune_eps = 0)
@@ -390,31 +411,55 @@ def main():
         units_per_launch = rows * nl * ndir * a.steps / max(nlaunch, 1)
         tasks_per_launch = rows * a.steps / max(nlaunch, 1)
         avg_s = ms / max(nlaunch, 1) * 1e-3
-        # Dominant kernel: nominal arithmetic = the complex line transforms it performs:
-        # (N/2+1) lines per task (direction mean taken before the transform), two wavelengths per
-        # complex transform, 5 N log2 N flops each.  exp, the bilinear extraction and the index
-        # arithmetic are not counted, so `frac` is a lower bound of the VALU work done.
-        # With line pruning only the transforms that were executed count: the lines below
-        # vkeep[row][pair] (rounded up to the kernel's line groups would be more; not counted).
         ntrans_all = tasks_per_launch * (dim // 2 + 1) * ((nl + 1) // 2)
         kept_frac = float(lines_kept.mean() / (dim // 2 + 1)) if lines_kept is not None else 1.0
-        ntrans = ntrans_all * kept_frac
-        flops = ntrans * fft_flops(dim)
+        if mf_work is not None:
+            # Dominant kernel = the per-wavelength stage on the matrix cores (otf_mfma.hip).  Executed
+            # arithmetic: a tile step (16 lines x 32 columns of the OTF against 48 table columns) is
+            # nine v_mfma_f32_16x16x32_f16 (three fp16 products per fp32-grade product), the second
+            # pass of an m-tile 24 v_mfma_f32_16x16x16_f16.  Only what the pruned launch executes is
+            # counted, so the fraction of the dense fp16 matrix peak is <= 1 by construction.  The
+            # fp32-equivalent figure counts one product per element and no padding (42 of 48
+            # columns; 21 x 21 of 32 x 32 in the second pass): the arithmetic the FFT path's
+            # fraction of the fp32 peak was quoted on.
+            steps = mf_work['tile_steps_per_row'] * tasks_per_launch
+            tiles = mf_work['tiles_per_row'] * tasks_per_launch
+            flops = steps * 9 * 2 * 16 * 16 * 32 + tiles * 24 * 2 * 16 * 16 * 16
+            flops32 = steps * 2 * 16 * 32 * 42 + tiles * 2 * 2 * 16 * 21 * 21
+            peak = PEAK_F16_MFMA_TFLOPS
+            bound = 'mfma'
+            kernel_name = 'otf_mfma'
+            model_txt = ('tile steps executed (block pruning: 16 x 32 blocks of the OTF half plane per row and '
+                         'wavelength) x 9 x v_mfma_f32_16x16x32_f16 + m-tiles x 24 x v_mfma_f32_16x16x16_f16; '
+                         'HIP events on the launch stream, timed region')
+        else:
+            # FFT kernels (f64 mode, several directions): nominal arithmetic = the complex line
+            # transforms performed, (N/2+1) lines per task, two wavelengths per complex transform,
+            # 5 N log2 N flops each; pruned lines are not counted.
+            ntrans = ntrans_all * kept_frac
+            flops = ntrans * fft_flops(dim)
+            flops32 = None
+            peak = PEAK_FP32_TFLOPS if mixed else PEAK_FP32_TFLOPS / 2
+            bound = 'valu_fp32' if mixed else 'valu_fp64'
+            kernel_name = DOMINANT
+            model_txt = ('lines transformed (line pruning: vkeep per row and wavelength pair, of (N/2+1) x '
+                         'ceil(nl/2) per row) x 5 N log2 N flops per complex N-point transform; HIP events on '
+                         'the launch stream, timed region')
         achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0
-        peak = PEAK_FP32_TFLOPS if mixed else PEAK_FP32_TFLOPS / 2
         util = (load_json('r02_kernel_util.json') or load_json('r01_kernel_util.json') or {})
-        u = util.get('k_' + DOMINANT) if (dim, mixed) == (512, True) else None
+        kkey = 'k_otf_mfma1' if mf_work is not None else 'k_' + DOMINANT
+        u = util.get(kkey) if (dim, mixed) == (512, True) else None
         tj = load_json('r02_traffic.json') or load_json('r01_traffic.json')
         traffic = None
         traffic_step = None
         if tj and (dim, nl, rows, a.npsflin, mixed) == (512, 35, 100, 1, True):
-            k = tj['kernels'].get('k_' + DOMINANT, {})
+            k = tj['kernels'].get(kkey, {})
             if k.get('fetch_kib') is not None and k.get('write_kib') is not None:
                 per_unit = (k['fetch_kib'] + k['write_kib']) * 1024.0 / tj['units_per_launch']
                 traffic = per_unit * units_per_launch
             traffic_step = sum((v.get('fetch_kib', 0) + v.get('write_kib', 0)) * 1024.0
                                for v in tj['kernels'].values())
-        model = hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac)
+        model = hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac, has_tq=mf_work is None)
         if tj and 'model_extra' in tj:          # e.g. an intermediate the current pipeline keeps
             model.update(tj['model_extra'])
         model_step = float(sum(model.values()))
@@ -425,26 +470,34 @@ def main():
             'value': round(npsf / dt, 1), 'unit': 'PSFs/sec', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': round(step_s * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64 PSD->structure function, f32 per-lambda OTF/FFT, f64 fit'
-                     if mixed else 'f64',
+            'dtype': ('f64 PSD->structure function, per-lambda OTF f32 -> split-fp16 MFMA (fp32 accumulate), '
+                      'f64 fit' if mf_work is not None else
+                      'f64 PSD->structure function, f32 per-lambda OTF/FFT, f64 fit') if mixed else 'f64',
             'data': 'synthetic',
             'config': {'workload': '%d synthetic SPARTA rows/GPU x %d lambda (%.0f-%.0f nm), '
                                    '%d^2 grid, pixscale %.5f, npsflin=%d (BASELINE.json '
                                    'configs[1])' % (rows, nl, lb[0], lb[-1], dim, ps, a.npsflin),
                        'rows_per_gpu': rows, 'nl': nl, 'dim': dim, 'npsflin': a.npsflin,
                        'chunk_tasks': chunk, 'parallelism': 'rows sharded x%d' % world},
-            # The dominant kernel is bounded by the fp32 vector pipe and the LDS, not by HBM
-            # (DESIGN.md section 5): the fraction is nominal FFT flops against the fp32 vector peak.
-            'roofline': {'bound': 'valu_fp32' if mixed else 'valu_fp64', 'kernel': DOMINANT,
+            # The dominant kernel is the per-wavelength stage: on the matrix
+            # cores in mixed mode with one direction, LDS FFTs on the vector pipe otherwise.
+            'roofline': {'bound': bound, 'kernel': kernel_name,
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'avg_launch_ms': round(avg_s * 1e3, 4), 'launches': nlaunch,
                          'nominal_flops_per_launch': flops,
-                         'model': 'lines transformed (line pruning: vkeep per row and wavelength pair, '
-                                  'of (N/2+1) x ceil(nl/2) per row) x 5 N log2 N flops per complex '
-                                  'N-point transform; HIP events on the launch stream, timed region',
+                         'model': model_txt,
+                         'fp32_equivalent': flops32 and {
+                             'flops_per_launch': flops32,
+                             'achieved': round(flops32 / avg_s / 1e12, 2), 'peak': PEAK_FP32_TFLOPS,
+                             'frac': round(flops32 / avg_s / 1e12 / PEAK_FP32_TFLOPS, 4),
+                             'note': 'one product per element, no padding, against the fp32 matrix / '
+                                     'vector peak'},
+                         'tile_steps_executed_fraction': mf_work and round(
+                             mf_work['tile_steps_per_row'] / mf_work['tile_steps_unpruned_per_row'], 4),
                          'lines_transformed_fraction': round(kept_frac, 4),
                          'valu_issue': u and u.get('valu_issue'),
+                         'mfma_busy': u and u.get('mfma_busy'),
                          'lds_busy': u and u.get('lds_array_busy'),
                          'pmc_source': u and 'profiles/ kernel_util.json (scripts/prof_table.sh, '
                                              'one step in flight)'},

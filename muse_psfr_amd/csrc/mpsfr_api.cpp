@@ -130,6 +130,9 @@ struct mpsfr_ctx {
     const void* cache_ao_ptr = nullptr;
     // bookkeeping for debug_fetch
     int last_ndir = 0, last_nl = 0, last_chunk_tasks = 0, last_lane = 0;
+    bool last_mf = false, last_pruned = false;
+    float last_thr_blk = 0.f;
+    std::vector<double> last_lpc;        // c of every wavelength of the last call
     // profiling
     double prof_ms[K_COUNT] = {0};
     long prof_n[K_COUNT] = {0};
@@ -891,6 +894,11 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     sl.call_pending = true;
     c->last_ndir = ndir;
     c->last_nl = nl;
+    c->last_mf = mf;
+    c->last_pruned = prune;
+    c->last_thr_blk = thr_blk;
+    c->last_lpc.resize(nl);
+    for (int l = 0; l < nl; ++l) c->last_lpc[l] = lp[l].c;
     if (!dev_out) {
         if (fit_out)
             HIPCHK(hipMemcpyAsync(fit_out, d_fit_all, (size_t)ntask * nl * NFIT * sizeof(double),
@@ -956,6 +964,40 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
         n = (size_t)c->last_chunk_tasks * c->last_nl * NS * NS;
         src = c->lane[c->last_lane].pre.p;
         is_real_r = true;
+    } else if (!strcmp(what, "mf_work")) {
+        // Work of the matrix-core per-wavelength kernel in the last chunk, recomputed on the host
+        // from the kernel's own inputs: [0] tile steps executed (16 lines x 32 columns each),
+        // [1] m-tiles with a second pass, [2] tile steps without any pruning.
+        if (capacity < 3) return fail(MPSFR_E_INVALID, "capacity %zu < 3", capacity);
+        if (!c->last_mf) return fail(MPSFR_E_INVALID, "the last call did not use the matrix-core kernel");
+        const int tc = c->last_chunk_tasks, nl = c->last_nl, npair = (nl + 1) / 2;
+        const int nks = N / 32, nmt = (H1 + 15) / 16, nb = nmt * nks;
+        const mpsfr_ctx::Lane& ln = c->lane[c->last_lane];
+        std::vector<int> vk((size_t)tc * npair);
+        std::vector<float> dm((size_t)tc * nb), tb((size_t)nb);
+        if (c->last_pruned) {
+            HIPCHK(hipMemcpy(vk.data(), ln.vkeep.p, vk.size() * sizeof(int), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(dm.data(), ln.dminb.p, dm.size() * sizeof(float), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(tb.data(), c->tlb.p, tb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        double steps = 0.0, tiles = 0.0;
+        for (int t = 0; t < tc; ++t)
+            for (int l = 0; l < nl; ++l) {
+                const float c2 = (float)c->last_lpc[l] * 1.44269504088896340736f;
+                const int nv = c->last_pruned ? vk[(size_t)t * npair + (l >> 1)] : H1;
+                for (int mt = 0; mt < (nv + 15) / 16; ++mt) {
+                    int n = 0;
+                    for (int ks = 0; ks < nks; ++ks)
+                        n += !c->last_pruned ||
+                             std::fmaf(c2, dm[((size_t)t * nmt + mt) * nks + ks], tb[mt * nks + ks]) > c->last_thr_blk;
+                    steps += n;
+                    tiles += n > 0;
+                }
+            }
+        out[0] = steps;
+        out[1] = tiles;
+        out[2] = (double)tc * nl * nb;
+        return 3;
     } else if (!strcmp(what, "mf_clock")) {
         if (!c->mfclk.p) return fail(MPSFR_E_INVALID, "mf_clock is off");
         n = capacity < (size_t)65536 * 64 ? capacity : (size_t)65536 * 64;

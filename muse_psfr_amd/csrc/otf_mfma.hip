@@ -35,11 +35,13 @@ constexpr int MTL = 16;      // lines per m-tile
 constexpr int KBL = 32;      // columns (u) per k-step
 constexpr int NCT = 3;       // column tiles of the first pass: 48 >= 42 real columns
 constexpr int NJT = 2;       // column tiles of the second pass: 32 >= 21
-// The OTF (<= 1, times the number of directions) is generated times 2^kShift: the low half of an
-// element stays a normal fp16 number down to 2^-14 / 2^-12 of 2^kShift, i.e. elements down to
-// 1.2e-4 keep 22 bits, smaller ones an absolute 3e-11.  The stamp is normalised to sum 1 at the end
-// (psfrec.py:685), so the factor drops out.
-constexpr float kShift = 11.0f;
+// The OTF (<= 1) is generated times 2^kShift = 32768: the matrix cores flush fp16 subnormals, so the
+// low half of an element (<= 2^-12 of it) survives down to elements of 2^-14 / 2^-12 / 2^15 = 7.6e-6;
+// smaller ones keep 11 bits (an absolute 2e-9 of the largest).  The first-pass sums, scaled back
+// by the table factors, stay below 2^kShift as well.  The stamp is normalised to sum 1 at the end
+// (psfrec.py:685), so the factor drops out.  (Several directions: the sum over the directions is
+// scaled down by the next power of two, see K_OTF_MFMA.)
+constexpr float kShift = 15.0f;
 // The E and G tables (|E| <= 1, |G| <= 2) are stored times 2^kTabShift for the same reason: the low
 // half of an entry (<= 2^-12 of it) would otherwise sit in the fp16 subnormal range, which the
 // matrix cores flush.
@@ -293,6 +295,8 @@ k_otf_mfma(const MfArgs a) {
         R2y[jt] = f4{0.f, 0.f, 0.f, 0.f};
     }
     const size_t dstride = (size_t)H1 * N;
+    float dirshift = 0.f;                      // sum over the directions <= 2^dirshift
+    while ((1 << (int)dirshift) < a.ndir) dirshift += 1.f;
     const float* Dtask = a.D0t + (size_t)task * a.ndir * dstride + 8 * lk;
     const float* Tl = a.tl2 + 8 * lk;
     const h8* El = a.E + (size_t)l * nks * NCT * 2 * 64 + lane;
@@ -359,8 +363,8 @@ k_otf_mfma(const MfArgs a) {
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        x[e] = s[e] * __builtin_amdgcn_exp2f(t0[e]);
-                        x[4 + e] = s[4 + e] * __builtin_amdgcn_exp2f(t1[e]);
+                        x[e] = s[e] * __builtin_amdgcn_exp2f(t0[e] - dirshift);
+                        x[4 + e] = s[4 + e] * __builtin_amdgcn_exp2f(t1[e] - dirshift);
                     }
                 }
                 h8 ah, al;
