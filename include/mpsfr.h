@@ -76,9 +76,13 @@ const char* mpsfr_last_error(void);
  * overlaps the next one's body; results are independent of it except for the summation order of
  * psf_sum_out in multi-chunk calls); "pipeline_calls" (default 1: asynchronous calls rotate over
  * the lanes; 0: every call starts on the first lane); "prune_eps" (mixed mode only, default 1e-9:
- * the trailing lines of the OTF half plane that together weigh less than eps of the PSF peak are
- * neither transformed nor summed -- no stamp pixel changes by more than eps of the peak;
- * 0 = transform every line); "profile" (0/1: bracket every kernel launch
+ * the parts of the OTF half plane -- trailing lines, and 16 x 32 blocks inside the lines kept --
+ * that together weigh less than eps of the PSF peak are neither generated nor summed: no stamp
+ * pixel changes by more than eps of the peak; 0 = everything); "otf_mfma" (mixed mode only,
+ * default 1: the per-wavelength stage as split-fp16 contractions on the matrix cores -- used for
+ * one direction, and on the 1280 grid for any; 0: LDS FFTs on the vector pipe); "otf_mfma_ndir"
+ * (default 0; 1: the matrix-core stage for several directions on every grid); "profile" (0/1:
+ * bracket every kernel launch
  * with HIP events on the stream it is launched on -- the event packets cost ~8 % of a step);
  * "profile_only" (-1 = all kernels, else the kernel id of mpsfr_profile_name to time alone). */
 int mpsfr_set_option(mpsfr_ctx* ctx, const char* key, double value);
@@ -144,6 +148,8 @@ int mpsfr_host_time(mpsfr_ctx* ctx, double* seconds, long* calls);
  *   "pre"        [chunk tasks][nl][dimpsf][dimpsf] stamps before the convolutions (psfrec.py:685)
  *   "vkeep"      [chunk tasks][(nl+1)/2] lines of the half plane transformed per wavelength pair
  *                (option "prune_eps")
+ *   "mf_work"    [3] matrix-core stage, last chunk: tile steps executed, m-tiles with a second
+ *                pass, tile steps without pruning
  * Returns the number of doubles written (<= capacity) or a negative error. */
 long mpsfr_debug_fetch(mpsfr_ctx* ctx, const char* what, double* out, size_t capacity);
 

@@ -662,10 +662,11 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     // G rows are padded to a multiple of 8 lines (paired-line layout of the fp32 second pass)
     if ((rc = ensure(c, c->G, (size_t)nl * ((H1 + 7) / 8 * 8) * NS * 2 * rsize(c)))) return rc;
     if ((rc = ensure(c, c->kmuse, (size_t)nl * ksz))) return rc;
-    // per-wavelength stage on the matrix cores: single direction (with several directions the OTF
-    // tile costs ndir exponentials per element and the FFT kernels, which keep D in registers
-    // over all wavelengths, measure 8 % faster at 256^2 x 9 directions)
-    const bool mf = !c->f64 && c->otf_mfma && (ndir == 1 || c->otf_mfma_ndir);
+    // Per-wavelength stage on the matrix cores: single direction.  With several directions the OTF
+    // tile costs ndir exponentials per element and nothing of it is shared between wavelengths: the
+    // FFT kernels, which keep D in registers over all wavelengths, measure 8-19 % faster at
+    // 256^2 ... 1024^2 -- but 30 % slower on the native 1280^2 grid (four-pass 4.4.4.20 lines).
+    const bool mf = !c->f64 && c->otf_mfma && (ndir == 1 || N == 1280 || c->otf_mfma_ndir);
     const bool r16 = !mf && otf_uses_r16(N, c->f64, nl, ndir);
     if (r16 && (rc = ensure(c, c->xtab, xtab_bytes(nl)))) return rc;
     if (mf) {

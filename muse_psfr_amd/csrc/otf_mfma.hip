@@ -267,7 +267,6 @@ struct MfArgs {
     unsigned long long* clk; // experiments: per-wave phase time stamps (or nullptr)
 };
 
-template <bool ONE_DIR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MPSFR_MF_WAVES, MPSFR_MF_WAVES)))
 k_otf_mfma(const MfArgs a) {
     constexpr int GRP = MPSFR_MF_GROUP;
@@ -341,14 +340,7 @@ k_otf_mfma(const MfArgs a) {
                 const float* tp = Tl + (size_t)v * N + KBL * ks;
                 const f4 t0 = *reinterpret_cast<const f4*>(tp), t1 = *reinterpret_cast<const f4*>(tp + 4);
                 float x[8];
-                if constexpr (ONE_DIR) {
-                    const f4 d0 = *reinterpret_cast<const f4*>(dp), d1 = *reinterpret_cast<const f4*>(dp + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        x[e] = __builtin_amdgcn_exp2f(fmaf(c2, d0[e], t0[e]));
-                        x[4 + e] = __builtin_amdgcn_exp2f(fmaf(c2, d1[e], t1[e]));
-                    }
-                } else {
+                {
                     float s[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) s[e] = 0.f;
@@ -757,10 +749,7 @@ void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const vo
     a.pre = (float*)d_pre;
     a.clk = (unsigned long long*)d_clk;
     a.order = d_order;
-#ifndef MPSFR_MF_DMA
-#define MPSFR_MF_DMA 1
-#endif
-    if (ndir == 1 && MPSFR_MF_DMA) {
+    if (ndir == 1) {
         // wavelength groups of at most eight, as even as possible: one wave per wavelength
         const int ngr = (nl + 7) / 8, per = (nl + ngr - 1) / ngr;
         allow_smem(k_otf_mfma1, (size_t)kMfLds);
@@ -769,8 +758,7 @@ void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const vo
     }
     const int nwg = ((ntask + 3) / 4) * nl;
     const int grid = (nwg + 7) / 8 * 8;
-    if (ndir == 1) hipLaunchKernelGGL(k_otf_mfma<true>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_otf_mfma<false>, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_otf_mfma, dim3(grid), dim3(256), 0, s, a);
 }
 
 }  // namespace mpsfr

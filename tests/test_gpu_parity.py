@@ -676,6 +676,44 @@ def test_line_pruning_changes_nothing_above_its_bound(api, dim, npl):
     assert vk[1, 0] < 0.25 * nv                          # and most of its half plane is dropped
 
 
+@pytest.mark.parametrize('dim,npl', [(512, 1), (128, 1), (256, 2), (1280, 1)])
+def test_matrix_core_stage_against_the_fft_stage(api, dim, npl):
+    """Mixed mode has two implementations of the per-wavelength stage: split-fp16 contractions on
+    the matrix cores (default for one direction; option otf_mfma_ndir for several) and LDS FFTs
+    (otf_mfma = 0).  Both are pinned to the oracle elsewhere; here they must agree with each other
+    at fp32 level on stamps and fits, with and without pruning, and the work the matrix-core stage
+    reports must shrink with the pruning."""
+    see, gl, l0 = api.synthetic_rows(6)
+    see[0], gl[0], l0[0] = 0.45, 0.9, 28.0
+    lb = np.array([470., 600., 760., 925.]) if dim != 1280 else np.array([500., 700., 930.])
+    ps = api.grid_pixscale(dim) if dim != 1280 else 0.2
+    three = (np.arange(6) % 3 == 1).astype(np.uint8)
+    out, work = {}, {}
+    for key, opts in (('fft', {'otf_mfma': 0}), ('mfma', {'otf_mfma_ndir': 1}),
+                      ('mfma_all', {'otf_mfma_ndir': 1, 'prune_eps': 0.0})):
+        ctx = api.Context(dim=dim, pixscale=ps, precision='mixed')
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        out[key] = ctx.reconstruct(lb, see, gl, l0, three, H, npsflin=npl)
+        if key != 'fft':
+            work[key] = ctx.debug_fetch('mf_work', (3,))
+        else:
+            with pytest.raises(api.MpsfrError):
+                ctx.debug_fetch('mf_work', (3,))
+        ctx.close()
+    a = out['fft']
+    peak = a['psf'].max(axis=(2, 3), keepdims=True)
+    for key in ('mfma', 'mfma_all'):
+        b = out[key]
+        assert (np.abs(b['psf'] - a['psf']) / peak).max() < 5e-6, key
+        well = a['fit'][:, :, 4] < 10
+        assert np.abs(b['fit'][:, :, 5] - a['fit'][:, :, 5])[well].max(initial=0) * ps < 1e-5, key
+        assert np.abs(b['fit'][:, :, 4] - a['fit'][:, :, 4])[well].max(initial=0) < 5e-5, key
+    assert work['mfma_all'][0] == work['mfma_all'][2]            # no pruning: every tile step
+    assert 0 < work['mfma'][0] < 0.8 * work['mfma_all'][0]
+    assert work['mfma'][1] <= work['mfma_all'][1]
+
+
 def test_line_pruning_is_off_in_f64_mode(api):
     ctx = api.Context(dim=128, pixscale=api.grid_pixscale(128), precision='f64')
     ctx.reconstruct([700.0], [1.0], [0.7], [25.0], [0], H)
