@@ -28,7 +28,7 @@ def test_library_builds_and_exports_the_header():
     assert lib.mpsfr_version() == 101
     from muse_psfr_amd._build import source_hash
     assert lib.mpsfr_build_id().decode() == source_hash()
-    assert lib.mpsfr_profile_count() == 12
+    assert lib.mpsfr_profile_count() == 13
     assert lib.mpsfr_profile_name(7) == b'otf_rowfft'
 
 
