@@ -430,7 +430,7 @@ k_otf_mfma(const MfArgs a) {
 // results bit-identical for any chunking or lane count.
 // ------------------------------------------------------------------------------------------
 #ifndef MPSFR_MF_KNOCK
-#define MPSFR_MF_KNOCK 0         // kernel experiments: 1 = no loads, 2 = loads only
+#define MPSFR_MF_KNOCK 0         // kernel experiments: 1 = no loads, 2 = loads only, 3 = no products, 4 = no OTF arithmetic
 #endif
 constexpr int kMfTiles = 8;                         // m-tiles per sweep over the k-steps
 constexpr int kMfStage = kMfTiles * 4096;           // one staging buffer: 8 x (D 2 KB | log2 tel 2 KB)
@@ -486,9 +486,22 @@ k_otf_mfma1(const MfArgs a, int per, int ngr) {
     // its own L2): XCD x takes the tasks of rank x, x + 8, ... in dispatch order (heaviest first),
     // all wavelength groups of a task one after the other (they read its D from that L2), longest
     // wavelengths first.
+    // The tasks beyond the last full round of eight (the lightest) are dealt group by group, so
+    // that no XCD gets a whole task more than another: 500 workgroups on 8 x 32 CUs must be 62 or
+    // 63 per XCD (two rounds), not 65 and 60.
     const int xcd = blockIdx.x & 7, ql = blockIdx.x >> 3;
-    const int rank = (ql / ngr) * 8 + xcd, grp = ngr - 1 - ql % ngr;
-    if (rank >= a.ntask) return;                         // whole workgroup
+    const int full = (a.ntask >> 3) * ngr;               // workgroups per XCD from the full rounds
+    int rank, gi;
+    if (ql < full) {
+        rank = (ql / ngr) * 8 + xcd;
+        gi = ql % ngr;
+    } else {
+        const int j = (ql - full) * 8 + xcd;
+        if (j >= (a.ntask & 7) * ngr) return;            // whole workgroup
+        rank = (a.ntask & ~7) + j / ngr;
+        gi = j % ngr;
+    }
+    const int grp = ngr - 1 - gi;
     const int task = a.order != nullptr ? a.order[rank] : rank;
     unsigned long long* clk = a.clk != nullptr && lane == 0 ? a.clk + ((size_t)blockIdx.x * 8 + wave) * 8 : nullptr;
 #define MF_STAMP(i_) if (clk != nullptr) clk[i_] = __builtin_readcyclecounter()
@@ -525,7 +538,7 @@ k_otf_mfma1(const MfArgs a, int per, int ngr) {
     const char* etab = reinterpret_cast<const char*>(a.E + (size_t)l * nks * NCT * 2 * 64);
     const h4* Gl = a.G + (size_t)l * nmt_all * NJT * 2 * 2 * 64 + lane;
 
-    unsigned long long t_kloop = 0, t_pass2 = 0;
+    unsigned long long t_kloop = 0, t_pass2 = 0, t_wload = 0, t_wbar = 0, n_iter = 0;
     unsigned mytiles = 0;                  // the tiles of a sweep this wave fetches
     for (int g = wave; g < GRP; g += per) mytiles |= 1u << g;
     for (int g0 = 0; g0 < nmtu; g0 += GRP) {
@@ -616,11 +629,16 @@ k_otf_mfma1(const MfArgs a, int per, int ngr) {
                     const f4 t0 = *reinterpret_cast<const f4*>(tp + 2048);
                     const f4 t1 = *reinterpret_cast<const f4*>(tp + 3072);
                     unsigned hi[4], lo[4];
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    if (MPSFR_MF_KNOCK == 4) {          // experiment: no OTF arithmetic
+                        ah = __builtin_bit_cast(h8, d0 + t0);
+                        al = __builtin_bit_cast(h8, d1 + t1);
+                        return;
+                    }
                     otf_pair(cc, f2{d0[0], d0[1]}, f2{t0[0], t0[1]}, &hi[0], &lo[0]);
                     otf_pair(cc, f2{d0[2], d0[3]}, f2{t0[2], t0[3]}, &hi[1], &lo[1]);
                     otf_pair(cc, f2{d1[0], d1[1]}, f2{t1[0], t1[1]}, &hi[2], &lo[2]);
                     otf_pair(cc, f2{d1[2], d1[3]}, f2{t1[2], t1[3]}, &hi[3], &lo[3]);
-                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
                     ah = __builtin_bit_cast(h8, u4{hi[0], hi[1], hi[2], hi[3]});
                     al = __builtin_bit_cast(h8, u4{lo[0], lo[1], lo[2], lo[3]});
                 };
@@ -631,7 +649,7 @@ k_otf_mfma1(const MfArgs a, int per, int ngr) {
                     const h8 ch = ah, cl = al;
                     const unsigned later = gbits & ~((2u << g) - 1u);
                     prepare(later != 0 ? __builtin_ctz(later) : g);
-                    if (MPSFR_MF_KNOCK == 2) {          // experiment: loads only
+                    if (MPSFR_MF_KNOCK == 2 || MPSFR_MF_KNOCK == 3) {   // experiments: loads only / no products
                         acc[g][0][0] += (float)ch[0] + (float)cl[0];
                         continue;
                     }
@@ -647,8 +665,15 @@ k_otf_mfma1(const MfArgs a, int per, int ngr) {
                 }
             }
             // the next k-step's tiles have landed, and nobody reads this k-step's any more
+            const unsigned long long tw0 = clk != nullptr ? __builtin_readcyclecounter() : 0;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long tw1 = clk != nullptr ? __builtin_readcyclecounter() : 0;
             __builtin_amdgcn_s_barrier();
+            if (clk != nullptr) {
+                t_wload += tw1 - tw0;
+                t_wbar += __builtin_readcyclecounter() - tw1;
+                n_iter += 1;
+            }
             buf ^= 1;
         }
         const unsigned long long tk1 = clk != nullptr ? __builtin_readcyclecounter() : 0;
@@ -707,7 +732,7 @@ k_otf_mfma1(const MfArgs a, int per, int ngr) {
         }
     }
     MF_STAMP(4);
-    if (clk != nullptr) { clk[6] = t_kloop; clk[7] = t_pass2; }
+    if (clk != nullptr) { clk[6] = t_kloop; clk[7] = t_pass2; clk[1] = t_wload; clk[2] = t_wbar; clk[3] = n_iter; }
     if (lv) write_stamp(P0, Q0, R2x, R2y, lr, lk, a.pre + ((size_t)task * a.nl + l) * NS * NS);
     MF_STAMP(5);
 #undef MF_STAMP
@@ -753,7 +778,8 @@ void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const vo
         // wavelength groups of at most eight, as even as possible: one wave per wavelength
         const int ngr = (nl + 7) / 8, per = (nl + ngr - 1) / ngr;
         allow_smem(k_otf_mfma1, (size_t)kMfLds);
-        hipLaunchKernelGGL(k_otf_mfma1, dim3(8 * ((ntask + 7) / 8) * ngr), dim3(64 * per), kMfLds, s, a, per, ngr);
+        const int per_xcd = (ntask / 8) * ngr + ((ntask % 8) * ngr + 7) / 8;
+        hipLaunchKernelGGL(k_otf_mfma1, dim3(8 * per_xcd), dim3(64 * per), kMfLds, s, a, per, ngr);
         return;
     }
     const int nwg = ((ntask + 3) / 4) * nl;
