@@ -29,11 +29,13 @@ print('Source: `scripts/prof_table.sh` -- rocprofv3 kernel trace (durations) and
 print('VALU = SQ_INSTS_VALU x 2 issue cycles / (1024 SIMDs x kernel cycles at 2.4 GHz), a lower bound: fp64 '
       'and transcendental instructions take 4; LDS = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles); '
       'HBM = (FETCH_SIZE + WRITE_SIZE) / duration, uncorrected.\n')
-print('| kernel | avg us | VALU issue | LDS array busy | of which bank conflicts | HBM GB/s |')
-print('|---|---|---|---|---|---|')
+print('MFMA = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles).\n')
+print('| kernel | avg us | VALU issue | MFMA busy | LDS array busy | of which bank conflicts | HBM GB/s |')
+print('|---|---|---|---|---|---|---|')
 util = {}
-for k in ('k_otf_r16', 'k_otf_rowfft', 'k_fit', 'k_conv_fft', 'k_colpass_m', 'k_psd_rowfft', 'k_colfft_dphi',
-          'k_khat', 'k_stamp_sum', 'k_dc_sum', 'k_vkeep'):
+for k in ('k_otf_mfma1', 'k_otf_mfma', 'k_otf_r16', 'k_otf_rowfft', 'k_fit', 'k_conv_fft', 'k_colpass_m',
+          'k_psd_rowfft', 'k_colfft_dphi', 'k_dmin', 'k_vkeep', 'k_task_order', 'k_khat', 'k_stamp_sum',
+          'k_dc_sum'):
     if k not in dur:
         continue
     t = dur[k]
@@ -42,9 +44,11 @@ for k in ('k_otf_r16', 'k_otf_rowfft', 'k_fit', 'k_conv_fft', 'k_colpass_m', 'k_
     lds = get(k, 'SQ_LDS_IDX_ACTIVE') / (256 * cyc)
     conf = get(k, 'SQ_LDS_BANK_CONFLICT') / max(get(k, 'SQ_LDS_IDX_ACTIVE'), 1)
     hbm = (get(k, 'FETCH_SIZE') + get(k, 'WRITE_SIZE')) * 1024 / t / 1e9
-    print('| `%s` | %.1f | %.0f %% | %.0f %% | %.0f %% | %.0f |' % (k, t * 1e6, valu * 100, lds * 100,
-                                                                 conf * 100, hbm))
-    util[k] = {'avg_us': round(t * 1e6, 1), 'valu_issue': round(valu, 3), 'lds_array_busy': round(lds, 3),
+    mfma = get(k, 'SQ_VALU_MFMA_BUSY_CYCLES') / (1024 * cyc)
+    print('| `%s` | %.1f | %.0f %% | %.0f %% | %.0f %% | %.0f %% | %.0f |' % (k, t * 1e6, valu * 100, mfma * 100,
+                                                                         lds * 100, conf * 100, hbm))
+    util[k] = {'avg_us': round(t * 1e6, 1), 'valu_issue': round(valu, 3), 'mfma_busy': round(mfma, 3),
+               'lds_array_busy': round(lds, 3),
                'lds_conflict_share': round(conf, 3), 'hbm_GBps': round(hbm, 1)}
     wc = get(k, 'SQ_WAVE_CYCLES')
     if wc:      # where the wave cycles go (disjoint): issuing / issue stall (of which LDS) / waitcnt
