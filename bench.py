@@ -193,7 +193,7 @@ def main():
 
     from muse_psfr_amd.distributed import ShardExchange
 
-    def make_runner(precision, nctx, prune_eps=a.prune_eps):
+    def make_runner(precision, nctx, prune_eps=a.prune_eps, streams=a.streams):
         """Steps are independent batches, pipelined through `nctx` contexts (each with its own
         HIP stream and workspaces) fed in turn.  A step is still one mpsfr_reconstruct of the
         rank's rows; every step's outputs are produced."""
@@ -203,8 +203,8 @@ def main():
             if a.chunk:
                 c.set_option('chunk_tasks', a.chunk)
             c.set_option('fast_exp', a.fast_exp)
-            if a.streams:
-                c.set_option('streams', a.streams)
+            if streams:
+                c.set_option('streams', streams)
             if prune_eps >= 0 and precision == 'mixed':
                 c.set_option('prune_eps', prune_eps)
             if os.environ.get('MPSFR_OTF_MFMA') and precision == 'mixed':     # experiments: 0 = FFT path
@@ -374,6 +374,21 @@ def main():
             mf_work = None
     R['close']()
 
+    # ---- the dominant kernel with one call in flight (no other kernel beside it on the GPU): what
+    # the kernel itself achieves, as opposed to its share of the GPU in the pipelined run
+    alone_ms = None
+    if mixed and a.profile_steps != 0:
+        R4 = make_runner(a.precision, 1, streams=1)
+        for _ in range(8):
+            R4['step']()
+        for c in R4['ctxs']:
+            c.set_option('profile_only', c.profile_names().index(DOMINANT))
+            c.set_option('profile', 1)
+        R4['timed'](40)
+        ms4, n4 = R4['profile_sum']()[DOMINANT]
+        alone_ms = ms4 / max(n4, 1)
+        R4['close']()
+
     # ---- the same workload with every line of the half plane transformed (prune_eps = 0)
     unpruned = None
     nunp = (max(20, a.steps // 4) if a.unpruned_steps < 0 else a.unpruned_steps) if lines_kept is not None else 0
@@ -487,6 +502,13 @@ def main():
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'avg_launch_ms': round(avg_s * 1e3, 4), 'launches': nlaunch,
+                         'one_call_in_flight': alone_ms and {
+                             'avg_launch_ms': round(alone_ms, 4),
+                             'achieved': round(flops / (alone_ms * 1e-3) / 1e12, 2),
+                             'frac': round(flops / (alone_ms * 1e-3) / 1e12 / peak, 4),
+                             'note': 'same launches with nothing else on the GPU (one lane, 40 steps after '
+                                     'the timed region); in the timed region the other lane\'s kernels '
+                                     'share the CUs'},
                          'nominal_flops_per_launch': flops,
                          'model': model_txt,
                          'fp32_equivalent': flops32 and {

@@ -422,13 +422,14 @@ __global__ void __launch_bounds__(256) k_vkeep(int H1, int nks, int ndir, int nl
 // on them (longest-processing-time-first list scheduling).
 __global__ void __launch_bounds__(256) k_task_order(int ntask, int npair, const int* __restrict__ vkeep,
                                                     int* __restrict__ order) {
+    constexpr int MAXT = 4096;                       // chunk_tasks is at most 4096
+    __shared__ int key[MAXT];
+    for (int t = threadIdx.x; t < ntask; t += 256) key[t] = vkeep[(size_t)t * npair + npair - 1];
+    __syncthreads();
     for (int t = threadIdx.x; t < ntask; t += 256) {
-        const int key = vkeep[(size_t)t * npair + npair - 1];
+        const int k = key[t];
         int rank = 0;
-        for (int o = 0; o < ntask; ++o) {
-            const int ko = vkeep[(size_t)o * npair + npair - 1];
-            rank += (ko > key) || (ko == key && o < t);
-        }
+        for (int o = 0; o < ntask; ++o) rank += (key[o] > k) || (key[o] == k && o < t);
         order[rank] = t;
     }
 }
