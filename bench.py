@@ -209,8 +209,6 @@ def main():
                 c.set_option('prune_eps', prune_eps)
             if os.environ.get('MPSFR_OTF_MFMA') and precision == 'mixed':     # experiments: 0 = FFT path
                 c.set_option('otf_mfma', int(os.environ['MPSFR_OTF_MFMA']))
-            if os.environ.get('MPSFR_OTF_MFMA_NDIR') and precision == 'mixed':
-                c.set_option('otf_mfma_ndir', int(os.environ['MPSFR_OTF_MFMA_NDIR']))
             if os.environ.get('MPSFR_PRUNE_FIXED') and precision == 'mixed':
                 c.set_option('prune_fixed', int(os.environ['MPSFR_PRUNE_FIXED']))
             ctxs.append(c)

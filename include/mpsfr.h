@@ -79,10 +79,8 @@ const char* mpsfr_last_error(void);
  * the parts of the OTF half plane -- trailing lines, and 16 x 32 blocks inside the lines kept --
  * that together weigh less than eps of the PSF peak are neither generated nor summed: no stamp
  * pixel changes by more than eps of the peak; 0 = everything); "otf_mfma" (mixed mode only,
- * default 1: the per-wavelength stage as split-fp16 contractions on the matrix cores -- used for
- * one direction, and on the 1280 grid for any; 0: LDS FFTs on the vector pipe); "otf_mfma_ndir"
- * (default 0; 1: the matrix-core stage for several directions on every grid); "profile" (0/1:
- * bracket every kernel launch
+ * default 1: the per-wavelength stage as split-fp16 contractions on the matrix cores; 0: LDS
+ * FFTs on the vector pipe); "profile" (0/1: bracket every kernel launch
  * with HIP events on the stream it is launched on -- the event packets cost ~8 % of a step);
  * "profile_only" (-1 = all kernels, else the kernel id of mpsfr_profile_name to time alone). */
 int mpsfr_set_option(mpsfr_ctx* ctx, const char* key, double value);

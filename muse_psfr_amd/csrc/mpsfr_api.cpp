@@ -69,7 +69,6 @@ struct mpsfr_ctx {
     int prune_fixed = 0;         // experiments: transform exactly this many lines (wrong results)
     double prune_eps = 1.0e-9;   // mixed mode: line pruning of the per-wavelength stage (0 = off)
     bool otf_mfma = true;        // mixed mode: per-wavelength stage on the matrix cores (otf_mfma.hip)
-    bool otf_mfma_ndir = false;  // ... also with several directions (generic kernel)
     bool mf_clock = false;       // experiments: phase time stamps of the matrix-core kernel
     DevBuf mfclk;
     // constant tables
@@ -427,8 +426,6 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         c->prune_eps = value;
     } else if (!strcmp(key, "otf_mfma")) {
         c->otf_mfma = value != 0.0;
-    } else if (!strcmp(key, "otf_mfma_ndir")) {
-        c->otf_mfma_ndir = value != 0.0;
     } else if (!strcmp(key, "mf_clock")) {
         c->mf_clock = value != 0.0;
         if (c->mf_clock) {
@@ -662,11 +659,8 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     // G rows are padded to a multiple of 8 lines (paired-line layout of the fp32 second pass)
     if ((rc = ensure(c, c->G, (size_t)nl * ((H1 + 7) / 8 * 8) * NS * 2 * rsize(c)))) return rc;
     if ((rc = ensure(c, c->kmuse, (size_t)nl * ksz))) return rc;
-    // Per-wavelength stage on the matrix cores: single direction.  With several directions the OTF
-    // tile costs ndir exponentials per element and nothing of it is shared between wavelengths: the
-    // FFT kernels, which keep D in registers over all wavelengths, measure 8-19 % faster at
-    // 256^2 ... 1024^2 -- but 30 % slower on the native 1280^2 grid (four-pass 4.4.4.20 lines).
-    const bool mf = !c->f64 && c->otf_mfma && (ndir == 1 || N == 1280 || c->otf_mfma_ndir);
+    // per-wavelength stage on the matrix cores (otf_mfma = 0: LDS FFTs on the vector pipe)
+    const bool mf = !c->f64 && c->otf_mfma;
     const bool r16 = !mf && otf_uses_r16(N, c->f64, nl, ndir);
     if (r16 && (rc = ensure(c, c->xtab, xtab_bytes(nl)))) return rc;
     if (mf) {

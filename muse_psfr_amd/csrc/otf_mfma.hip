@@ -233,23 +233,12 @@ __device__ __forceinline__ void write_stamp(const f4* P0, const f4* Q0, const f4
 }
 
 // ------------------------------------------------------------------------------------------
-// K_OTF_MFMA.  One wavefront per (task, wavelength); a workgroup is four tasks at one wavelength
-// (their E / G table reads meet in the L1), and the workgroups of one task follow each other on
-// the same XCD (its D lines stay in that L2).
-//
-// Pruning.  vkeep[task][pair] (K_VKEEP, stage_a.hip) bounds the lines; inside them a block of
-// 16 lines x 32 columns is generated only if  2^(c' dminb + tlb) > 2^thr,  dminb the block minimum
-// of D over lines, columns and directions (K_VKEEP) and tlb the block maximum of log2 tel: every
-// element of a dropped block is below 2^thr, and the host sets thr so that all blocks together
-// weigh less than eps / 2 of the PSF peak (>= OTF[0][0] = 1).
+// Pruning of K_OTF_MFMA1.  vkeep[task][pair] (K_VKEEP, stage_a.hip) bounds the lines; inside them
+// a block of 16 lines x 32 columns is generated only if  2^(c' dminb + tlb) > 2^thr,  dminb the
+// block minimum of D over lines, columns and directions (K_DMIN, K_VKEEP) and tlb the block maximum
+// of log2 tel: every element of a dropped block is below 2^thr, and the host sets thr so that all
+// blocks together weigh less than eps / 2 of the PSF peak (>= OTF[0][0] = 1).
 // ------------------------------------------------------------------------------------------
-#ifndef MPSFR_MF_GROUP
-#define MPSFR_MF_GROUP 8        // m-tiles accumulated per sweep over the k-steps
-#endif
-#ifndef MPSFR_MF_WAVES
-#define MPSFR_MF_WAVES 2
-#endif
-
 struct MfArgs {
     int N, ntask, ndir, nl;
     const float* D0t;        // [ntask ndir][N/2+1][N]
@@ -266,145 +255,6 @@ struct MfArgs {
     const int* order;        // [ntask] dispatch order of the tasks, or nullptr
     unsigned long long* clk; // experiments: per-wave phase time stamps (or nullptr)
 };
-
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MPSFR_MF_WAVES, MPSFR_MF_WAVES)))
-k_otf_mfma(const MfArgs a) {
-    constexpr int GRP = MPSFR_MF_GROUP;
-    const int N = a.N, H1 = N / 2 + 1, nks = mf_nks(N), nmt_all = mf_nmt(N);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lr = lane & 15, lk = lane >> 4;
-    // workgroup -> (task quad, wavelength): consecutive blockIdx go round the 8 XCDs, so the
-    // logical index runs through one XCD's share before the next one's
-    const int nwg = gridDim.x, per_xcd = (nwg + 7) / 8;
-    const int q = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int ntq = (a.ntask + 3) / 4;
-    if (q >= ntq * a.nl) return;
-    const int l = q % a.nl, task = (q / a.nl) * 4 + wave;
-    if (task >= a.ntask) return;
-    const float c2 = (float)a.lp[l].c * 1.44269504088896340736f;
-    const int nv = a.vkeep != nullptr ? a.vkeep[(size_t)task * ((a.nl + 1) / 2) + (l >> 1)] : H1;
-    const int nmt = (nv + MTL - 1) / MTL;
-
-    f4 P0[NJT], Q0[NJT], R2x[NJT], R2y[NJT];
-#pragma unroll
-    for (int jt = 0; jt < NJT; ++jt) {
-        P0[jt] = f4{0.f, 0.f, 0.f, 0.f};
-        Q0[jt] = f4{0.f, 0.f, 0.f, 0.f};
-        R2x[jt] = f4{0.f, 0.f, 0.f, 0.f};
-        R2y[jt] = f4{0.f, 0.f, 0.f, 0.f};
-    }
-    const size_t dstride = (size_t)H1 * N;
-    float dirshift = 0.f;                      // sum over the directions <= 2^dirshift
-    while ((1 << (int)dirshift) < a.ndir) dirshift += 1.f;
-    const float* Dtask = a.D0t + (size_t)task * a.ndir * dstride + 8 * lk;
-    const float* Tl = a.tl2 + 8 * lk;
-    const h8* El = a.E + (size_t)l * nks * NCT * 2 * 64 + lane;
-    const h4* Gl = a.G + (size_t)l * nmt_all * NJT * 2 * 2 * 64 + lane;
-
-    for (int g0 = 0; g0 < nmt; g0 += GRP) {
-        // which k-steps each m-tile of the group needs
-        unsigned long long mask[GRP], uni = 0;
-#pragma unroll
-        for (int g = 0; g < GRP; ++g) {
-            const int mt = g0 + g;
-            bool on = mt < nmt && lane < nks;
-            if (a.dminb != nullptr && on) {
-                const float dm = a.dminb[((size_t)task * nmt_all + mt) * nks + lane];
-                on = fmaf(c2, dm, a.tlb[mt * nks + lane]) > a.thr;
-            }
-            mask[g] = __ballot(on);
-            uni |= mask[g];
-        }
-        f4 acc[GRP][NCT];
-#pragma unroll
-        for (int g = 0; g < GRP; ++g)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[g][ct] = f4{0.f, 0.f, 0.f, 0.f};
-
-        while (uni != 0) {
-            const int ks = __builtin_ctzll(uni);
-            uni &= uni - 1;
-            h8 bh[NCT], bl[NCT];
-            const h8* Ek = El + (size_t)ks * NCT * 2 * 64;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                bh[ct] = Ek[(ct * 2) * 64];
-                bl[ct] = Ek[(ct * 2 + 1) * 64];
-            }
-#pragma unroll
-            for (int g = 0; g < GRP; ++g) {
-                if (!((mask[g] >> ks) & 1)) continue;
-                const int v = MTL * (g0 + g) + lr;
-                const int vc = v < H1 ? v : H1 - 1;          // padding lines: tl2 = -inf there
-                const float* dp = Dtask + (size_t)vc * N + KBL * ks;
-                const float* tp = Tl + (size_t)v * N + KBL * ks;
-                const f4 t0 = *reinterpret_cast<const f4*>(tp), t1 = *reinterpret_cast<const f4*>(tp + 4);
-                float x[8];
-                {
-                    float s[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) s[e] = 0.f;
-                    for (int d = 0; d < a.ndir; ++d) {
-                        const f4 d0 = *reinterpret_cast<const f4*>(dp + d * dstride);
-                        const f4 d1 = *reinterpret_cast<const f4*>(dp + d * dstride + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            s[e] += __builtin_amdgcn_exp2f(c2 * d0[e]);
-                            s[4 + e] += __builtin_amdgcn_exp2f(c2 * d1[e]);
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        x[e] = s[e] * __builtin_amdgcn_exp2f(t0[e] - dirshift);
-                        x[4 + e] = s[4 + e] * __builtin_amdgcn_exp2f(t1[e] - dirshift);
-                    }
-                }
-                h8 ah, al;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    _Float16 h, w;
-                    split16(x[e], &h, &w);
-                    ah[e] = h;
-                    al[e] = w;
-                }
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ct], acc[g][ct], 0, 0, 0);
-                    acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ct], acc[g][ct], 0, 0, 0);
-                    acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ct], acc[g][ct], 0, 0, 0);
-                }
-            }
-        }
-        // second pass: the accumulator tile (rows = lines on registers / lane groups, column on
-        // the lane) is the A operand of a 16x16x16 product that sums over its rows
-#pragma unroll
-        for (int g = 0; g < GRP; ++g) {
-            if (mask[g] == 0) continue;
-            const h4* Gm = Gl + (size_t)(g0 + g) * NJT * 2 * 2 * 64;
-            h4 th[NCT], tw[NCT];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    _Float16 h, w;
-                    split16(acc[g][ct][r] * a.tq_scale, &h, &w);
-                    th[ct][r] = h;
-                    tw[ct][r] = w;
-                }
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
-                const h4 gxh = Gm[((jt * 2 + 0) * 2 + 0) * 64], gxl = Gm[((jt * 2 + 0) * 2 + 1) * 64];
-                const h4 gyh = Gm[((jt * 2 + 1) * 2 + 0) * 64], gyl = Gm[((jt * 2 + 1) * 2 + 1) * 64];
-                P0[jt] = mm16(P0[jt], th[0], tw[0], gxh, gxl);
-                Q0[jt] = mm16(Q0[jt], th[1], tw[1], gyh, gyl);
-                R2x[jt] = mm16(R2x[jt], th[2], tw[2], gxh, gxl);
-                R2y[jt] = mm16(R2y[jt], th[2], tw[2], gyh, gyl);
-            }
-        }
-    }
-
-    write_stamp(P0, Q0, R2x, R2y, lr, lk, a.pre + ((size_t)task * a.nl + l) * NS * NS);
-}
 
 
 // ------------------------------------------------------------------------------------------
@@ -435,6 +285,8 @@ k_otf_mfma(const MfArgs a) {
 constexpr int kMfTiles = 8;                         // m-tiles per sweep over the k-steps
 constexpr int kMfStage = kMfTiles * 4096;           // one staging buffer: 8 x (D 2 KB | log2 tel 2 KB)
 constexpr int kMfLds = 2 * kMfStage + 8 * 6 * 1024; // two staging buffers + one E slab per wave
+constexpr int kMfStageMulti = 52 * 1024;            // several directions: a tile of 25 directions + log2 tel
+constexpr int kMfLdsMulti = 2 * kMfStageMulti + 8 * 6 * 1024;
 
 // one LDS-DMA load: 16 bytes per lane from sbase + voff to lds_dst + 16 lane
 __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
@@ -460,12 +312,9 @@ __device__ __forceinline__ void glds_tile(const void* dbase, const void* tbase, 
         : "v"(voff), "v"(voff16), "s"(dbase), "s"(tbase), "s"(lds_dst)
         : "memory", "scc");
 }
-// x = 2^(c d + t) for two elements, split into fp16 halves: hi = rne(x), lo = rne(x - hi)
+// two elements split into fp16 halves: hi = rne(x), lo = rne(x - hi)
 typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void otf_pair(f2 cc, f2 d, f2 t, unsigned* hi, unsigned* lo) {
-    f2 y;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(cc), "v"(d), "v"(t));
-    const float x0 = __builtin_amdgcn_exp2f(y[0]), x1 = __builtin_amdgcn_exp2f(y[1]);
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned* hi, unsigned* lo) {
     unsigned h;
     float l0, l1;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
@@ -474,10 +323,23 @@ __device__ __forceinline__ void otf_pair(f2 cc, f2 d, f2 t, unsigned* hi, unsign
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(*lo) : "v"(l0), "v"(l1));
     *hi = h;
 }
+// x = 2^(c d + t) for two elements, split
+__device__ __forceinline__ void otf_pair(f2 cc, f2 d, f2 t, unsigned* hi, unsigned* lo) {
+    f2 y;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(cc), "v"(d), "v"(t));
+    split_pair(__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1]), hi, lo);
+}
 
+// MULTI: several directions.  A staged tile is then ndir x D | log2 tel ((ndir + 1) x 2 KB), a sweep
+// takes as many m-tiles as fit the staging buffer (tpg: three at four directions, one at nine), and
+// the OTF tile costs ndir exponentials per element -- the vector pipe, not the loads, sets the pace.
+template <bool MULTI>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_otf_mfma1(const MfArgs a, int per, int ngr) {
+k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
     constexpr int GRP = kMfTiles;
+    const int ndir = MULTI ? a.ndir : 1;
+    const int tile_bytes = (ndir + 1) * 2048;
+    constexpr int STAGE = MULTI ? kMfStageMulti : kMfStage;
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.N, H1 = N / 2 + 1, nks = mf_nks(N), nmt_all = mf_nmt(N);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -518,8 +380,8 @@ k_otf_mfma1(const MfArgs a, int per, int ngr) {
     const int nmt = lv ? (nv + MTL - 1) / MTL : 0, nmtu = (nvu + MTL - 1) / MTL;
 
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    unsigned char* slab = smem + 2 * kMfStage + wave * 6 * 1024;
-    const unsigned slab_lds = lds0 + 2 * kMfStage + (unsigned)wave * 6 * 1024;
+    unsigned char* slab = smem + 2 * STAGE + wave * 6 * 1024;
+    const unsigned slab_lds = lds0 + 2 * STAGE + (unsigned)wave * 6 * 1024;
 
     f4 P0[NJT], Q0[NJT], R2x[NJT], R2y[NJT];
 #pragma unroll
@@ -533,7 +395,11 @@ k_otf_mfma1(const MfArgs a, int per, int ngr) {
     // the last m-tile read the zeroed padding behind D (log2 tel = -inf there).
     const unsigned voff = (unsigned)(((size_t)lr * N + 8 * lk) * sizeof(float)), voff16 = voff + 16;
     const unsigned voffb = (unsigned)lane * 16;
-    const char* dtask = reinterpret_cast<const char*>(a.D0t + (size_t)task * H1 * N);
+    const char* dtask = reinterpret_cast<const char*>(a.D0t + (size_t)task * ndir * H1 * N);
+    const size_t dstride = (size_t)H1 * N * sizeof(float);       // one direction of D
+    float dirshift = 0.f;                      // several directions: their sum <= 2^dirshift
+    while ((1 << (int)dirshift) < ndir) dirshift += 1.f;
+    const f2 dsh = {dirshift, dirshift};
     const char* ttab = reinterpret_cast<const char*>(a.tl2);
     const char* etab = reinterpret_cast<const char*>(a.E + (size_t)l * nks * NCT * 2 * 64);
     const h4* Gl = a.G + (size_t)l * nmt_all * NJT * 2 * 2 * 64 + lane;
@@ -541,7 +407,7 @@ k_otf_mfma1(const MfArgs a, int per, int ngr) {
     unsigned long long t_kloop = 0, t_pass2 = 0, t_wload = 0, t_wbar = 0, n_iter = 0;
     unsigned mytiles = 0;                  // the tiles of a sweep this wave fetches
     for (int g = wave; g < GRP; g += per) mytiles |= 1u << g;
-    for (int g0 = 0; g0 < nmtu; g0 += GRP) {
+    for (int g0 = 0; g0 < nmtu; g0 += tpg) {
         // which k-steps each m-tile needs: for this wave's wavelength and for the group's longest
         unsigned long long own[GRP], uni[GRP], kown = 0, kuni = 0;
         float dm[GRP], tb[GRP];
@@ -556,7 +422,7 @@ k_otf_mfma1(const MfArgs a, int per, int ngr) {
 #pragma unroll
         for (int g = 0; g < GRP; ++g) {
             const int mt = g0 + g;
-            bool ou = mt < nmtu && lane < nks, oo = mt < nmt && lane < nks;
+            bool ou = g < tpg && mt < nmtu && lane < nks, oo = g < tpg && mt < nmt && lane < nks;
             if (a.dminb != nullptr) {
                 ou = ou && fmaf(c2u, dm[g], tb[g]) > a.thr;
                 oo = oo && fmaf(c2, dm[g], tb[g]) > a.thr;
@@ -575,11 +441,28 @@ k_otf_mfma1(const MfArgs a, int per, int ngr) {
         // stage the tiles of k-step ks (wave w fetches tiles w, w + per, ...) and this wave's E slab
         auto stage = [&](int ks, int buf) {
             if (MPSFR_MF_KNOCK == 1) return;
+            if constexpr (!MULTI) {
 #pragma unroll
-            for (int g = 0; g < GRP; ++g) {
-                if (!((mytiles >> g) & 1) || !((uni[g] >> ks) & 1)) continue;
-                const size_t off = ((size_t)(MTL * (g0 + g)) * N + (size_t)KBL * ks) * sizeof(float);
-                glds_tile(dtask + off, ttab + off, voff, voff16, lds0 + buf * kMfStage + g * 4096);
+                for (int g = 0; g < GRP; ++g) {
+                    if (!((mytiles >> g) & 1) || !((uni[g] >> ks) & 1)) continue;
+                    const size_t off = ((size_t)(MTL * (g0 + g)) * N + (size_t)KBL * ks) * sizeof(float);
+                    glds_tile(dtask + off, ttab + off, voff, voff16, lds0 + buf * STAGE + g * 4096);
+                }
+            } else {
+                // pieces (tile, direction or log2 tel) of 2 KB, dealt to the waves in turn
+                int piece = 0;
+#pragma unroll
+                for (int g = 0; g < GRP; ++g) {
+                    if (!((uni[g] >> ks) & 1)) continue;          // (uni[g] = 0 for g >= tpg)
+                    const size_t off = ((size_t)(MTL * (g0 + g)) * N + (size_t)KBL * ks) * sizeof(float);
+                    const unsigned dst = lds0 + buf * STAGE + g * tile_bytes;
+                    for (int d = 0; d <= ndir; ++d, ++piece) {
+                        if (piece % per != wave) continue;
+                        const char* src = d < ndir ? dtask + d * dstride + off : ttab + off;
+                        glds16s(src, voff, dst + d * 2048);
+                        glds16s(src, voff16, dst + d * 2048 + 1024);
+                    }
+                }
             }
             if ((kown >> ks) & 1) {
                 const char* Ek = etab + (size_t)ks * NCT * 2 * 1024;
@@ -617,28 +500,53 @@ k_otf_mfma1(const MfArgs a, int per, int ngr) {
                 // the scheduler puts the vector work into the shadow of the MFMAs.  The m-tile of
                 // the products is a compile-time index (the accumulators stay where they are); the
                 // tile that is prepared is a run-time one.  The last tile prepares itself again.
-                const unsigned char* tbuf = smem + buf * kMfStage + lane * 16;
+                const unsigned char* tbuf = smem + buf * STAGE + lane * 16;
                 unsigned gbits = 0;
 #pragma unroll
                 for (int g = 0; g < GRP; ++g) gbits |= (unsigned)((own[g] >> ks) & 1) << g;
                 h8 ah, al;
                 auto prepare = [&](int g) {
-                    const unsigned char* tp = tbuf + g * 4096;
-                    const f4 d0 = *reinterpret_cast<const f4*>(tp);
-                    const f4 d1 = *reinterpret_cast<const f4*>(tp + 1024);
-                    const f4 t0 = *reinterpret_cast<const f4*>(tp + 2048);
-                    const f4 t1 = *reinterpret_cast<const f4*>(tp + 3072);
-                    unsigned hi[4], lo[4];
+                    const unsigned char* tp = tbuf + g * (MULTI ? tile_bytes : 4096);
                     typedef unsigned u4 __attribute__((ext_vector_type(4)));
-                    if (MPSFR_MF_KNOCK == 4) {          // experiment: no OTF arithmetic
-                        ah = __builtin_bit_cast(h8, d0 + t0);
-                        al = __builtin_bit_cast(h8, d1 + t1);
-                        return;
+                    unsigned hi[4], lo[4];
+                    if constexpr (!MULTI) {
+                        const f4 d0 = *reinterpret_cast<const f4*>(tp);
+                        const f4 d1 = *reinterpret_cast<const f4*>(tp + 1024);
+                        const f4 t0 = *reinterpret_cast<const f4*>(tp + 2048);
+                        const f4 t1 = *reinterpret_cast<const f4*>(tp + 3072);
+                        if (MPSFR_MF_KNOCK == 4) {          // experiment: no OTF arithmetic
+                            ah = __builtin_bit_cast(h8, d0 + t0);
+                            al = __builtin_bit_cast(h8, d1 + t1);
+                            return;
+                        }
+                        otf_pair(cc, f2{d0[0], d0[1]}, f2{t0[0], t0[1]}, &hi[0], &lo[0]);
+                        otf_pair(cc, f2{d0[2], d0[3]}, f2{t0[2], t0[3]}, &hi[1], &lo[1]);
+                        otf_pair(cc, f2{d1[0], d1[1]}, f2{t1[0], t1[1]}, &hi[2], &lo[2]);
+                        otf_pair(cc, f2{d1[2], d1[3]}, f2{t1[2], t1[3]}, &hi[3], &lo[3]);
+                    } else {
+                        // x = sum_dir 2^(c D_dir + log2 tel - dirshift): one fma + v_exp_f32 per direction
+                        const f4 t0 = *reinterpret_cast<const f4*>(tp + ndir * 2048);
+                        const f4 t1 = *reinterpret_cast<const f4*>(tp + ndir * 2048 + 1024);
+                        f2 tt[4] = {f2{t0[0], t0[1]} - dsh, f2{t0[2], t0[3]} - dsh, f2{t1[0], t1[1]} - dsh,
+                                    f2{t1[2], t1[3]} - dsh};
+                        float x[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = 0.f;
+                        for (int d = 0; d < ndir; ++d) {
+                            const f4 d0 = *reinterpret_cast<const f4*>(tp + d * 2048);
+                            const f4 d1 = *reinterpret_cast<const f4*>(tp + d * 2048 + 1024);
+                            const f2 dd[4] = {f2{d0[0], d0[1]}, f2{d0[2], d0[3]}, f2{d1[0], d1[1]}, f2{d1[2], d1[3]}};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                f2 y;
+                                asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(cc), "v"(dd[k]), "v"(tt[k]));
+                                x[2 * k] += __builtin_amdgcn_exp2f(y[0]);
+                                x[2 * k + 1] += __builtin_amdgcn_exp2f(y[1]);
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) split_pair(x[2 * k], x[2 * k + 1], &hi[k], &lo[k]);
                     }
-                    otf_pair(cc, f2{d0[0], d0[1]}, f2{t0[0], t0[1]}, &hi[0], &lo[0]);
-                    otf_pair(cc, f2{d0[2], d0[3]}, f2{t0[2], t0[3]}, &hi[1], &lo[1]);
-                    otf_pair(cc, f2{d1[0], d1[1]}, f2{t1[0], t1[1]}, &hi[2], &lo[2]);
-                    otf_pair(cc, f2{d1[2], d1[3]}, f2{t1[2], t1[3]}, &hi[3], &lo[3]);
                     ah = __builtin_bit_cast(h8, u4{hi[0], hi[1], hi[2], hi[3]});
                     al = __builtin_bit_cast(h8, u4{lo[0], lo[1], lo[2], lo[3]});
                 };
@@ -774,17 +682,18 @@ void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const vo
     a.pre = (float*)d_pre;
     a.clk = (unsigned long long*)d_clk;
     a.order = d_order;
+    // wavelength groups of at most eight, as even as possible: one wave per wavelength
+    const int ngr = (nl + 7) / 8, per = (nl + ngr - 1) / ngr;
+    const int per_xcd = (ntask / 8) * ngr + ((ntask % 8) * ngr + 7) / 8;
     if (ndir == 1) {
-        // wavelength groups of at most eight, as even as possible: one wave per wavelength
-        const int ngr = (nl + 7) / 8, per = (nl + ngr - 1) / ngr;
-        allow_smem(k_otf_mfma1, (size_t)kMfLds);
-        const int per_xcd = (ntask / 8) * ngr + ((ntask % 8) * ngr + 7) / 8;
-        hipLaunchKernelGGL(k_otf_mfma1, dim3(8 * per_xcd), dim3(64 * per), kMfLds, s, a, per, ngr);
-        return;
+        allow_smem(k_otf_mfma1<false>, (size_t)kMfLds);
+        hipLaunchKernelGGL(k_otf_mfma1<false>, dim3(8 * per_xcd), dim3(64 * per), kMfLds, s, a, per, ngr, kMfTiles);
+    } else {
+        // a staged tile is ndir x D + log2 tel, 2 KB each: 52 KB at the 25 directions of npsflin = 5
+        const int fit = kMfStageMulti / ((ndir + 1) * 2048), tpg = fit < kMfTiles ? fit : kMfTiles;
+        allow_smem(k_otf_mfma1<true>, (size_t)kMfLdsMulti);
+        hipLaunchKernelGGL(k_otf_mfma1<true>, dim3(8 * per_xcd), dim3(64 * per), kMfLdsMulti, s, a, per, ngr, tpg);
     }
-    const int nwg = ((ntask + 3) / 4) * nl;
-    const int grid = (nwg + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_otf_mfma, dim3(grid), dim3(256), 0, s, a);
 }
 
 }  // namespace mpsfr

@@ -676,11 +676,10 @@ def test_line_pruning_changes_nothing_above_its_bound(api, dim, npl):
     assert vk[1, 0] < 0.25 * nv                          # and most of its half plane is dropped
 
 
-@pytest.mark.parametrize('dim,npl', [(512, 1), (128, 1), (256, 2), (1280, 1)])
+@pytest.mark.parametrize('dim,npl', [(512, 1), (128, 1), (256, 2), (256, 5), (512, 3), (1280, 1)])
 def test_matrix_core_stage_against_the_fft_stage(api, dim, npl):
     """Mixed mode has two implementations of the per-wavelength stage: split-fp16 contractions on
-    the matrix cores (default for one direction; option otf_mfma_ndir for several) and LDS FFTs
-    (otf_mfma = 0).  Both are pinned to the oracle elsewhere; here they must agree with each other
+    the matrix cores (default) and LDS FFTs (otf_mfma = 0).  Both are pinned to the oracle elsewhere; here they must agree with each other
     at fp32 level on stamps and fits, with and without pruning, and the work the matrix-core stage
     reports must shrink with the pruning."""
     see, gl, l0 = api.synthetic_rows(6)
@@ -689,8 +688,7 @@ def test_matrix_core_stage_against_the_fft_stage(api, dim, npl):
     ps = api.grid_pixscale(dim) if dim != 1280 else 0.2
     three = (np.arange(6) % 3 == 1).astype(np.uint8)
     out, work = {}, {}
-    for key, opts in (('fft', {'otf_mfma': 0}), ('mfma', {'otf_mfma_ndir': 1}),
-                      ('mfma_all', {'otf_mfma_ndir': 1, 'prune_eps': 0.0})):
+    for key, opts in (('fft', {'otf_mfma': 0}), ('mfma', {}), ('mfma_all', {'prune_eps': 0.0})):
         ctx = api.Context(dim=dim, pixscale=ps, precision='mixed')
         for k, v in opts.items():
             ctx.set_option(k, v)
