@@ -490,8 +490,10 @@ def main():
                       'f64 PSD->structure function, f32 per-lambda OTF/FFT, f64 fit') if mixed else 'f64',
             'data': 'synthetic',
             'config': {'workload': '%d synthetic SPARTA rows/GPU x %d lambda (%.0f-%.0f nm), '
-                                   '%d^2 grid, pixscale %.5f, npsflin=%d (BASELINE.json '
-                                   'configs[1])' % (rows, nl, lb[0], lb[-1], dim, ps, a.npsflin),
+                                   '%d^2 grid, pixscale %.5f, npsflin=%d%s' % (
+                                       rows, nl, lb[0], lb[-1], dim, ps, a.npsflin,
+                                       ' (BASELINE.json configs[1])'
+                                       if (rows, nl, dim, a.npsflin) == (100, 35, 512, 1) else ''),
                        'rows_per_gpu': rows, 'nl': nl, 'dim': dim, 'npsflin': a.npsflin,
                        'chunk_tasks': chunk, 'parallelism': 'rows sharded x%d' % world},
             # The dominant kernel is the per-wavelength stage: on the matrix
