@@ -30,7 +30,7 @@ PRIME_STEPS = 64             # untimed, before the warm-up steps
 PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector / fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak (same guide)
 PEAK_HBM_GBPS = 8000.0
-PIPELINE_HAS_TQ = True       # the sampled first-pass lines go through HBM between two kernels
+PIPELINE_HAS_TQ = True       # FFT form of the per-wavelength stage: the sampled first-pass lines go through HBM
 sys.path.insert(0, ROOT)
 
 
