@@ -685,14 +685,18 @@ void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const vo
     // wavelength groups of at most eight, as even as possible: one wave per wavelength
     const int ngr = (nl + 7) / 8, per = (nl + ngr - 1) / ngr;
     const int per_xcd = (ntask / 8) * ngr + ((ntask % 8) * ngr + 7) / 8;
+    // LDS: two staging buffers + one E slab per wave -- no more than the waves there are, so that
+    // a workgroup of another kernel (the other pipeline lane) fits beside it on the CU
     if (ndir == 1) {
+        const size_t sm = 2 * (size_t)kMfStage + (size_t)per * 6 * 1024;
         allow_smem(k_otf_mfma1<false>, (size_t)kMfLds);
-        hipLaunchKernelGGL(k_otf_mfma1<false>, dim3(8 * per_xcd), dim3(64 * per), kMfLds, s, a, per, ngr, kMfTiles);
+        hipLaunchKernelGGL(k_otf_mfma1<false>, dim3(8 * per_xcd), dim3(64 * per), sm, s, a, per, ngr, kMfTiles);
     } else {
         // a staged tile is ndir x D + log2 tel, 2 KB each: 52 KB at the 25 directions of npsflin = 5
         const int fit = kMfStageMulti / ((ndir + 1) * 2048), tpg = fit < kMfTiles ? fit : kMfTiles;
+        const size_t sm = 2 * (size_t)kMfStageMulti + (size_t)per * 6 * 1024;
         allow_smem(k_otf_mfma1<true>, (size_t)kMfLdsMulti);
-        hipLaunchKernelGGL(k_otf_mfma1<true>, dim3(8 * per_xcd), dim3(64 * per), kMfLdsMulti, s, a, per, ngr, tpg);
+        hipLaunchKernelGGL(k_otf_mfma1<true>, dim3(8 * per_xcd), dim3(64 * per), sm, s, a, per, ngr, tpg);
     }
 }
 
