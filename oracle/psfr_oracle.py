@@ -463,3 +463,71 @@ def psf_stamps_restructured(psd, lbda_nm, dimpsf=40, pixscale=0.2):
         st = np.maximum(st, 0)
         out[k] = st / st.sum()
     return out
+
+
+def _split16(x, flush=True):
+    """x = hi + lo in fp16 (round to nearest even), as the matrix-core kernel splits its operands;
+    flush: fp16 subnormals are flushed to zero, as the MFMA inputs are."""
+    x = np.asarray(x, dtype=np.float32)
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    if flush:
+        tiny = np.float16(2.0 ** -14)
+        hi = np.where(np.abs(hi) < tiny, np.float16(0), hi)
+        lo = np.where(np.abs(lo) < tiny, np.float16(0), lo)
+    return hi.astype(np.float32), lo.astype(np.float32)
+
+
+def psf_stamps_contraction_fp16(psd, lbda_nm, dimpsf=40, pixscale=0.2, otf_shift=15, tab_shift=9):
+    """Arithmetic model of the matrix-core per-wavelength kernel (muse_psfr_amd/csrc/otf_mfma.hip):
+    the stamps of psf_stamps_refshaped via the half plane v in [0, N/2], the 21 distinct samples
+    per direction (E_(40-i) = conj E_i, so stamp = P +- Q), fp32 OTF elements 2^(c D + log2 tel),
+    every operand split into two fp16 halves (three products, fp32 accumulation) and scaled by
+    2^otf_shift / 2^tab_shift out of the fp16 subnormal range.  Test infrastructure: documents what
+    precision the split buys (and what an unscaled table costs); the kernel itself is checked
+    against psf_stamps_refshaped on the GPU."""
+    lbda_nm = np.atleast_1d(np.asarray(lbda_nm, dtype=float))
+    if psd.ndim == 2:
+        psd = psd[None]
+    dim = psd.shape[1]
+    nh, ns = dim // 2 + 1, dimpsf // 2 + 1
+    tel = telescope_otf(dim)
+    tel = (tel / tel[0, 0])[:, :nh].T                        # tel[0][0] = 1; transposed half plane [v][u]
+    with np.errstate(divide='ignore'):
+        tl2 = (np.log2(tel) + otf_shift).astype(np.float32)
+    d0 = np.array([structure_function0(p)[:, :nh].T for p in psd]).astype(np.float32)
+    npixc = npix_crop(lbda_nm, dimpsf, pixscale)
+    wv = np.full(nh, 2.0)
+    wv[0] = wv[-1] = 1.0
+    f32 = np.float32
+    lg = int(np.ceil(np.log2(dim)))
+    out = np.zeros((lbda_nm.size, dimpsf, dimpsf))
+    for k, lb in enumerate(lbda_nm):
+        c2 = f32(-0.5 * (2 * np.pi / lb) ** 2 * np.log2(np.e))
+        a = np.exp2(c2 * d0 + tl2[None], dtype=f32).sum(axis=0, dtype=f32)       # [v][u], x 2^otf_shift
+        a = a * f32(2.0 ** -np.ceil(np.log2(psd.shape[0])))
+        S = sample_matrix(dim, npixc[k], dimpsf)[:ns]          # [i][x], W = exp(+2 pi i / N)
+        E = np.conj(S).T * 2.0 ** tab_shift                    # forward kernel along the line: [u][i]
+        G = (S[:, :nh] * wv[None, :]).T * 2.0 ** tab_shift     # conj of the forward kernel: [v][j]
+        ah, al = _split16(a)
+        t = []
+        for part in (E.real, E.imag):                          # first contraction: Tq = OTF . E
+            eh, el = _split16(part)
+            t.append((al @ eh + ah @ el + ah @ eh).astype(f32))
+        scale = f32(2.0 ** -(lg + tab_shift))
+        pq = []
+        for tq, part in zip(t, (G.real, G.imag)):              # second: P = Tx^T Gx, Q = Ty^T Gy
+            th, tw = _split16(tq * scale)
+            gh, gl = _split16(part)
+            pq.append((tw.T @ gh + th.T @ gl + th.T @ gh).astype(f32))
+        P, Q = pq
+        st = np.zeros((dimpsf, dimpsf), f32)
+        ii = np.arange(ns)
+        st[np.ix_(ii, ii)] = P + Q
+        m = np.arange(1, dimpsf // 2)                           # mirrored indices 40 - i
+        st[np.ix_(dimpsf - m, ii)] = (P - Q)[m]
+        st[np.ix_(ii, dimpsf - m)] = (P - Q)[:, m]
+        st[np.ix_(dimpsf - m, dimpsf - m)] = (P + Q)[np.ix_(m, m)]
+        st = np.maximum(st, 0)
+        out[k] = st / st.sum(dtype=np.float64)
+    return out

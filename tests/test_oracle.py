@@ -61,6 +61,26 @@ def test_native_grid_against_reference(golden, ref_masks, run):
     assert rel_err(fin, g['fin_%d' % run][sel]) < 1e-12
 
 
+@pytest.mark.parametrize('dim,npl', [(128, 1), (128, 3), (256, 1)])
+def test_split_fp16_contraction_model(dim, npl):
+    """The identities and the arithmetic the matrix-core kernel rests on (otf_mfma.hip), on the CPU:
+    stamps from the half plane and the 21 distinct samples per direction (P +- Q), every operand as
+    two fp16 halves with fp32 accumulation.  Scaled out of the fp16 subnormal range the model sits
+    at fp32 level against the reference-shaped oracle; with the tables unscaled (low halves flushed
+    by the matrix cores) it is an order of magnitude worse -- the trap DESIGN.md section 7 records."""
+    ps = 0.2 * dim / 1344
+    lb = np.array([480.0, 700.0, 925.0])
+    psd = O.residual_psd([0.7, 0.3], H, 0.6, 25.0, npl, dim, False)
+    ref = O.psf_stamps_refshaped(psd, lb, 40, ps)
+    peak = ref.max(axis=(1, 2), keepdims=True)
+    good = O.psf_stamps_contraction_fp16(psd, lb, 40, ps)
+    bad = O.psf_stamps_contraction_fp16(psd, lb, 40, ps, otf_shift=11, tab_shift=0)
+    eg, eb = (np.abs(good - ref) / peak).max(), (np.abs(bad - ref) / peak).max()
+    assert eg < 3e-6, eg
+    assert eb > 5 * eg, (eg, eb)
+    np.testing.assert_allclose(good.sum(axis=(1, 2)), 1.0, rtol=1e-6)
+
+
 def test_fit_oracle_reproduces_the_reference_known_answers(golden):
     """test_psfrec.py:121-127: LBDA 5000 7000 9000 / FWHM 0.85 0.73 0.62 / BETA 2.73 2.55 2.23 for
     (seeing 1.0, GL 0.7, L0 25), printed with two decimals; centre 20 (test_psfrec.py:28)."""
