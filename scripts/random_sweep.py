@@ -1,0 +1,37 @@
+"""One-off soak of the mixed path against the f64 path on random shapes (the logic of
+tests/test_gpu_random.py over many more seeds, incl. the larger grids).  usage: random_sweep.py N0 N1"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import muse_psfr_amd as api
+H = (100, 10000)
+bad = 0
+for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    rng = np.random.default_rng(9000 + seed)
+    dim = int(rng.choice([128, 256, 256, 512, 512, 1024, 1280]))
+    nl = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 13, 16, 17, 35]))
+    ntask = int(rng.integers(1, 30 if dim <= 512 else 8))
+    npl = int(rng.choice([1, 1, 1, 2, 3, 4, 5])) if dim <= 512 else int(rng.choice([1, 1, 2]))
+    ps = api.grid_pixscale(dim) if dim != 1280 else 0.2
+    lo = 470.0 if dim != 1280 else 490.0
+    lb = np.sort(rng.uniform(lo, 930.0, nl))
+    see = rng.uniform(0.4, 1.4, ntask); gl = rng.uniform(0.1, 0.95, ntask); l0 = rng.uniform(8.0, 40.0, ntask)
+    three = (rng.random(ntask) < 0.3).astype(np.uint8)
+    out = {}
+    for key, prec, opts in (('f64', 'f64', {}), ('mixed', 'mixed', {}),
+                            ('chunked', 'mixed', {'chunk_tasks': int(rng.integers(1, 8)), 'streams': 2})):
+        ctx = api.Context(dim=dim, pixscale=ps, precision=prec)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        out[key] = ctx.reconstruct(lb, see, gl, l0, three, H, npsflin=npl)
+        ctx.close()
+    a, b = out['mixed'], out['f64']
+    peak = b['psf'].max(axis=(2, 3), keepdims=True)
+    e = (np.abs(a['psf'] - b['psf']) / peak).max()
+    same = np.array_equal(out['chunked']['psf'], a['psf']) and np.array_equal(out['chunked']['fit'], a['fit'])
+    ok = e < 2e-5 and same and np.isfinite(a['psf']).all()
+    bad += not ok
+    print('%3d dim %4d nl %2d ntask %2d npl %d  stamp err %.1e  chunk-invariant %s %s' % (
+        seed, dim, nl, ntask, npl, e, same, '' if ok else '<-- FAIL'), flush=True)
+print('failures:', bad)
+sys.exit(1 if bad else 0)
