@@ -4,7 +4,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from muse_psfr_amd import Context, grid_pixscale
 from muse_psfr_amd.synthetic import synthetic_rows
-dim, rows, nl = 512, 100, 35
+dim, rows, nl = int(os.environ.get('MF_DIM', 512)), 100, 35
+npl = int(os.environ.get('MF_NPL', 1))
 see, gl, l0 = synthetic_rows(rows)
 lb = np.linspace(465, 930, nl)
 ctx = Context(dim=dim, pixscale=grid_pixscale(dim), precision='mixed')
@@ -14,7 +15,7 @@ eps = float(sys.argv[1]) if len(sys.argv) > 1 else None
 if eps is not None:
     ctx.set_option('prune_eps', eps)
 for _ in range(3):
-    r = ctx.reconstruct(lb, see, gl, l0, np.zeros(rows, np.uint8), (100, 10000))
+    r = ctx.reconstruct(lb, see, gl, l0, np.zeros(rows, np.uint8), (100, 10000), npsflin=npl)
 nwg = 520
 c = ctx.debug_fetch('mf_clock', (nwg, 8, 8))
 cc = c[:, :7, :]
