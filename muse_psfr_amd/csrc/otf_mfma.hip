@@ -450,14 +450,16 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
                 }
             } else {
                 // pieces (tile, direction or log2 tel) of 2 KB, dealt to the waves in turn
-                int piece = 0;
+                int turn = 0;                                    // whose piece it is (no division)
 #pragma unroll
                 for (int g = 0; g < GRP; ++g) {
                     if (!((uni[g] >> ks) & 1)) continue;          // (uni[g] = 0 for g >= tpg)
                     const size_t off = ((size_t)(MTL * (g0 + g)) * N + (size_t)KBL * ks) * sizeof(float);
                     const unsigned dst = lds0 + buf * STAGE + g * tile_bytes;
-                    for (int d = 0; d <= ndir; ++d, ++piece) {
-                        if (piece % per != wave) continue;
+                    for (int d = 0; d <= ndir; ++d) {
+                        const bool mine = turn == wave;
+                        turn = turn + 1 == per ? 0 : turn + 1;
+                        if (!mine) continue;
                         const char* src = d < ndir ? dtask + d * dstride + off : ttab + off;
                         glds16s(src, voff, dst + d * 2048);
                         glds16s(src, voff16, dst + d * 2048 + 1024);
@@ -532,9 +534,8 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
                         float x[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) x[e] = 0.f;
-                        for (int d = 0; d < ndir; ++d) {
-                            const f4 d0 = *reinterpret_cast<const f4*>(tp + d * 2048);
-                            const f4 d1 = *reinterpret_cast<const f4*>(tp + d * 2048 + 1024);
+                        // two directions per turn: their LDS reads and exp chains overlap
+                        auto add_dir = [&](const f4& d0, const f4& d1) {
                             const f2 dd[4] = {f2{d0[0], d0[1]}, f2{d0[2], d0[3]}, f2{d1[0], d1[1]}, f2{d1[2], d1[3]}};
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
@@ -543,7 +544,19 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
                                 x[2 * k] += __builtin_amdgcn_exp2f(y[0]);
                                 x[2 * k + 1] += __builtin_amdgcn_exp2f(y[1]);
                             }
+                        };
+                        int d = 0;
+                        for (; d + 1 < ndir; d += 2) {
+                            const f4 a0 = *reinterpret_cast<const f4*>(tp + d * 2048);
+                            const f4 a1 = *reinterpret_cast<const f4*>(tp + d * 2048 + 1024);
+                            const f4 b0 = *reinterpret_cast<const f4*>(tp + d * 2048 + 2048);
+                            const f4 b1 = *reinterpret_cast<const f4*>(tp + d * 2048 + 3072);
+                            add_dir(a0, a1);
+                            add_dir(b0, b1);
                         }
+                        if (d < ndir)
+                            add_dir(*reinterpret_cast<const f4*>(tp + d * 2048),
+                                    *reinterpret_cast<const f4*>(tp + d * 2048 + 1024));
 #pragma unroll
                         for (int k = 0; k < 4; ++k) split_pair(x[2 * k], x[2 * k + 1], &hi[k], &lo[k]);
                     }
@@ -603,10 +616,12 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
 #pragma unroll
                     for (int hl = 0; hl < 2; ++hl) gq[jt][xy][hl] = Gm[((jt * 2 + xy) * 2 + hl) * 64];
         };
-        if (tbits != 0) fetch_g(__builtin_ctz(tbits));
+        // (several directions: the registers of the prefetch are what the kernel spills without)
+        if (!MULTI && tbits != 0) fetch_g(__builtin_ctz(tbits));
 #pragma unroll
         for (int g2 = 0; g2 < GRP; ++g2) {
             if (!((tbits >> g2) & 1)) continue;
+            if constexpr (MULTI) fetch_g(g2);
             h4 gc[NJT][2][2];
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt)
@@ -614,8 +629,10 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
                 for (int xy = 0; xy < 2; ++xy)
 #pragma unroll
                     for (int hl = 0; hl < 2; ++hl) gc[jt][xy][hl] = gq[jt][xy][hl];
-            const unsigned later = tbits & ~((2u << g2) - 1u);
-            fetch_g(later != 0 ? __builtin_ctz(later) : g2);
+            if constexpr (!MULTI) {
+                const unsigned later = tbits & ~((2u << g2) - 1u);
+                fetch_g(later != 0 ? __builtin_ctz(later) : g2);
+            }
             h4 th[NCT], tw[NCT];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
