@@ -404,7 +404,7 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
     const char* etab = reinterpret_cast<const char*>(a.E + (size_t)l * nks * NCT * 2 * 64);
     const h4* Gl = a.G + (size_t)l * nmt_all * NJT * 2 * 2 * 64 + lane;
 
-    unsigned long long t_kloop = 0, t_pass2 = 0, t_wload = 0, t_wbar = 0, n_iter = 0;
+    unsigned long long t_kloop = 0, t_pass2 = 0, t_wload = 0, t_wbar = 0, n_iter = 0, t_issue = 0, t_comp = 0;
     unsigned mytiles = 0;                  // the tiles of a sweep this wave fetches
     for (int g = wave; g < GRP; g += per) mytiles |= 1u << g;
     for (int g0 = 0; g0 < nmtu; g0 += tpg) {
@@ -484,6 +484,7 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
             const int ks = __builtin_ctzll(rest);
             rest &= rest - 1;
             const bool mine = (kown >> ks) & 1;
+            const unsigned long long ti0 = clk != nullptr ? __builtin_readcyclecounter() : 0;
             h8 bh[NCT], bl[NCT];
             if (mine) {
 #pragma unroll
@@ -495,6 +496,7 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             if (rest != 0) stage(__builtin_ctzll(rest), buf ^ 1);
+            const unsigned long long ti1 = clk != nullptr ? __builtin_readcyclecounter() : 0;
             if (mine) {
                 // The tile steps of the k-step, software pipelined inside the wave: the operands of
                 // the NEXT tile the wave needs are read from LDS and turned into the fp16 halves of
@@ -587,6 +589,7 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
             }
             // the next k-step's tiles have landed, and nobody reads this k-step's any more
             const unsigned long long tw0 = clk != nullptr ? __builtin_readcyclecounter() : 0;
+            if (clk != nullptr) { t_issue += ti1 - ti0; t_comp += tw0 - ti1; }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             const unsigned long long tw1 = clk != nullptr ? __builtin_readcyclecounter() : 0;
             __builtin_amdgcn_s_barrier();
@@ -657,7 +660,7 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
         }
     }
     MF_STAMP(4);
-    if (clk != nullptr) { clk[6] = t_kloop; clk[7] = t_pass2; clk[1] = t_wload; clk[2] = t_wbar; clk[3] = n_iter; }
+    if (clk != nullptr) { clk[6] = t_kloop; clk[7] = t_pass2; clk[1] = t_wload; clk[2] = t_wbar; clk[3] = n_iter; clk[0] = t_issue; clk[4] = t_comp; }
     if (lv) write_stamp(P0, Q0, R2x, R2y, lr, lk, a.pre + ((size_t)task * a.nl + l) * NS * NS);
     MF_STAMP(5);
 #undef MF_STAMP

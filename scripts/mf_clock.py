@@ -28,6 +28,7 @@ for i, name in enumerate(('masks', 'first stage+barrier', 'k-loop', 'second pass
     print('%-22s mean %8.0f  max %8.0f' % (name, d[:, i].mean(), d[:, i].max()))
 print('all groups: k-loops mean %.0f max %.0f | second passes mean %.0f max %.0f' % (cc[ok][:, 6].mean(), cc[ok][:, 6].max(), cc[ok][:, 7].mean(), cc[ok][:, 7].max()))
 print('in the k-loops: wait for loads mean %.0f | wait at the barrier mean %.0f | iterations mean %.1f' % (cc[ok][:, 1].mean(), cc[ok][:, 2].mean(), cc[ok][:, 3].mean()))
+print('in the k-loops: slab read + staging issue mean %.0f | tile steps mean %.0f' % (cc[ok][:, 0].mean(), cc[ok][:, 4].mean()))
 print('start spread: p50 %.0f p90 %.0f max %.0f' % tuple(np.percentile(c[ok][:, 0] - t0, [50, 90, 100])))
 print('wave total: mean %.0f max %.0f' % ((c[ok][:, 5] - c[ok][:, 0]).mean(), (c[ok][:, 5] - c[ok][:, 0]).max()))
 ctx.close()
