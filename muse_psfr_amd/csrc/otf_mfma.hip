@@ -279,6 +279,16 @@ struct MfArgs {
 // A wave owns its stamp from the OTF to the normalised 40 x 40 pixels: no inter-wave reduction,
 // results bit-identical for any chunking or lane count.
 // ------------------------------------------------------------------------------------------
+#ifndef MPSFR_MF_BASE_NOP
+#define MPSFR_MF_BASE_NOP 4      // s_nop N between scalar address arithmetic and the load that reads it
+#endif
+#ifndef MF_XSTR
+#define MF_STR(x_) #x_
+#define MF_XSTR(x_) MF_STR(x_)
+#endif
+#ifndef MPSFR_MF_CLOCK
+#define MPSFR_MF_CLOCK 0
+#endif
 #ifndef MPSFR_MF_KNOCK
 #define MPSFR_MF_KNOCK 0         // kernel experiments: 1 = no loads, 2 = loads only, 3 = no products, 4 = no OTF arithmetic
 #endif
@@ -288,11 +298,17 @@ constexpr int kMfLds = 2 * kMfStage + 8 * 6 * 1024; // two staging buffers + one
 constexpr int kMfStageMulti = 52 * 1024;            // several directions: a tile of 25 directions + log2 tel
 constexpr int kMfLdsMulti = 2 * kMfStageMulti + 8 * 6 * 1024;
 
+// Wait states of the inline-asm statements below (hipcc pads nothing inside an asm string and
+// does not know what the string reads): an SGPR written by a scalar ALU instruction needs five wait
+// states before a vector-memory instruction reads it as its base -- the bases here come straight from
+// scalar address arithmetic, so every load statement opens with s_nop 4 -- and M0 needs one before
+// the LDS-DMA that uses it.  (A version without the s_nop 4 passed every test until an unrelated
+// edit moved the address arithmetic next to the statement: stamps off by 1e-5, no fault.)
 // one LDS-DMA load: 16 bytes per lane from sbase + voff to lds_dst + 16 lane
 __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        "s_nop " MF_XSTR(MPSFR_MF_BASE_NOP) "\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
@@ -302,7 +318,7 @@ __device__ __forceinline__ void glds_tile(const void* dbase, const void* tbase, 
                                           unsigned voff16, unsigned lds_dst) {
     unsigned keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
+        "s_nop " MF_XSTR(MPSFR_MF_BASE_NOP) "\n\ts_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
@@ -312,15 +328,18 @@ __device__ __forceinline__ void glds_tile(const void* dbase, const void* tbase, 
         : "v"(voff), "v"(voff16), "s"(dbase), "s"(tbase), "s"(lds_dst)
         : "memory", "scc");
 }
-// two elements split into fp16 halves: hi = rne(x), lo = rne(x - hi)
+// two elements split into fp16 halves: hi = rne(x), lo = rne(x - hi).  The conversions are the
+// compiler's (v_cvt_pk_f16_f32; it knows the wait states between a vector write and the MFMA that
+// takes it as an operand, and after a transcendental); only the two v_fma_mix_f32, which read the
+// fp16 halves of hi directly, are asm -- a vector instruction between vector instructions.
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned* hi, unsigned* lo) {
-    unsigned h;
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{x0, x1}, h2));
     float l0, l1;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h), "v"(x0));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h), "v"(x1));
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(*lo) : "v"(l0), "v"(l1));
+    *lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{l0, l1}, h2));
     *hi = h;
 }
 // x = 2^(c d + t) for two elements, split
@@ -365,7 +384,10 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
     }
     const int grp = ngr - 1 - gi;
     const int task = a.order != nullptr ? a.order[rank] : rank;
-    unsigned long long* clk = a.clk != nullptr && lane == 0 ? a.clk + ((size_t)blockIdx.x * 8 + wave) * 8 : nullptr;
+    // experiment clock (scripts/mf_clock.py): compiled in with -DMPSFR_MF_CLOCK=1 only -- even untaken,
+    // its lane-0 branches inside the k-loop cost 4 % of the launch
+    unsigned long long* const clk = MPSFR_MF_CLOCK && a.clk != nullptr && lane == 0
+                                        ? a.clk + ((size_t)blockIdx.x * 8 + wave) * 8 : nullptr;
 #define MF_STAMP(i_) if (clk != nullptr) clk[i_] = __builtin_readcyclecounter()
     MF_STAMP(0);
     const int lmax = min(a.nl - 1, grp * per + per - 1);  // the group's longest wavelength

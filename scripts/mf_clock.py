@@ -1,4 +1,7 @@
-"""Phase time stamps of the matrix-core per-wavelength kernel (one launch, bench workload)."""
+"""Phase time stamps of the matrix-core per-wavelength kernel (one launch, bench workload).
+Needs a library built with the clock compiled in:
+    python scripts/variants.py build clock=-DMPSFR_MF_CLOCK=1      (here)
+    MPSFR_LIB_PATH=variants/clock.so python scripts/mf_clock.py [prune_eps]      (on the GPU box)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
