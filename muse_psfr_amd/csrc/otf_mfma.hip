@@ -16,11 +16,13 @@
 // store path; a dense contraction also prunes in BOTH directions (blocks of 16 lines x 32 columns
 // whose elements are all below the bound are never generated), which an FFT cannot.
 //
-// One wavefront owns one (task, wavelength): no LDS, no barrier, no inter-wave reduction; the
-// result is bit-identical for any chunking or lane count.  The OTF tile is generated in registers
-// in the A-operand layout (one fma + v_exp_f32 per element), the E / G tables are pre-split fp16 in
-// the B-operand layout (cached per wavelength set), and the accumulator tile of the first pass
-// is, as it stands, the A operand of the second (its rows are the contraction index).
+// One wavefront owns one stamp from the OTF to the normalised 40 x 40 pixels: no inter-wave
+// reduction, results bit-identical for any chunking or lane count.  The OTF tile is generated in
+// registers in the A-operand layout (one fma + v_exp_f32 per element and direction), the E / G
+// tables are pre-split fp16 in the B-operand layout (cached per wavelength set), and the
+// accumulator tile of the first pass is, as it stands, the A operand of the second (its rows are
+// the contraction index).  A workgroup is one task and up to eight wavelengths, which share the
+// D | log2 tel tiles through LDS (K_OTF_MFMA1 below).
 #include "device_common.h"
 
 namespace mpsfr {
@@ -258,7 +260,7 @@ struct MfArgs {
 
 
 // ------------------------------------------------------------------------------------------
-// K_OTF_MFMA1: the single-direction kernel.
+// K_OTF_MFMA1: the per-wavelength kernel (MULTI: several directions, see the template comment).
 //
 // What bounds the stage is not the matrix pipe but the vector-memory path of a CU (about 30 B/clk
 // from the L2 in gather-shaped loads): a tile step consumes 4 KB of D and log2 tel and shares a
