@@ -25,7 +25,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-DOMINANT = 'otf_rowfft'      # the kernel the roofline object describes
+DOMINANT = 'otf_rowfft'      # the kernel the roofline object describes (FFT form; 'otf_mfma' on the matrix cores)
 PRIME_STEPS = 64             # untimed, before the warm-up steps
 PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector / fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak (same guide)
@@ -209,6 +209,9 @@ def main():
                 c.set_option('prune_eps', prune_eps)
             if os.environ.get('MPSFR_OTF_MFMA') and precision == 'mixed':     # experiments: 0 = FFT path
                 c.set_option('otf_mfma', int(os.environ['MPSFR_OTF_MFMA']))
+            for key in ('mf_floor', 'mf_kernel', 'mf_permax', 'mf_mid_log2'):      # experiments
+                if os.environ.get('MPSFR_' + key.upper()) and precision == 'mixed':
+                    c.set_option(key, float(os.environ['MPSFR_' + key.upper()]))
             if os.environ.get('MPSFR_PRUNE_FIXED') and precision == 'mixed':
                 c.set_option('prune_fixed', int(os.environ['MPSFR_PRUNE_FIXED']))
             ctxs.append(c)
@@ -315,8 +318,16 @@ def main():
     # Timed region: HIP events only around the dominant kernel (roofline.achieved); bracketing
     # every launch costs ~8 % of a step in event packets, so the per-kernel table comes from a
     # second, untimed pass.
+    # which form of the per-wavelength stage runs: one probing step with every slot timed
     for c in ctxs:
-        c.set_option('profile_only', c.profile_names().index(DOMINANT))
+        c.set_option('profile_only', -1)
+        c.set_option('profile', 1)
+        c.profile_reset()
+    R['step']()
+    R['fence']()
+    dominant = 'otf_mfma' if R['profile_sum']().get('otf_mfma', (0, 0))[1] > 0 else DOMINANT
+    for c in ctxs:
+        c.set_option('profile_only', c.profile_names().index(dominant))
         c.set_option('profile', 1)
     dt, t_enq = R['timed'](a.steps)
     prof = R['profile_sum']()
@@ -365,9 +376,10 @@ def main():
                 ctxs[0].reconstruct_device(lb, see[sp], gl[sp], l0[sp], three[:nprobe], h, 12.0, a.npsflin,
                                            None, None, psm.data_ptr(), pf.data_ptr())
                 ctxs[0].sync()
-            w = ctxs[0].debug_fetch('mf_work', (3,))
+            w = ctxs[0].debug_fetch('mf_work', (5,))
             mf_work = {'tile_steps_per_row': w[0] / nprobe, 'tiles_per_row': w[1] / nprobe,
-                       'tile_steps_unpruned_per_row': w[2] / nprobe}
+                       'tile_steps_unpruned_per_row': w[2] / nprobe,
+                       'full_steps_per_row': w[3] / nprobe, 'mid_steps_per_row': w[4] / nprobe}
         except Exception:       # the FFT kernels ran (several directions, or otf_mfma = 0)
             mf_work = None
     R['close']()
@@ -380,16 +392,17 @@ def main():
         for _ in range(8):
             R4['step']()
         for c in R4['ctxs']:
-            c.set_option('profile_only', c.profile_names().index(DOMINANT))
+            c.set_option('profile_only', c.profile_names().index(dominant))
             c.set_option('profile', 1)
         R4['timed'](40)
-        ms4, n4 = R4['profile_sum']()[DOMINANT]
+        ms4, n4 = R4['profile_sum']()[dominant]
         alone_ms = ms4 / max(n4, 1)
         R4['close']()
 
     # ---- the same workload with every line of the half plane transformed (prune_eps = 0)
     unpruned = None
-    nunp = (max(20, a.steps // 4) if a.unpruned_steps < 0 else a.unpruned_steps) if lines_kept is not None else 0
+    pruned = mixed and a.prune_eps != 0 and not os.environ.get('MPSFR_PRUNE_FIXED')
+    nunp = (max(20, a.steps // 4) if a.unpruned_steps < 0 else a.unpruned_steps) if pruned else 0
     if nunp > 0:
         R3 = make_runner('mixed', max(1, a.inflight), prune_eps=0.0)
         for _ in range(8):
@@ -421,7 +434,7 @@ def main():
     if rank == 0:
         npsf = world * rows * nl * a.steps
         ndir = a.npsflin ** 2
-        ms, nlaunch = prof[DOMINANT]
+        ms, nlaunch = prof[dominant]
         chunk = a.chunk or 'auto'
         units_per_launch = rows * nl * ndir * a.steps / max(nlaunch, 1)
         tasks_per_launch = rows * a.steps / max(nlaunch, 1)
@@ -439,7 +452,9 @@ def main():
             # fraction of the fp32 peak was quoted on.
             steps = mf_work['tile_steps_per_row'] * tasks_per_launch
             tiles = mf_work['tiles_per_row'] * tasks_per_launch
-            flops = steps * 9 * 2 * 16 * 16 * 32 + tiles * 24 * 2 * 16 * 16 * 16
+            # a full tile step is nine MFMA, a mid one (no low half of the OTF: otf_mfma2.hip) six
+            nmfma = (mf_work['full_steps_per_row'] * 9 + mf_work['mid_steps_per_row'] * 6) * tasks_per_launch
+            flops = nmfma * 2 * 16 * 16 * 32 + tiles * 24 * 2 * 16 * 16 * 16
             flops32 = steps * 2 * 16 * 32 * 42 + tiles * 2 * 2 * 16 * 21 * 21
             peak = PEAK_F16_MFMA_TFLOPS
             bound = 'mfma'
@@ -456,13 +471,13 @@ def main():
             flops32 = None
             peak = PEAK_FP32_TFLOPS if mixed else PEAK_FP32_TFLOPS / 2
             bound = 'valu_fp32' if mixed else 'valu_fp64'
-            kernel_name = DOMINANT
+            kernel_name = dominant
             model_txt = ('lines transformed (line pruning: vkeep per row and wavelength pair, of (N/2+1) x '
                          'ceil(nl/2) per row) x 5 N log2 N flops per complex N-point transform; HIP events on '
                          'the launch stream, timed region')
         achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0
         util = (load_json('r02_kernel_util.json') or load_json('r01_kernel_util.json') or {})
-        kkey = 'k_otf_mfma1' if mf_work is not None else 'k_' + DOMINANT
+        kkey = 'k_otf_mfma' if mf_work is not None else 'k_' + dominant
         u = util.get(kkey) if (dim, mixed) == (512, True) else None
         tj = load_json('r02_traffic.json') or load_json('r01_traffic.json')
         traffic = None

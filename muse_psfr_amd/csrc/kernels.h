@@ -54,7 +54,9 @@ enum KernelId {
     K_CONV,
     K_FIT,
     K_STAMP_SUM,
-    K_VKEEP,
+    K_VKEEP,        // FFT path: K_DMIN + K_VKEEP
+    K_OTF_MFMA,     // matrix-core per-wavelength stage (K_OTF_MFMA2 + K_MF_FINISH, or K_OTF_MFMA1)
+    K_MF_PREP,      // its preparation: K_DMIN + K_MF_MASKS + K_MF_SCHED (or K_DMIN + K_VKEEP + K_TASK_ORDER)
     K_COUNT
 };
 
@@ -70,7 +72,9 @@ void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const do
 // Pruning of the per-wavelength stage (stage_a.hip, "Line pruning"): minima of D per line
 // ([ntd][N/2+1]) and per block of 16 lines x 32 columns ([ntd][nmt][N/32]), then the lines to keep
 // per (task, wavelength pair) and the block minima over the directions
-void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk);
+// d_zero: 17 ints the kernel sets to zero (the work-list counters of launch_mf_masks), or nullptr
+void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk,
+                 int* d_zero = nullptr);
 void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax);
 void launch_vkeep(hipStream_t s, int N, int ntask, int ndir, int nl, const LamPar* d_lp,
                   const float* d_dline, const float* d_dblk, const float* d_tlmax, float thr_sum,
@@ -94,6 +98,24 @@ void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const vo
                      const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,
                      const int* d_vkeep, const float* d_dminb, const float* d_tlb, float thr,
                      void* d_pre, const int* d_order = nullptr, void* d_clk = nullptr);
+// Second generation of the matrix-core stage (otf_mfma2.hip, one direction): block masks per
+// (task, wavelength) in two precision tiers, then the thin-wave kernel.  permax: wavelengths per
+// workgroup (8: 16 waves of 128 registers; 6: 12 waves of 168).
+size_t mf2_own_bytes(int N, int ntask, int nl);
+size_t mf2_uni_bytes(int N, int ntask, int nl);
+size_t mf2_sched_bytes(int N, int ntask, int nl);
+size_t mf2_part_bytes(int N, int ntask, int nl);
+void mf2_groups(int nl, int permax, int* per, int* ngr);
+// K_MF_MASKS: block masks and the work lists of launch_otf_mfma2; d_sched[0..16] must be zero
+// (launch_dmin does that)
+void launch_mf_masks(hipStream_t s, int N, int ntask, int nl, int permax, const LamPar* d_lp,
+                     const float* d_dminb, const float* d_tlb, float thr, float thr_mid, void* d_own,
+                     void* d_uni, void* d_sched);
+// K_OTF_MFMA2 (persistent, ncu workgroups) + K_MF_FINISH
+void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int ncu, const void* d_D0t,
+                      const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,
+                      const void* d_own, const void* d_uni, void* d_sched, void* d_part, void* d_pre,
+                      void* d_clk = nullptr);
 void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void* d_tw64,
                    int* d_samp_p, void* d_samp_a, void* d_G, bool f64);
 void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,

@@ -21,6 +21,10 @@ namespace {
 
 thread_local std::string g_err;
 
+// log2 of the smallest OTF element (relative to OTF[0][0] = 1) whose fp16 halves are not flushed by
+// the matrix cores, with a margin for the fp32 rounding of the bound (otf_mfma.hip: kShift = 15)
+constexpr float kMfFloorLog2 = -29.01f;
+
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -41,7 +45,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* kKernelNames[K_COUNT] = {
     "ao_tables", "tel_otf", "psd_rowfft", "dc_sum", "colfft_dphi", "gtable",
-    "moffat_kernels", "otf_rowfft", "colpass", "conv", "fit", "stamp_sum", "vkeep"};
+    "moffat_kernels", "otf_rowfft", "colpass", "conv", "fit", "stamp_sum", "vkeep", "otf_mfma", "mf_prep"};
 
 struct DevBuf {
     void* p = nullptr;
@@ -56,7 +60,7 @@ struct Pending {
 }  // namespace
 
 struct mpsfr_ctx {
-    int device = 0, N = 0, dimpsf = 0, prec = 0;
+    int device = 0, N = 0, dimpsf = 0, prec = 0, ncu = 256;
     double pixscale = 0.2;
     bool f64 = false;
     hipStream_t stream = nullptr;
@@ -69,6 +73,10 @@ struct mpsfr_ctx {
     int prune_fixed = 0;         // experiments: transform exactly this many lines (wrong results)
     double prune_eps = 1.0e-9;   // mixed mode: line pruning of the per-wavelength stage (0 = off)
     bool otf_mfma = true;        // mixed mode: per-wavelength stage on the matrix cores (otf_mfma.hip)
+    bool mf_floor = true;        // matrix-core stage: skip blocks below the fp16 representation floor
+    int mf_kernel = 2;           // 2: thin-wave kernel with precision tiers (otf_mfma2.hip, one direction); 1: otf_mfma.hip
+    int mf_permax = 6;           // wavelengths per workgroup of the thin-wave kernel (6: 12 waves, 8: 16 waves)
+    double mf_mid_log2 = -18.01; // blocks below 2^this need no low half of the OTF (see otf_mfma2.hip)
     bool mf_clock = false;       // experiments: phase time stamps of the matrix-core kernel
     DevBuf mfclk;
     // constant tables
@@ -83,7 +91,7 @@ struct mpsfr_ctx {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;       // after the lane's last chunk of the most recent call
         bool busy = false;               // `done` has been recorded
-        DevBuf C, s00, D0t, Tq, pre, fin, dmin, dblk, vkeep, dminb, order;
+        DevBuf C, s00, D0t, Tq, pre, fin, dmin, dblk, vkeep, dminb, order, mown, muni, msched, mpart;
         const void* outs[3] = {nullptr, nullptr, nullptr};   // device outputs of its latest call
     };
     static constexpr int MAX_LANES = 4;
@@ -129,7 +137,7 @@ struct mpsfr_ctx {
     const void* cache_ao_ptr = nullptr;
     // bookkeeping for debug_fetch
     int last_ndir = 0, last_nl = 0, last_chunk_tasks = 0, last_lane = 0;
-    bool last_mf = false, last_pruned = false;
+    bool last_mf = false, last_pruned = false, last_mf2 = false;
     float last_thr_blk = 0.f;
     std::vector<double> last_lpc;        // c of every wavelength of the last call
     // profiling
@@ -355,6 +363,11 @@ int mpsfr_create(mpsfr_ctx** out, int device_id, int dim, int dimpsf, double pix
     HIPCHK(hipSetDevice(device_id));
     mpsfr_ctx* c = new mpsfr_ctx();
     c->device = device_id;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0)
+            c->ncu = ncu;
+    }
     c->N = dim;
     c->dimpsf = dimpsf;
     c->pixscale = pixscale;
@@ -389,7 +402,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         mpsfr_ctx::Lane& ln = c->lane[k];
         if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
         if (ln.done) (void)hipEventDestroy(ln.done);
-        DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.dmin, &ln.dblk, &ln.vkeep, &ln.dminb, &ln.order};
+        DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.dmin, &ln.dblk, &ln.vkeep, &ln.dminb, &ln.order, &ln.mown, &ln.muni, &ln.msched, &ln.mpart};
         for (auto b : lb) release(*b);
     }
     for (int k = 0; k < mpsfr_ctx::NSTAGE; ++k) {
@@ -426,6 +439,16 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         c->prune_eps = value;
     } else if (!strcmp(key, "otf_mfma")) {
         c->otf_mfma = value != 0.0;
+    } else if (!strcmp(key, "mf_floor")) {
+        c->mf_floor = value != 0.0;
+    } else if (!strcmp(key, "mf_kernel")) {
+        if (value != 1.0 && value != 2.0) return fail(MPSFR_E_INVALID, "mf_kernel must be 1 or 2");
+        c->mf_kernel = (int)value;
+    } else if (!strcmp(key, "mf_permax")) {
+        if (value != (int)value || value < 1.0 || value > 8.0) return fail(MPSFR_E_INVALID, "mf_permax must be 1..8");
+        c->mf_permax = (int)value;
+    } else if (!strcmp(key, "mf_mid_log2")) {
+        c->mf_mid_log2 = value;
     } else if (!strcmp(key, "mf_clock")) {
         c->mf_clock = value != 0.0;
         if (c->mf_clock) {
@@ -661,6 +684,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     if ((rc = ensure(c, c->kmuse, (size_t)nl * ksz))) return rc;
     // per-wavelength stage on the matrix cores (otf_mfma = 0: LDS FFTs on the vector pipe)
     const bool mf = !c->f64 && c->otf_mfma;
+    const bool mf2 = mf && ndir == 1 && c->mf_kernel == 2;      // thin-wave kernel (otf_mfma2.hip)
     const bool r16 = !mf && otf_uses_r16(N, c->f64, nl, ndir);
     if (r16 && (rc = ensure(c, c->xtab, xtab_bytes(nl)))) return rc;
     if (mf) {
@@ -737,8 +761,13 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     // matrix-core path: half of eps for the lines, half for the 16 x 32 blocks inside them (every
     // element of a dropped block is below 2^thr_blk; both half planes, all directions)
     const float thr_sum = prune ? (float)((mf ? 0.5 : 1.0) * c->prune_eps / (2.0 * N * ndir)) : 0.f;
-    const float thr_blk = (prune && mf)
+    float thr_blk = (prune && mf)
         ? (float)std::log2(0.5 * c->prune_eps / (2.0 * ndir * 16 * 32 * mf_block_count(N))) : 0.f;
+    // Representation floor of the split-fp16 operands: the OTF is generated times 2^15, so an element
+    // below 2^-29 of OTF[0][0] has both fp16 halves in the subnormal range, which the matrix cores
+    // flush to zero -- a block whose bound is below 2^-29.01 contributes exactly nothing, and skipping
+    // it changes no bit of the result.
+    if (prune && mf && c->mf_floor && thr_blk < kMfFloorLog2) thr_blk = kMfFloorLog2;
     for (int j = 0; j < NL; ++j) {
         mpsfr_ctx::Lane& ln = lane_of(j);
         // row FFTs of the PSD: only the N/2 + 40 distinct rows are stored (K_PSD_ROWFFT)
@@ -754,6 +783,12 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         if (!mf && (rc = ensure(c, ln.Tq, (size_t)TC * nl * H1 * NSH * 2 * rsize(c)))) return rc;
         if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * (c->f64 ? 8 : 4)))) return rc;
         if ((rc = ensure(c, ln.fin, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
+        if (mf2) {
+            if ((rc = ensure(c, ln.mown, mf2_own_bytes(N, TC, nl)))) return rc;
+            if ((rc = ensure(c, ln.muni, mf2_uni_bytes(N, TC, nl)))) return rc;
+            if ((rc = ensure(c, ln.msched, mf2_sched_bytes(N, TC, nl)))) return rc;
+            if ((rc = ensure(c, ln.mpart, mf2_part_bytes(N, TC, nl)))) return rc;
+        }
         if (prune) {
             if ((rc = ensure(c, ln.dmin, (size_t)TC * ndir * H1 * sizeof(float)))) return rc;
             if ((rc = ensure(c, ln.dblk, (size_t)ndir * mf_dminb_bytes(N, TC)))) return rc;
@@ -808,8 +843,12 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
             launch_colfft_dphi(ls, N, ntd, ln.C.p, (const double*)ln.s00.p, scale2, ln.D0t.p,
                                c->f64, c->tw64.p);
         }
-        if (prune) {
-            ProfScope ps(c, K_VKEEP, ls);
+        if (prune && mf2) {
+            // thin-wave kernel: block minima only (its masks need no line bounds, otf_mfma2.hip)
+            ProfScope ps(c, K_MF_PREP, ls);
+            launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p, (int*)ln.msched.p);
+        } else if (prune) {
+            ProfScope ps(c, mf ? K_MF_PREP : K_VKEEP, ls);
             launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p);
             launch_vkeep(ls, N, tc, ndir, nl, d_lp, (const float*)ln.dmin.p, (const float*)ln.dblk.p,
                          (const float*)c->tlmax.p, thr_sum, (int*)ln.vkeep.p, c->prune_fixed,
@@ -817,8 +856,23 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
             if (mf) launch_task_order(ls, tc, nl, (const int*)ln.vkeep.p, (int*)ln.order.p);
         }
         const int* d_vkeep = prune ? (const int*)ln.vkeep.p : nullptr;
-        if (mf) {
-            ProfScope ps(c, K_OTF_ROWFFT, ls);
+        if (mf2) {
+            {
+                ProfScope ps(c, K_MF_PREP, ls);
+                // (without pruning K_DMIN, which resets the counters of the work list, has not run)
+                if (!prune) HIPCHK(hipMemsetAsync(ln.msched.p, 0, 17 * sizeof(int), ls));
+                // one direction: the block minima of K_DMIN are the minima over the directions
+                launch_mf_masks(ls, N, tc, nl, c->mf_permax, d_lp, prune ? (const float*)ln.dblk.p : nullptr,
+                                (const float*)c->tlb.p, thr_blk,
+                                (prune && c->mf_floor) ? (float)c->mf_mid_log2 : -1.0e30f, ln.mown.p, ln.muni.p,
+                                ln.msched.p);
+            }
+            ProfScope ps(c, K_OTF_MFMA, ls);
+            launch_otf_mfma2(ls, N, tc, nl, c->mf_permax, c->ncu, ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
+                             c->gtab.p, ln.mown.p, ln.muni.p, ln.msched.p, ln.mpart.p, ln.pre.p,
+                             c->mf_clock ? c->mfclk.p : nullptr);
+        } else if (mf) {
+            ProfScope ps(c, K_OTF_MFMA, ls);
             launch_otf_mfma(ls, N, tc, ndir, nl, ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
                             c->gtab.p, d_vkeep, prune ? (const float*)ln.dminb.p : nullptr,
                             (const float*)c->tlb.p, thr_blk, ln.pre.p,
@@ -890,6 +944,7 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     c->last_ndir = ndir;
     c->last_nl = nl;
     c->last_mf = mf;
+    c->last_mf2 = mf2;
     c->last_pruned = prune;
     c->last_thr_blk = thr_blk;
     c->last_lpc.resize(nl);
@@ -970,12 +1025,23 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
         const mpsfr_ctx::Lane& ln = c->lane[c->last_lane];
         std::vector<int> vk((size_t)tc * npair);
         std::vector<float> dm((size_t)tc * nb), tb((size_t)nb);
-        if (c->last_pruned) {
+        if (c->last_pruned && !c->last_mf2) {
             HIPCHK(hipMemcpy(vk.data(), ln.vkeep.p, vk.size() * sizeof(int), hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(dm.data(), ln.dminb.p, dm.size() * sizeof(float), hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(tb.data(), c->tlb.p, tb.size() * sizeof(float), hipMemcpyDeviceToHost));
         }
-        double steps = 0.0, tiles = 0.0;
+        double steps = 0.0, tiles = 0.0, steps_full = 0.0, steps_mid = 0.0;
+        if (c->last_mf2) {          // the masks the thin-wave kernel ran on (K_MF_MASKS)
+            std::vector<unsigned long long> own((size_t)tc * nl * nmt * 2);
+            HIPCHK(hipMemcpy(own.data(), ln.mown.p, own.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < own.size(); i += 2) {
+                const int nf = __builtin_popcountll(own[i]), nm = __builtin_popcountll(own[i + 1]);
+                steps_full += nf;
+                steps_mid += nm;
+                tiles += (nf + nm) > 0;
+            }
+            steps = steps_full + steps_mid;
+        } else {
         for (int t = 0; t < tc; ++t)
             for (int l = 0; l < nl; ++l) {
                 const float c2 = (float)c->last_lpc[l] * 1.44269504088896340736f;
@@ -989,10 +1055,15 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
                     tiles += n > 0;
                 }
             }
+        steps_full = steps;
+        }
         out[0] = steps;
         out[1] = tiles;
         out[2] = (double)tc * nl * nb;
-        return 3;
+        if (capacity < 5) return 3;
+        out[3] = steps_full;         // tile steps with all three products (9 MFMA)
+        out[4] = steps_mid;          // tile steps without the low half of the OTF (6 MFMA)
+        return 5;
     } else if (!strcmp(what, "mf_clock")) {
         if (!c->mfclk.p) return fail(MPSFR_E_INVALID, "mf_clock is off");
         n = capacity < (size_t)65536 * 64 ? capacity : (size_t)65536 * 64;
@@ -1001,7 +1072,9 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
         for (size_t i = 0; i < n; ++i) out[i] = (double)tmp[i];
         return (long)n;
     } else if (!strcmp(what, "vkeep")) {
-        if (c->f64 || !(c->prune_eps > 0.0)) return fail(MPSFR_E_INVALID, "line pruning is off");
+        if (c->f64 || !(c->prune_eps > 0.0) || c->last_mf2)
+            return fail(MPSFR_E_INVALID, "line pruning is off (f64 mode, prune_eps = 0, or the block-masked "
+                                         "matrix-core kernel ran)");
         n = (size_t)c->last_chunk_tasks * ((c->last_nl + 1) / 2);
         if (n > capacity) return fail(MPSFR_E_INVALID, "capacity %zu < %zu", capacity, n);
         std::vector<int> tmp(n);

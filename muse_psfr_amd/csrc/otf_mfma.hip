@@ -23,34 +23,11 @@
 // accumulator tile of the first pass is, as it stands, the A operand of the second (its rows are
 // the contraction index).  A workgroup is one task and up to eight wavelengths, which share the
 // D | log2 tel tiles through LDS (K_OTF_MFMA1 below).
-#include "device_common.h"
+#include "mf_common.h"
 
 namespace mpsfr {
 
 namespace {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-constexpr int MTL = 16;      // lines per m-tile
-constexpr int KBL = 32;      // columns (u) per k-step
-constexpr int NCT = 3;       // column tiles of the first pass: 48 >= 42 real columns
-constexpr int NJT = 2;       // column tiles of the second pass: 32 >= 21
-// The OTF (<= 1) is generated times 2^kShift = 32768: the matrix cores flush fp16 subnormals, so the
-// low half of an element (<= 2^-12 of it) survives down to elements of 2^-14 / 2^-12 / 2^15 = 7.6e-6;
-// smaller ones keep 11 bits (an absolute 2e-9 of the largest).  The first-pass sums, scaled back
-// by the table factors, stay below 2^kShift as well.  The stamp is normalised to sum 1 at the end
-// (psfrec.py:685), so the factor drops out.  (Several directions: the sum over the directions is
-// scaled down by the next power of two, see K_OTF_MFMA.)
-constexpr float kShift = 15.0f;
-// The E and G tables (|E| <= 1, |G| <= 2) are stored times 2^kTabShift for the same reason: the low
-// half of an entry (<= 2^-12 of it) would otherwise sit in the fp16 subnormal range, which the
-// matrix cores flush.
-constexpr int kTabShift = 9;
-
-__host__ __device__ constexpr int mf_nks(int N) { return N / KBL; }
-__host__ __device__ constexpr int mf_nmt(int N) { return (N / 2 + 1 + MTL - 1) / MTL; }
 
 // Column c of the first pass -> (sample i, real / imaginary part); -1 = padding.
 //   tile 0: Re i = 0..15      tile 1: Im i = 0..15      tile 2: c-32 = 0..4 Re 16..20, 8..12 Im 16..20
@@ -61,12 +38,6 @@ __host__ __device__ inline int col_sample(int c, bool* imag) {
     if (r < 5) { *imag = false; return 16 + r; }
     if (r >= 8 && r < 13) { *imag = true; return 16 + r - 8; }
     return -1;
-}
-
-__device__ __forceinline__ void split16(float x, _Float16* hi, _Float16* lo) {
-    const _Float16 h = (_Float16)x;
-    *hi = h;
-    *lo = (_Float16)(x - (float)h);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -174,66 +145,6 @@ k_mf_tel(int N, const float* __restrict__ telT, float* __restrict__ tl2, float* 
     if ((int)threadIdx.x < nks) tlb[mt * nks + threadIdx.x] = __builtin_amdgcn_logf(bmax[threadIdx.x]);
 }
 
-// three fp16 products for one fp32-grade product: c += a b with a = ahi + alo, b = bhi + blo
-__device__ __forceinline__ f4 mm16(f4 c, h4 ahi, h4 alo, h4 bhi, h4 blo) {
-    c = __builtin_amdgcn_mfma_f32_16x16x16f16(alo, bhi, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x16f16(ahi, blo, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(ahi, bhi, c, 0, 0, 0);
-}
-
-// Epilogue of the per-wavelength kernels: the second-pass tiles of one wave -> the 40 x 40 stamp.
-__device__ __forceinline__ void write_stamp(const f4* P0, const f4* Q0, const f4* R2x, const f4* R2y,
-                                            int lr, int lk, float* __restrict__ out) {
-    // Epilogue.  Result tiles: column j = 16 jt + lr on the lane, row 4 lk + r in register r.
-    //   P0 / Q0: rows = samples i = 0..15;  R2x rows 0..4 = P of i = 16..20;  R2y rows 8..12 = Q of
-    //   i = 16..20 (32 lanes away).  stamp[i][j] = P + Q, and with Tq[v][40-i] = conj Tq[v][i],
-    //   G[v][40-j] = conj G[v][j]:  stamp[40-i][j] = stamp[i][40-j] = P - Q,  stamp[40-i][40-j] = P + Q.
-    // Clamp (psfrec.py:680), normalise to sum 1 (:685).
-    float va[2 * NJT * 4], vb[2 * NJT * 4];     // P + Q, P - Q (clamped); first the 0..15 rows
-    float part = 0.f;
-#pragma unroll
-    for (int jt = 0; jt < NJT; ++jt) {
-        const int jj = 16 * jt + lr;
-        const bool jok = jj < NSH;
-        const float mj = (jj >= 1 && jj <= NS / 2 - 1) ? 1.f : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float qhi = __shfl_xor(R2y[jt][r], 32, 64);
-#pragma unroll
-            for (int top = 0; top < 2; ++top) {
-                const int row = 4 * lk + r;
-                const int ii = top ? 16 + row : row;
-                const bool ok = jok && (top ? row < 5 : true);
-                const float Pv = top ? R2x[jt][r] : P0[jt][r];
-                const float Qv = top ? qhi : Q0[jt][r];
-                const float pa = ok ? fmaxf(Pv + Qv, 0.f) : 0.f;
-                const float pb = ok ? fmaxf(Pv - Qv, 0.f) : 0.f;
-                const float mi = (ii >= 1 && ii <= NS / 2 - 1) ? 1.f : 0.f;
-                part += pa * (1.f + mi * mj) + pb * (mi + mj);
-                va[(top * NJT + jt) * 4 + r] = pa;
-                vb[(top * NJT + jt) * 4 + r] = pb;
-            }
-        }
-    }
-    const double tot = wave_sum((double)part);
-    const float inv = (float)(1.0 / tot);
-#pragma unroll
-    for (int top = 0; top < 2; ++top)
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * lk + r, ii = top ? 16 + row : row, jj = 16 * jt + lr;
-                if (jj >= NSH || (top && row >= 5)) continue;
-                const float pa = va[(top * NJT + jt) * 4 + r] * inv, pb = vb[(top * NJT + jt) * 4 + r] * inv;
-                const bool mi = ii >= 1 && ii <= NS / 2 - 1, mj = jj >= 1 && jj <= NS / 2 - 1;
-                out[ii * NS + jj] = pa;
-                if (mi) out[(NS - ii) * NS + jj] = pb;
-                if (mj) out[ii * NS + NS - jj] = pb;
-                if (mi && mj) out[(NS - ii) * NS + NS - jj] = pa;
-            }
-}
-
 // ------------------------------------------------------------------------------------------
 // Pruning of K_OTF_MFMA1.  vkeep[task][pair] (K_VKEEP, stage_a.hip) bounds the lines; inside them
 // a block of 16 lines x 32 columns is generated only if  2^(c' dminb + tlb) > 2^thr,  dminb the
@@ -281,13 +192,6 @@ struct MfArgs {
 // A wave owns its stamp from the OTF to the normalised 40 x 40 pixels: no inter-wave reduction,
 // results bit-identical for any chunking or lane count.
 // ------------------------------------------------------------------------------------------
-#ifndef MPSFR_MF_BASE_NOP
-#define MPSFR_MF_BASE_NOP 4      // s_nop N between scalar address arithmetic and the load that reads it
-#endif
-#ifndef MF_XSTR
-#define MF_STR(x_) #x_
-#define MF_XSTR(x_) MF_STR(x_)
-#endif
 #ifndef MPSFR_MF_CLOCK
 #define MPSFR_MF_CLOCK 0
 #endif
@@ -300,50 +204,6 @@ constexpr int kMfLds = 2 * kMfStage + 8 * 6 * 1024; // two staging buffers + one
 constexpr int kMfStageMulti = 52 * 1024;            // several directions: a tile of 25 directions + log2 tel
 constexpr int kMfLdsMulti = 2 * kMfStageMulti + 8 * 6 * 1024;
 
-// Wait states of the inline-asm statements below (hipcc pads nothing inside an asm string and
-// does not know what the string reads): an SGPR written by a scalar ALU instruction needs five wait
-// states before a vector-memory instruction reads it as its base -- the bases here come straight from
-// scalar address arithmetic, so every load statement opens with s_nop 4 -- and M0 needs one before
-// the LDS-DMA that uses it.  (A version without the s_nop 4 passed every test until an unrelated
-// edit moved the address arithmetic next to the statement: stamps off by 1e-5, no fault.)
-// one LDS-DMA load: 16 bytes per lane from sbase + voff to lds_dst + 16 lane
-__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_nop " MF_XSTR(MPSFR_MF_BASE_NOP) "\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_dst)
-        : "memory");
-}
-// the four loads of a tile: D (two halves of the lane's 8 columns), log2 tel (likewise)
-__device__ __forceinline__ void glds_tile(const void* dbase, const void* tbase, unsigned voff,
-                                          unsigned voff16, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_nop " MF_XSTR(MPSFR_MF_BASE_NOP) "\n\ts_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "v"(voff16), "s"(dbase), "s"(tbase), "s"(lds_dst)
-        : "memory", "scc");
-}
-// two elements split into fp16 halves: hi = rne(x), lo = rne(x - hi).  The conversions are the
-// compiler's (v_cvt_pk_f16_f32; it knows the wait states between a vector write and the MFMA that
-// takes it as an operand, and after a transcendental); only the two v_fma_mix_f32, which read the
-// fp16 halves of hi directly, are asm -- a vector instruction between vector instructions.
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned* hi, unsigned* lo) {
-    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{x0, x1}, h2));
-    float l0, l1;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h), "v"(x0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h), "v"(x1));
-    *lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{l0, l1}, h2));
-    *hi = h;
-}
 // x = 2^(c d + t) for two elements, split
 __device__ __forceinline__ void otf_pair(f2 cc, f2 d, f2 t, unsigned* hi, unsigned* lo) {
     f2 y;

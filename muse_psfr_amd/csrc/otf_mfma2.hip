@@ -1,0 +1,683 @@
+// Per-wavelength stage of the mixed-precision path on the matrix cores, second generation
+// (gfx950, wave64).  Reference citations are to /root/reference/muse_psfr/psfrec.py.
+//
+// Same contraction as otf_mfma.hip:
+//     stamp[i][j] = sum_v sum_u  G[v][j] * OTF[v][u] * E[u][i]              (psfrec.py:672-685, 793-801)
+// with OTF[v][u] = tel[v][u] 2^(c D[v][u]) generated in registers in the A-operand layout, the E / G
+// tables of K_MF_TABLES as B operands, split-fp16 products with fp32 accumulation.  What is new:
+//
+//  * Precision tiers per block of 16 lines x 32 columns, decided from the same bound as the block
+//    pruning (every element of the block is below 2^(c' dmin + log2 telmax)):
+//      - below 2^-29 of OTF[0][0] both fp16 halves of every element are subnormal (the OTF is
+//        generated times 2^15) and the matrix cores flush them: the block contributes exactly
+//        nothing and is dropped;
+//      - below 2^-18 the LOW half of every element is subnormal: its product with the table is
+//        exactly zero, so the block needs two of the three products and no low half ("mid" blocks:
+//        6 MFMA and 16 vector instructions per tile step instead of 9 and 28);
+//      - above, the full three products.
+//    All three are bit-for-bit what the full products would give.
+//  * The masks (which blocks a wavelength keeps, in which tier; which blocks a wavelength group
+//    stages) are computed once per (task, wavelength) by K_MF_MASKS instead of by every wave, and
+//    the group's staging mask is the exact union of its members (no assumption on the order of
+//    the wavelengths).
+//  * Thin waves: a workgroup still shares the D | log2 tel tiles of a k-step through LDS between
+//    the up to eight wavelengths of a group, but every wavelength has TWO waves, each owning four
+//    of the sweep's eight m-tiles (48 accumulator registers instead of 96).  12-16 waves per CU
+//    instead of 7 hide each other's LDS latency, LDS-DMA issue and barrier waits; the E slab of a
+//    wavelength is fetched once for its two waves (double buffered, so no wave waits for its
+//    partner before the next slab is requested).  The two partial stamps meet in LDS.
+//  * Work items and a queue.  The unit of work is (task, wavelength group, SWEEP of eight m-tiles)
+//    instead of (task, group): the sharpest PSFs keep three sweeps and six times the blocks of the
+//    broadest, and with one workgroup per (task, group) the launch ended on them at twice the
+//    balanced time.  K_MF_MASKS files every non-empty item in one of 16 lists by the number of
+//    blocks it stages; one persistent workgroup per CU takes the items from an atomic counter,
+//    heaviest class first (longest-processing-time-first, to the width of a class).  A (task, group) with one sweep is
+//    finished by its workgroup; with several, every sweep leaves its partial tiles in memory and
+//    K_MF_FINISH adds them in sweep order (fixed order: results do not depend on who ran what).
+#include "mf_common.h"
+
+namespace mpsfr {
+
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr int kT2 = 8;                  // m-tiles staged per sweep over the k-steps
+constexpr int kTW = 4;                  // m-tiles per wave: tiles 2 i + half of the sweep
+constexpr int kStage2 = kT2 * 4096;     // one staging buffer: 8 x (D 2 KB | log2 tel 2 KB)
+constexpr int kSlab = 6 * 1024;         // E slab of one wavelength and k-step: 3 column tiles x (hi | lo)
+
+// ------------------------------------------------------------------------------------------
+// K_MF_MASKS: one workgroup per (task, wavelength group), one wave per wavelength, lane = k-step.
+//   own[task][l][mt][2]   bit ks of word 0: block (mt, ks) is a full block of wavelength l;
+//                         word 1: a mid block (see the file comment)
+//   uni[task][grp][mt]    bit ks: some wavelength of the group keeps the block (what the workgroup
+//                         stages)
+//   ksum[task][l][sw], kuni[task][grp][sw]   the k-steps with work, per sweep of eight m-tiles
+//   gsw[task][grp]        bit sw: the sweep has work
+//   items[cls][]          the work lists of K_OTF_MFMA2: {task, grp, sweep, sweeps of the (task, grp)} of
+//                         every sweep with work, filed by work class (blocks staged / 8, at most 15)
+//                         with one atomic add on the class counter sched[cls].  The order inside a
+//                         class is left to the hardware and changes no result (items are independent).
+// A block is kept if its bound e = c' dmin + log2 telmax is above thr (every element of a dropped
+// block is below 2^thr); it is full if e is above thr_mid.  Without pruning (dminb = nullptr) every
+// block of the half plane is full.  (The line pruning of the FFT path, K_VKEEP, is not needed here:
+// a line it drops consists of blocks this rule drops.)
+// ------------------------------------------------------------------------------------------
+struct MaskArgs {
+    int N, nl, per, ngr;
+    const LamPar* lp;
+    const float* dminb;      // [ntask][nmt][nks] or nullptr
+    const float* tlb;        // [nmt][nks]
+    float thr, thr_mid;
+    u64* own;
+    u64* uni;
+    u64* ksum;
+    u64* kuni;
+    int* gsw;
+    int* sched;              // [0..15] items per work class (zeroed by K_DMIN), [16] queue head of K_OTF_MFMA2
+    int4* items;             // [16][cap]
+    int cap;                 // ntask ngr nsw
+};
+
+__global__ void __launch_bounds__(512) k_mf_masks(const MaskArgs a) {
+    __shared__ u64 s_any[2][8][kT2];                 // [sweep parity][wavelength slot][m-tile of the sweep]
+    const int grp = blockIdx.x, task = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int N = a.N, nks = mf_nks(N), nmt = mf_nmt(N), nsw = (nmt + kT2 - 1) / kT2;
+    const int l = grp * a.per + w;
+    const bool lv = l < a.nl;
+    const int kk = min(lane, nks - 1);
+    const float c2 = (float)a.lp[lv ? l : a.nl - 1].c * 1.44269504088896340736f;
+    float dm[kT2], tb[kT2];
+    auto fetch = [&](int sw) {
+#pragma unroll
+        for (int g = 0; g < kT2; ++g) {
+            const int mt = min(sw * kT2 + g, nmt - 1);
+            dm[g] = a.dminb != nullptr ? a.dminb[((size_t)task * nmt + mt) * nks + kk] : 0.f;
+            tb[g] = a.tlb[mt * nks + kk];
+        }
+    };
+    fetch(0);
+    int sweeps = 0, mywork = 0;                       // (wave 0) lane sw keeps the blocks staged in sweep sw
+    for (int sw = 0; sw < nsw; ++sw) {
+        u64 any[kT2], ks_l = 0;
+#pragma unroll
+        for (int g = 0; g < kT2; ++g) {
+            const int mt = sw * kT2 + g;
+            const float e = fmaf(c2, dm[g], tb[g]);
+            const bool keep = lv && lane < nks && mt < nmt && (a.dminb == nullptr || e > a.thr);
+            const bool full = keep && (a.dminb == nullptr || e > a.thr_mid);
+            const u64 bf = __ballot(full), bm = __ballot(keep && !full);
+            if (lane == 0 && lv && mt < nmt) {
+                u64* o = a.own + (((size_t)task * a.nl + l) * nmt + mt) * 2;
+                o[0] = bf;
+                o[1] = bm;
+            }
+            any[g] = bf | bm;
+            ks_l |= any[g];
+        }
+        if (sw + 1 < nsw) fetch(sw + 1);             // in flight behind the exchange below
+        if (lane == 0) {
+            if (lv) a.ksum[((size_t)task * a.nl + l) * nsw + sw] = ks_l;
+#pragma unroll
+            for (int g = 0; g < kT2; ++g) s_any[sw & 1][w][g] = any[g];
+        }
+        __syncthreads();
+        if (w == 0) {                                // lanes 0..7: the group's union per m-tile
+            u64 u = 0;
+            if (lane < kT2)
+                for (int j = 0; j < a.per; ++j) u |= s_any[sw & 1][j][lane];
+            if (lane < kT2 && sw * kT2 + lane < nmt) a.uni[((size_t)task * a.ngr + grp) * nmt + sw * kT2 + lane] = u;
+            u64 ku = u;
+            int pc = __builtin_popcountll(u);
+#pragma unroll
+            for (int o = 1; o < kT2; o <<= 1) {
+                ku |= __shfl_xor(ku, o, 64);
+                pc += __shfl_xor(pc, o, 64);
+            }
+            if (lane == 0) a.kuni[((size_t)task * a.ngr + grp) * nsw + sw] = ku;
+            if (ku != 0) sweeps |= 1 << sw;          // (uniform over the lanes 0..7)
+            if (lane == sw) mywork = pc;
+        }
+        // (s_any is double buffered by sweep parity: the next sweep writes the other half, and the
+        // one after that comes behind the next barrier)
+    }
+    if (w == 0) {
+        sweeps = __builtin_amdgcn_readfirstlane(sweeps);
+        if (lane == 0) a.gsw[task * a.ngr + grp] = sweeps;
+        if (lane < nsw && ((sweeps >> lane) & 1)) {     // one lane per sweep: the atomics overlap
+            const int cls = min(15, mywork >> 3);
+            const int k = atomicAdd(a.sched + cls, 1);
+            a.items[(size_t)cls * a.cap + k] = make_int4(task, grp, lane, __builtin_popcount(sweeps));
+        }
+    }
+}
+
+// the 64-bit word that lane `src` (wave-uniform) holds, into scalar registers
+__device__ __forceinline__ u64 lane_word(u64 w, int src) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)w, src);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(w >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+
+// two LDS-DMA loads of one staging unit: 16 bytes per lane from sbase + voff / + voff16 to
+// lds_dst + 16 lane / + 1024 + 16 lane (wait states: mf_common.h)
+__device__ __forceinline__ void glds_pair(const void* sbase, unsigned voff, unsigned voff16, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_nop " MF_XSTR(MPSFR_MF_BASE_NOP) "\n\ts_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "v"(voff16), "s"(sbase), "s"(lds_dst)
+        : "memory", "scc");
+}
+
+struct Mf2Args {
+    int N, ntask, nl, per, ngr;
+    const float* D0t;        // [ntask][N/2+1][N] (+ 16 finite padding lines)
+    const float* tl2;        // [nmt 16][N]
+    const LamPar* lp;
+    const h8* E;
+    const h4* G;
+    const u64* own;          // K_MF_MASKS
+    const u64* uni;
+    const u64* ksum;
+    const u64* kuni;
+    int* sched;              // [0..15] items per work class (K_MF_MASKS), [16] queue head
+    const int4* items;       // [16][cap]
+    int cap;
+    f4* part;                // [ntask][nl][nsw][8][64]: partial tiles of (task, group)s with several sweeps
+    unsigned long long* clk; // experiments (-DMPSFR_MF_CLOCK=1): per-wave phase times, or nullptr
+    float tq_scale;          // 2^-ceil(log2 N) 2^-kTabShift: first-pass sums back into the fp16 range
+    float* pre;              // [ntask][nl][40][40]
+};
+
+#ifndef MPSFR_MF2_PKFMA
+#define MPSFR_MF2_PKFMA 0        // 1: v_pk_fma_f32 (inline asm) for the exponent, 0: two v_fma_f32
+#endif
+
+// x = 2^(c d + t) for two elements: the fp16 high halves, and the low halves if `full`
+template <bool FULL>
+__device__ __forceinline__ void otf_pair2(float c, f2 d, f2 t, unsigned* hi, unsigned* lo) {
+#if MPSFR_MF2_PKFMA
+    f2 y;
+    const f2 cc = {c, c};
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(cc), "v"(d), "v"(t));
+    const float x0 = __builtin_amdgcn_exp2f(y[0]), x1 = __builtin_amdgcn_exp2f(y[1]);
+#else
+    const float x0 = __builtin_amdgcn_exp2f(__builtin_fmaf(c, d[0], t[0]));
+    const float x1 = __builtin_amdgcn_exp2f(__builtin_fmaf(c, d[1], t[1]));
+#endif
+    if constexpr (FULL) {
+        split_pair(x0, x1, hi, lo);
+    } else {
+        *hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{x0, x1}, h2));
+    }
+}
+
+#ifndef MPSFR_MF_CLOCK
+#define MPSFR_MF_CLOCK 0
+#endif
+
+// ------------------------------------------------------------------------------------------
+// K_OTF_MFMA2 (one direction).  Persistent workgroups (one per CU) of 2 per waves take items (task,
+// wavelength group of `per` <= 8 wavelengths, sweep of eight m-tiles) from the list of K_MF_MASKS.
+// Wave w < per is the even half (m-tiles 0, 2, 4, 6 of the sweep) of wavelength slot w, wave
+// per + w the odd half.  Per k-step (32 columns) the workgroup stages, by LDS-DMA into the buffer
+// the previous k-step does not read: the D | log2 tel tiles the group's union mask keeps (16 units
+// of 2 KB dealt over the waves) and, per wavelength with work in the k-step, its 6 KB E slab (high
+// halves by the even wave, low halves by the odd one).  One raw s_barrier per k-step hands the
+// buffers over (hipcc does not count asm memory operations: the waits are explicit).
+// WPE = waves per SIMD the register budget is cut for (4: up to 16 waves, 128 registers; 3: up to
+// 12 waves, 168).
+// ------------------------------------------------------------------------------------------
+template <int WPE>
+__global__ void __launch_bounds__(WPE * 256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+k_otf_mfma2(const Mf2Args a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = a.N, H1 = N / 2 + 1, nks = mf_nks(N), nmt_all = mf_nmt(N), nsw = (nmt_all + kT2 - 1) / kT2;
+    const int per = a.per, ngr = a.ngr;
+    const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
+    const int nw = 2 * per;
+    const char* ttab = reinterpret_cast<const char*>(a.tl2);
+    // the item number travels through a word of staging buffer 1, which no load touches before
+    // the first barrier of the k-loop (every wave has read it by then)
+    volatile int* s_item = reinterpret_cast<volatile int*>(smem + kStage2);
+    // the 16 lists as one queue, heaviest class first: item i of the queue is entry i - first[c] of
+    // the class c with first[c] <= i < first[c] + count[c]
+    // (lane c < 16 keeps the bounds of class c)
+    const int ccnt = lane0 < 16 ? a.sched[lane0] : 0;
+    int cfirst = 0, nitems = 0;
+#pragma unroll
+    for (int c = 15; c >= 0; --c) {
+        if (lane0 == c) cfirst = nitems;
+        nitems += __builtin_amdgcn_readlane(ccnt, c);
+    }
+#if MPSFR_MF_CLOCK
+    unsigned long long* const clk = a.clk != nullptr && lane0 == 0 ? a.clk + ((size_t)blockIdx.x * 16 + wave0) * 16 : nullptr;
+    unsigned long long t_kloop = 0, t_stage = 0, t_tiles = 0, t_wload = 0, t_wbar = 0, t_pass2 = 0, t_masks = 0, t_tail = 0;
+    unsigned long long n_ks = 0, n_tiles = 0, n_dma = 0, n_items = 0;
+#define MF2_NOW() __builtin_readcyclecounter()
+    const unsigned long long t_begin = MF2_NOW();
+#else
+#define MF2_NOW() 0ull
+#endif
+
+    for (;;) {
+#if MPSFR_MF_CLOCK
+        const unsigned long long ti0 = MF2_NOW();
+#endif
+        if (threadIdx.x == 0) *s_item = atomicAdd(a.sched + 16, 1);
+        __syncthreads();
+        const int item = __builtin_amdgcn_readfirstlane(*s_item);
+        if (item >= nitems) break;
+        const int cls = __builtin_ctzll(__ballot(lane0 < 16 && item >= cfirst && item < cfirst + ccnt));
+        const int ipos = item - __builtin_amdgcn_readlane(cfirst, cls);
+        // Everything derived from the lane and wave numbers is recomputed per item: hoisted out of
+        // this loop the two dozen addresses and constants live across it and spill (the reloads sat
+        // on the serial path of every item's epilogue).
+        int lane = lane0, wave = wave0;
+        asm volatile("" : "+v"(lane));
+        asm volatile("" : "+s"(wave));
+        const int half = wave >= per ? 1 : 0, slot = wave - half * per;
+        const int lr = lane & 15, lk = lane >> 4;
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+        const unsigned slab_off = 2 * kStage2 + (unsigned)slot * kSlab;      // + buf * per * kSlab
+        // lane part of a tile's addresses (bytes); the rest is wave-uniform.  Lines beyond N/2 of
+        // the last m-tile read the finite padding behind D (log2 tel = -inf there).
+        const unsigned voff = (unsigned)((lr * N + 8 * lk) * sizeof(float)), voff16 = voff + 16;
+        const unsigned voffb = (unsigned)lane * 16;
+        const int4 it = a.items[(size_t)cls * a.cap + ipos];
+        const int task = __builtin_amdgcn_readfirstlane(it.x), grp = __builtin_amdgcn_readfirstlane(it.y);
+        const int sw = __builtin_amdgcn_readfirstlane(it.z), nsweeps = __builtin_amdgcn_readfirstlane(it.w);
+        const int g0 = sw * kT2;
+        const int l = grp * per + slot;
+        const bool lv = l < a.nl;
+        const int lc = lv ? l : a.nl - 1;
+        const float c2 = (float)a.lp[lc].c * 1.44269504088896340736f;
+        const char* dtask = reinterpret_cast<const char*>(a.D0t + (size_t)task * H1 * N);
+        const char* etab = reinterpret_cast<const char*>(a.E + (size_t)lc * nks * NCT * 2 * 64);
+        const h4* Gl = a.G + (size_t)lc * nmt_all * NJT * 2 * 2 * 64 + lane;
+        // The masks of the sweep (K_MF_MASKS) with ONE load instruction: lane 8 k + g holds, for m-tile
+        // g0 + g, the group's staging mask (k = 0), this wavelength's full blocks (1) and mid blocks
+        // (2); lane 24 the k-steps in which the wavelength has work, lane 25 the group's k-steps.
+        u64 mw = 0;
+        {
+            const int g = lane & 7, mt = g0 + g, kind = lane >> 3;
+            const size_t tl_ = (size_t)task * a.nl + lc, tg_ = (size_t)task * ngr + grp;
+            if (kind == 0) { if (mt < nmt_all) mw = a.uni[tg_ * nmt_all + mt]; }
+            else if (kind < 3) { if (mt < nmt_all && lv) mw = a.own[(tl_ * nmt_all + mt) * 2 + kind - 1]; }
+            else if (lane == 24) { if (lv) mw = a.ksum[tl_ * nsw + sw]; }
+            else if (lane == 25) mw = a.kuni[tg_ * nsw + sw];
+        }
+        const u64 kuni = lane_word(mw, 25);            // != 0: K_MF_MASKS lists no empty item
+        const u64 sany = lane_word(mw, 24);
+        u64 of[kTW], om[kTW];              // this wave's tiles 2 i + half: full / mid blocks
+#pragma unroll
+        for (int i = 0; i < kTW; ++i) {
+            of[i] = lane_word(mw, 8 + 2 * i + half);
+            om[i] = lane_word(mw, 16 + 2 * i + half);
+        }
+        f4 acc[kTW][NCT];
+#pragma unroll
+        for (int i = 0; i < kTW; ++i)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[i][ct] = f4{0.f, 0.f, 0.f, 0.f};
+#if MPSFR_MF_CLOCK
+        const unsigned long long tm1 = MF2_NOW();
+        t_masks += tm1 - ti0;
+        n_items += 1;
+#endif
+
+        // This wave's share of the loads of k-step ks, into staging buffer `buf`.  Staging units of a
+        // k-step: unit q = 2 g + kind (kind 0: D of tile g, 1: log2 tel), dealt over the waves from the
+        // top (the waves with a second unit change with `per`).
+        auto stage = [&](int ks, int buf) {
+            const unsigned koff = (unsigned)(KBL * ks) * (unsigned)sizeof(float);
+            for (int q = nw - 1 - wave; q < 2 * kT2; q += nw) {
+                const int g = q >> 1;
+                if (!((lane_word(mw, g) >> ks) & 1)) continue;
+                const unsigned off = (unsigned)(MTL * (g0 + g)) * (unsigned)N * (unsigned)sizeof(float) + koff;
+                glds_pair(((q & 1) ? ttab : dtask) + off, voff, voff16,
+                          lds0 + buf * kStage2 + g * 4096 + (q & 1) * 2048);
+#if MPSFR_MF_CLOCK
+                n_dma += 2;
+#endif
+            }
+            if ((sany >> ks) & 1) {
+                const char* Ek = etab + (unsigned)ks * (NCT * 2 * 1024) + half * 1024;
+                const unsigned dst = lds0 + slab_off + buf * per * kSlab + half * 1024;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) glds16s(Ek + ct * 2048, voffb, dst + ct * 2048);
+#if MPSFR_MF_CLOCK
+                n_dma += 3;
+#endif
+            }
+        };
+        u64 rest = kuni;
+        int buf = 0;
+        stage(__builtin_ctzll(rest), 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#if MPSFR_MF_CLOCK
+        const unsigned long long tk0 = MF2_NOW();
+#endif
+        while (rest != 0) {
+            const int ks = __builtin_ctzll(rest);
+            rest &= rest - 1;
+            unsigned fb = 0, mb = 0;
+#pragma unroll
+            for (int i = 0; i < kTW; ++i) {
+                fb |= (unsigned)((of[i] >> ks) & 1) << i;
+                mb |= (unsigned)((om[i] >> ks) & 1) << i;
+            }
+            const unsigned ab = fb | mb;
+            h8 bh[NCT], bl[NCT];
+            if (ab != 0) {
+                const unsigned char* slab = smem + slab_off + buf * per * kSlab + lane * 16;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    bh[ct] = *reinterpret_cast<const h8*>(slab + (ct * 2) * 1024);
+                    bl[ct] = *reinterpret_cast<const h8*>(slab + (ct * 2 + 1) * 1024);
+                }
+            }
+#if MPSFR_MF_CLOCK
+            const unsigned long long ts0 = MF2_NOW();
+#endif
+            if (rest != 0) stage(__builtin_ctzll(rest), buf ^ 1);
+#if MPSFR_MF_CLOCK
+            const unsigned long long ts1 = MF2_NOW();
+            t_stage += ts1 - ts0;
+            n_ks += 1;
+            n_tiles += __builtin_popcount(ab);
+#endif
+            if (ab != 0) {
+                const unsigned char* tbuf = smem + buf * kStage2 + half * 4096 + lane * 16;
+#pragma unroll
+                for (int i = 0; i < kTW; ++i) {
+                    if (!((ab >> i) & 1)) continue;
+                    const unsigned char* tp = tbuf + i * 8192;
+                    const f4 d0 = *reinterpret_cast<const f4*>(tp);
+                    const f4 d1 = *reinterpret_cast<const f4*>(tp + 1024);
+                    const f4 t0 = *reinterpret_cast<const f4*>(tp + 2048);
+                    const f4 t1 = *reinterpret_cast<const f4*>(tp + 3072);
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    unsigned hi[4], lo[4];
+                    if ((fb >> i) & 1) {
+                        otf_pair2<true>(c2, f2{d0[0], d0[1]}, f2{t0[0], t0[1]}, &hi[0], &lo[0]);
+                        otf_pair2<true>(c2, f2{d0[2], d0[3]}, f2{t0[2], t0[3]}, &hi[1], &lo[1]);
+                        otf_pair2<true>(c2, f2{d1[0], d1[1]}, f2{t1[0], t1[1]}, &hi[2], &lo[2]);
+                        otf_pair2<true>(c2, f2{d1[2], d1[3]}, f2{t1[2], t1[3]}, &hi[3], &lo[3]);
+                        const h8 ah = __builtin_bit_cast(h8, u4{hi[0], hi[1], hi[2], hi[3]});
+                        const h8 al = __builtin_bit_cast(h8, u4{lo[0], lo[1], lo[2], lo[3]});
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct)
+                            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ct], acc[i][ct], 0, 0, 0);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct)
+                            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ct], acc[i][ct], 0, 0, 0);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct)
+                            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ct], acc[i][ct], 0, 0, 0);
+                    } else {
+                        otf_pair2<false>(c2, f2{d0[0], d0[1]}, f2{t0[0], t0[1]}, &hi[0], &lo[0]);
+                        otf_pair2<false>(c2, f2{d0[2], d0[3]}, f2{t0[2], t0[3]}, &hi[1], &lo[1]);
+                        otf_pair2<false>(c2, f2{d1[0], d1[1]}, f2{t1[0], t1[1]}, &hi[2], &lo[2]);
+                        otf_pair2<false>(c2, f2{d1[2], d1[3]}, f2{t1[2], t1[3]}, &hi[3], &lo[3]);
+                        const h8 ah = __builtin_bit_cast(h8, u4{hi[0], hi[1], hi[2], hi[3]});
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct)
+                            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ct], acc[i][ct], 0, 0, 0);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct)
+                            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ct], acc[i][ct], 0, 0, 0);
+                    }
+                }
+            }
+#if MPSFR_MF_CLOCK
+            const unsigned long long tw0 = MF2_NOW();
+            t_tiles += tw0 - ts1;
+#endif
+            // the next k-step's tiles and slabs have landed, and nobody reads this k-step's any more
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if MPSFR_MF_CLOCK
+            const unsigned long long tw1 = MF2_NOW();
+#endif
+            __builtin_amdgcn_s_barrier();
+#if MPSFR_MF_CLOCK
+            t_wload += tw1 - tw0;
+            t_wbar += MF2_NOW() - tw1;
+#endif
+            buf ^= 1;
+        }
+#if MPSFR_MF_CLOCK
+        const unsigned long long tk1 = MF2_NOW();
+        t_kloop += tk1 - tk0;
+#endif
+        // second pass: the accumulator tile (rows = lines on registers / lane groups, column on
+        // the lane) is the A operand of a 16x16x16 product that sums over its rows; the G fragments
+        // of the next tile the wave needs are in flight behind the products of the current one
+        f4 P0[NJT], Q0[NJT], R2x[NJT], R2y[NJT];
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            P0[jt] = f4{0.f, 0.f, 0.f, 0.f};
+            Q0[jt] = f4{0.f, 0.f, 0.f, 0.f};
+            R2x[jt] = f4{0.f, 0.f, 0.f, 0.f};
+            R2y[jt] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+        unsigned tbits = 0;
+#pragma unroll
+        for (int i = 0; i < kTW; ++i) tbits |= (unsigned)((of[i] | om[i]) != 0) << i;
+        h4 gq[NJT][2][2];
+        auto fetch_g = [&](int i) {
+            const h4* Gm = Gl + (size_t)(g0 + 2 * i + half) * NJT * 2 * 2 * 64;
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+                    for (int hl = 0; hl < 2; ++hl) gq[jt][xy][hl] = Gm[((jt * 2 + xy) * 2 + hl) * 64];
+        };
+        if (tbits != 0) fetch_g(__builtin_ctz(tbits));
+#pragma unroll
+        for (int i = 0; i < kTW; ++i) {
+            if (!((tbits >> i) & 1)) continue;
+            h4 gc[NJT][2][2];
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+                    for (int hl = 0; hl < 2; ++hl) gc[jt][xy][hl] = gq[jt][xy][hl];
+            const unsigned later = tbits & ~((2u << i) - 1u);
+            fetch_g(later != 0 ? __builtin_ctz(later) : i);
+            h4 th[NCT], tw[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    _Float16 h, w;
+                    split16(acc[i][ct][r] * a.tq_scale, &h, &w);
+                    th[ct][r] = h;
+                    tw[ct][r] = w;
+                }
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                P0[jt] = mm16(P0[jt], th[0], tw[0], gc[jt][0][0], gc[jt][0][1]);
+                Q0[jt] = mm16(Q0[jt], th[1], tw[1], gc[jt][1][0], gc[jt][1][1]);
+                R2x[jt] = mm16(R2x[jt], th[2], tw[2], gc[jt][0][0], gc[jt][0][1]);
+                R2y[jt] = mm16(R2y[jt], th[2], tw[2], gc[jt][1][0], gc[jt][1][1]);
+            }
+        }
+#if MPSFR_MF_CLOCK
+        const unsigned long long t_red = MF2_NOW();
+        t_pass2 += t_red - tk1;
+#endif
+        // The two halves of the sweep meet in LDS (the staging buffers are free: the k-loop ends on a
+        // barrier behind its last reads): the odd wave leaves its partial tiles, the even wave adds
+        // them to its own -- a fixed order.  A (task, group) with a single sweep is finished here;
+        // otherwise the sweep's tiles go to memory for K_MF_FINISH.
+        f4* red = reinterpret_cast<f4*>(smem + slot * 8192) + lane;
+        if (half == 1) {
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                red[(0 * NJT + jt) * 64] = P0[jt];
+                red[(1 * NJT + jt) * 64] = Q0[jt];
+                red[(2 * NJT + jt) * 64] = R2x[jt];
+                red[(3 * NJT + jt) * 64] = R2y[jt];
+            }
+        }
+        __syncthreads();
+        if (half == 0 && lv) {
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                P0[jt] += red[(0 * NJT + jt) * 64];
+                Q0[jt] += red[(1 * NJT + jt) * 64];
+                R2x[jt] += red[(2 * NJT + jt) * 64];
+                R2y[jt] += red[(3 * NJT + jt) * 64];
+            }
+            if (nsweeps == 1) {
+                write_stamp(P0, Q0, R2x, R2y, lr, lk, a.pre + ((size_t)task * a.nl + l) * NS * NS);
+            } else {
+                f4* pt = a.part + (((size_t)task * a.nl + l) * nsw + sw) * (4 * NJT * 64) + lane;
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    pt[(0 * NJT + jt) * 64] = P0[jt];
+                    pt[(1 * NJT + jt) * 64] = Q0[jt];
+                    pt[(2 * NJT + jt) * 64] = R2x[jt];
+                    pt[(3 * NJT + jt) * 64] = R2y[jt];
+                }
+            }
+        }
+        __syncthreads();           // the tiles in LDS have been read: the next item may stage over them
+#if MPSFR_MF_CLOCK
+        t_tail += MF2_NOW() - t_red;
+#endif
+    }
+#if MPSFR_MF_CLOCK
+    if (clk != nullptr) {
+        const unsigned long long t_end = MF2_NOW();
+        clk[0] = t_begin; clk[1] = t_masks; clk[2] = t_kloop; clk[3] = t_stage; clk[4] = t_tiles;
+        clk[5] = t_wload; clk[6] = t_wbar; clk[7] = t_pass2; clk[8] = t_end; clk[9] = n_ks;
+        clk[10] = n_tiles; clk[11] = t_tail; clk[12] = n_dma; clk[13] = n_items;
+    }
+#endif
+#undef MF2_NOW
+}
+
+// K_MF_FINISH: the stamps of the (task, group)s with several sweeps: their partial tiles added in
+// sweep order, then the epilogue of K_OTF_MFMA2.  One wave per (task, wavelength).
+__global__ void __launch_bounds__(64) k_mf_finish(int N, int nl, int per, int ngr, const int* __restrict__ gsw,
+                                                  const f4* __restrict__ part, float* __restrict__ pre) {
+    const int l = blockIdx.x, task = blockIdx.y, lane = threadIdx.x;
+    const int m = gsw[task * ngr + l / per];
+    if (__builtin_popcount(m) <= 1) return;
+    const int nmt = mf_nmt(N), nsw = (nmt + kT2 - 1) / kT2;
+    f4 P0[NJT], Q0[NJT], R2x[NJT], R2y[NJT];
+    bool first = true;
+    for (int sw = 0; sw < nsw; ++sw) {
+        if (!((m >> sw) & 1)) continue;
+        const f4* pt = part + (((size_t)task * nl + l) * nsw + sw) * (4 * NJT * 64) + lane;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const f4 p = pt[(0 * NJT + jt) * 64], q = pt[(1 * NJT + jt) * 64];
+            const f4 x = pt[(2 * NJT + jt) * 64], y = pt[(3 * NJT + jt) * 64];
+            P0[jt] = first ? p : P0[jt] + p;
+            Q0[jt] = first ? q : Q0[jt] + q;
+            R2x[jt] = first ? x : R2x[jt] + x;
+            R2y[jt] = first ? y : R2y[jt] + y;
+        }
+        first = false;
+    }
+    write_stamp(P0, Q0, R2x, R2y, lane & 15, lane >> 4, pre + ((size_t)task * nl + l) * NS * NS);
+}
+
+}  // namespace
+
+static size_t mf2_nsw(int N) { return (size_t)(mf_nmt(N) + kT2 - 1) / kT2; }
+size_t mf2_own_bytes(int N, int ntask, int nl) { return (size_t)ntask * nl * mf_nmt(N) * 2 * sizeof(u64); }
+// uni | ksum | kuni in one buffer (any grouping: at most nl groups)
+size_t mf2_uni_bytes(int N, int ntask, int nl) {
+    return (size_t)ntask * nl * (mf_nmt(N) + 2 * mf2_nsw(N)) * sizeof(u64);
+}
+// sched[20] | gsw | items (int4) [16 classes][ntask ngr nsw]
+size_t mf2_sched_bytes(int N, int ntask, int nl) {
+    return (20 + (size_t)ntask * nl + 4 + 16 * (size_t)ntask * nl * mf2_nsw(N) * 4) * sizeof(int);
+}
+size_t mf2_part_bytes(int N, int ntask, int nl) { return (size_t)ntask * nl * mf2_nsw(N) * 4 * NJT * 64 * sizeof(f4); }
+
+// wavelength groups of at most `permax` (8: 16 waves at 128 registers; 6: 12 waves at 168), as even
+// as possible
+void mf2_groups(int nl, int permax, int* per, int* ngr) {
+    *ngr = (nl + permax - 1) / permax;
+    *per = (nl + *ngr - 1) / *ngr;
+}
+
+namespace {
+struct SchedPtrs { int* sched; int* gsw; int4* items; };
+SchedPtrs sched_ptrs(void* d_sched, int ntask, int nl) {
+    SchedPtrs p;
+    p.sched = (int*)d_sched;
+    p.gsw = p.sched + 20;
+    p.items = (int4*)(p.sched + 20 + (((size_t)ntask * nl + 3) & ~(size_t)3));
+    return p;
+}
+}  // namespace
+
+// masks of every (task, wavelength) and the work lists (d_sched[0..16] must be zero: launch_dmin)
+void launch_mf_masks(hipStream_t s, int N, int ntask, int nl, int permax, const LamPar* d_lp,
+                     const float* d_dminb, const float* d_tlb, float thr, float thr_mid, void* d_own,
+                     void* d_uni, void* d_sched) {
+    MaskArgs a;
+    a.N = N; a.nl = nl;
+    mf2_groups(nl, permax, &a.per, &a.ngr);
+    a.lp = d_lp; a.dminb = d_dminb; a.tlb = d_tlb;
+    a.thr = thr; a.thr_mid = thr_mid;
+    a.own = (u64*)d_own; a.uni = (u64*)d_uni;
+    a.ksum = a.uni + (size_t)ntask * nl * mf_nmt(N);
+    a.kuni = a.ksum + (size_t)ntask * nl * mf2_nsw(N);
+    const SchedPtrs p = sched_ptrs(d_sched, ntask, nl);
+    a.gsw = p.gsw; a.sched = p.sched; a.items = p.items;
+    a.cap = ntask * a.ngr * (int)mf2_nsw(N);
+    hipLaunchKernelGGL(k_mf_masks, dim3(a.ngr, ntask), dim3(64 * a.per), 0, s, a);
+}
+
+void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int ncu, const void* d_D0t,
+                      const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,
+                      const void* d_own, const void* d_uni, void* d_sched, void* d_part, void* d_pre,
+                      void* d_clk) {
+    Mf2Args a;
+    a.N = N; a.ntask = ntask; a.nl = nl;
+    mf2_groups(nl, permax, &a.per, &a.ngr);
+    a.D0t = (const float*)d_D0t; a.tl2 = d_tl2; a.lp = d_lp;
+    a.E = (const h8*)d_E; a.G = (const h4*)d_G;
+    a.own = (const u64*)d_own; a.uni = (const u64*)d_uni;
+    a.ksum = a.uni + (size_t)ntask * nl * mf_nmt(N);
+    a.kuni = a.ksum + (size_t)ntask * nl * mf2_nsw(N);
+    const SchedPtrs p = sched_ptrs(d_sched, ntask, nl);
+    a.sched = p.sched; a.items = p.items;
+    a.cap = ntask * a.ngr * (int)mf2_nsw(N);
+    a.part = (f4*)d_part;
+    a.clk = (unsigned long long*)d_clk;
+    int lg = 0;
+    while ((1 << lg) < N) ++lg;
+    a.tq_scale = 1.0f / ((float)(1 << lg) * (float)(1 << kTabShift));
+    a.pre = (float*)d_pre;
+    // one persistent workgroup per CU (its LDS admits no second one), never more than there can be items
+    const int maxitems = ntask * a.ngr * (int)mf2_nsw(N);
+    const int nwg = ncu < maxitems ? ncu : maxitems;
+    const size_t sm = 2 * (size_t)kStage2 + 2 * (size_t)a.per * kSlab;
+    if (permax > 6) {
+        allow_smem(k_otf_mfma2<4>, 2 * (size_t)kStage2 + 2 * (size_t)8 * kSlab);
+        hipLaunchKernelGGL(k_otf_mfma2<4>, dim3(nwg), dim3(128 * a.per), sm, s, a);
+    } else {
+        allow_smem(k_otf_mfma2<3>, 2 * (size_t)kStage2 + 2 * (size_t)6 * kSlab);
+        hipLaunchKernelGGL(k_otf_mfma2<3>, dim3(nwg), dim3(128 * a.per), sm, s, a);
+    }
+    hipLaunchKernelGGL(k_mf_finish, dim3(nl, ntask), dim3(64), 0, s, N, nl, a.per, a.ngr, (const int*)p.gsw,
+                       (const f4*)a.part, a.pre);
+}
+
+}  // namespace mpsfr

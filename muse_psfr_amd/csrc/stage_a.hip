@@ -294,11 +294,14 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
 // minima cost inside K_COLFFT_DPHI, whose column transforms then wait for the reductions.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_dmin(int N, const float* __restrict__ D0t,
-                                              float* __restrict__ dline, float* __restrict__ dblk) {
+                                              float* __restrict__ dline, float* __restrict__ dblk,
+                                              int* __restrict__ zero2) {
     constexpr int MAXKS = 1280 / 32;
     __shared__ int sblk[MAXKS], sline[16];          // bits of non-negative floats: integer order
     const int H1 = N / 2 + 1, nks = N / 32, nmt = (H1 + 15) / 16;
     const int mt = blockIdx.x, td = blockIdx.y;
+    // the counters of the matrix-core stage's work list (K_MF_MASKS, K_OTF_MFMA2) start from zero
+    if (zero2 != nullptr && mt == 0 && td == 0 && threadIdx.x < 17) zero2[threadIdx.x] = 0;
     if (threadIdx.x < MAXKS) sblk[threadIdx.x] = 0x7f800000;
     if (threadIdx.x < 16) sline[threadIdx.x] = 0x7f800000;
     __syncthreads();
@@ -476,9 +479,10 @@ void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax)
     hipLaunchKernelGGL(k_tel_linemax, dim3(N / 2 + 1), dim3(256), 0, s, N, (const float*)d_tel, d_tlmax);
 }
 
-void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk) {
+void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk,
+                 int* d_zero2) {
     hipLaunchKernelGGL(k_dmin, dim3((N / 2 + 1 + 15) / 16, ntd), dim3(256), 0, s, N, (const float*)d_D0t,
-                       d_dline, d_dblk);
+                       d_dline, d_dblk, d_zero2);
 }
 
 void launch_task_order(hipStream_t s, int ntask, int nl, const int* d_vkeep, int* d_order) {

@@ -320,13 +320,14 @@ def test_profile_options(api):
     lb = np.linspace(500, 900, 4)
     ctx = api.Context(dim=128, pixscale=api.grid_pixscale(128))
     names = ctx.profile_names()
-    assert 'otf_rowfft' in names and 'fit' in names
+    assert 'otf_mfma' in names and 'otf_rowfft' in names and 'fit' in names
     ctx.set_option('profile', 1)
     ctx.profile_reset()
     first = ctx.reconstruct(lb, see, gl, l0, np.zeros(6, np.uint8), H)
     prof = ctx.profile()
-    assert prof['otf_rowfft'][1] == 1 and prof['fit'][1] == 1 and prof['otf_rowfft'][0] > 0
-    ctx.set_option('profile_only', names.index('otf_rowfft'))
+    assert prof['otf_mfma'][1] == 1 and prof['fit'][1] == 1 and prof['otf_mfma'][0] > 0
+    assert prof['otf_rowfft'][1] == 0 and prof['mf_prep'][1] == 2       # block minima, masks
+    ctx.set_option('profile_only', names.index('otf_mfma'))
     ctx.profile_reset()
     import torch
     from muse_psfr_amd import NFIT
@@ -338,7 +339,7 @@ def test_profile_options(api):
                                psum.data_ptr(), fit.data_ptr())
     ctx.sync()
     prof = ctx.profile()
-    assert prof['otf_rowfft'][1] == 9 and prof['fit'][1] == 0
+    assert prof['otf_mfma'][1] == 9 and prof['fit'][1] == 0
     np.testing.assert_array_equal(fit.cpu().numpy(), first['fit'])
     with pytest.raises(api.MpsfrError):
         ctx.set_option('profile_only', 99)
@@ -660,6 +661,11 @@ def test_line_pruning_changes_nothing_above_its_bound(api, dim, npl):
             ctx.set_option('prune_eps', eps)
         out[key] = ctx.reconstruct(lb, see, gl, l0, three, H, npsflin=npl)
         if key == 'pruned':
+            if npl == 1:        # one direction: the block-masked kernel runs, which needs no line bounds
+                with pytest.raises(api.MpsfrError):
+                    ctx.debug_fetch('vkeep', (12, 4))
+                ctx.set_option('mf_kernel', 1)
+                ctx.reconstruct(lb, see, gl, l0, three, H, npsflin=npl)
             vk = ctx.debug_fetch('vkeep', (12, 4))
         ctx.close()
     a, b, c = out['all'], out['pruned'], out['loose']
