@@ -4,9 +4,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload at every N (weak scaling): BASELINE.json configs[1] per GPU -- 100 synthetic SPARTA
-rows x 35 wavelengths (465-930 nm) on a 512^2 grid, pixscale 0.2*512/1344,
-npsflin=1.  One step = one pass of the hot path over the rank's 100-row batch plus, for N > 1,
+Workload: N = 1: BASELINE.json configs[1] -- 100 synthetic SPARTA rows x 35 wavelengths
+(465-930 nm) on a 512^2 grid, pixscale 0.2*512/1344, npsflin=1.  N > 1:
+BASELINE.json configs[2] -- the same grid and wavelengths, a 1000-row table row-sharded over the N
+GPUs (muse_psfr_amd.distributed.shard_bounds: strong scaling); `--rows R` instead gives every rank
+R rows (weak scaling).  One step = one pass of the hot path over the rank's rows plus, for N > 1,
 the RCCL all-gather of the fit tables and sum-reduce of the partial mean-PSF numerators.
 With N > 1 and no launcher environment the script starts its own N ranks
 (torch.distributed.run), like the reference fans out by itself (psfrec.py:1082-1083).
@@ -115,7 +117,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=400)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--rows', type=int, default=100, help='rows per GPU per step')
+    ap.add_argument('--rows', type=int, default=0,
+                    help='rows per GPU per step (weak scaling); default: 100 at N = 1 (configs[1]), a 1000-row '
+                         'table sharded over the ranks at N > 1 (configs[2])')
+    ap.add_argument('--table-rows', type=int, default=1000, help='rows of the sharded table at N > 1')
     ap.add_argument('--dim', type=int, default=512)
     ap.add_argument('--nl', type=int, default=35)
     ap.add_argument('--npsflin', type=int, default=1)
@@ -134,6 +139,15 @@ def main():
                     help='steps of the fp64-mode leg (-1: steps/8, 0: skip)')
     ap.add_argument('--unpruned-steps', type=int, default=-1,
                     help='steps of the leg without line pruning (-1: steps/4, 0: skip)')
+    ap.add_argument('--host-steps', type=int, default=-1,
+                    help='steps of the host-output leg (synchronous call, fit table + stamp sum copied to the '
+                         'host; -1: min(steps, 50), 0: skip)')
+    ap.add_argument('--native-steps', type=int, default=-1,
+                    help='steps of the native-grid leg (1280^2, pixscale 0.2, 490-930 nm: what the reference\'s '
+                         'compute_psf runs; -1: 20 at the default workload, 0: skip)')
+    ap.add_argument('--min-seconds', type=float, default=0.2,
+                    help='if the timed region is shorter, repeat it (value stays the first, value_min/max '
+                         'report the spread)')
     ap.add_argument('--profile-steps', type=int, default=-1,
                     help='steps of the untimed per-kernel event pass (-1: min(steps, 40), 0: skip)')
     a = ap.parse_args()
@@ -146,11 +160,23 @@ def main():
     a.gpus = world
 
     from muse_psfr_amd import synthetic_rows, grid_pixscale
-    dim, nl, rows = a.dim, a.nl, a.rows
+    from muse_psfr_amd.distributed import shard_bounds
+    dim, nl = a.dim, a.nl
     ps = grid_pixscale(dim)
     lb = np.linspace(465.0, 930.0, nl) if dim != 1280 else np.linspace(490.0, 930.0, nl)
-    see, gl, l0 = synthetic_rows(rows * world)
-    sl = slice(rank * rows, (rank + 1) * rows)
+    # the table and this rank's contiguous shard of it
+    strong = world > 1 and a.rows <= 0
+    if strong:
+        total_rows = a.table_rows
+        bounds = shard_bounds(total_rows, world)
+    else:
+        per = a.rows if a.rows > 0 else 100
+        total_rows = per * world
+        bounds = [(r * per, (r + 1) * per) for r in range(world)]
+    see, gl, l0 = synthetic_rows(total_rows)
+    sl = slice(*bounds[rank])
+    rows = bounds[rank][1] - bounds[rank][0]
+    default_workload = (world == 1 and (rows, nl, dim, a.npsflin, a.precision) == (100, 35, 512, 1, 'mixed'))
     mixed = a.precision == 'mixed'
 
     # ---- CPU baseline first (fork pool, before this process touches the GPU)
@@ -173,6 +199,19 @@ def main():
         if cal:
             cpu['calibration'] = cal
 
+    # ---- oracle sample for the native-grid leg (1280^2, pixscale 0.2: what the reference's compute_psf runs)
+    nnat = (20 if default_workload else 0) if a.native_steps < 0 else a.native_steps
+    if world > 1 or not mixed:
+        nnat = 0
+    lb_nat = np.linspace(490.0, 930.0, nl)
+    nat_sel = [0, nl // 2, nl - 1]
+    nat_fits = None
+    if nnat > 0 and rank == 0 and a.cpu_rows != 0:
+        import multiprocessing as mp
+        jobs = [(lb_nat[nat_sel], see[i], gl[i], l0[i], 1280, 0.2, True) for i in range(min(4, rows))]
+        with mp.get_context('fork').Pool(min(len(jobs), 4)) as pool:
+            nat_fits = np.array([r[0] for r in pool.map(_cpu_rows, jobs, chunksize=1)])
+
     import torch
     import torch.distributed as dist
     from muse_psfr_amd import Context, NFIT
@@ -193,7 +232,7 @@ def main():
 
     from muse_psfr_amd.distributed import ShardExchange
 
-    def make_runner(precision, nctx, prune_eps=a.prune_eps, streams=a.streams):
+    def make_runner(precision, nctx, prune_eps=a.prune_eps, streams=a.streams, dim=dim, ps=ps, lb=lb):
         """Steps are independent batches, pipelined through `nctx` contexts (each with its own
         HIP stream and workspaces) fed in turn.  A step is still one mpsfr_reconstruct of the
         rank's rows; every step's outputs are produced."""
@@ -222,7 +261,7 @@ def main():
         psums = [torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev) for _ in range(nset)]
         # the exchange buffers are allocated once (one set per result-buffer set)
         xdev = dev if backend == 'nccl' else torch.device('cpu')
-        exch = [ShardExchange(world * rows, nl, NFIT, xdev) for _ in range(nset)] if world > 1 else None
+        exch = [ShardExchange(total_rows, nl, NFIT, xdev) for _ in range(nset)] if world > 1 else None
         state = {'i': 0, 'ev': [None] * nset}
         # torch orders its collectives against the library on the GPU (no host sync inside a
         # step): torch's stream waits for the context's stream (which is ordered after every call
@@ -332,6 +371,12 @@ def main():
     dt, t_enq = R['timed'](a.steps)
     prof = R['profile_sum']()
     host_lib_s = R['host_lib']()
+    # A region of a few milliseconds is thin evidence: repeat it (same K steps, same brackets) until
+    # --min-seconds of timed work have been seen; `value` stays the FIRST region, the repeats only
+    # report the spread.
+    rep_dt = [dt]
+    while sum(rep_dt) < a.min_seconds and len(rep_dt) < 64:
+        rep_dt.append(R['timed'](a.steps)[0])
     nprof = min(a.steps, 40) if a.profile_steps < 0 else a.profile_steps
     prof_all = {}
     if nprof > 0:
@@ -355,7 +400,7 @@ def main():
             nprobe = min(nprobe, a.chunk)
         pf = torch.zeros((nprobe, nl, NFIT), dtype=torch.float64, device=dev)
         psm = torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev)
-        sp = slice(rank * rows, rank * rows + nprobe)
+        sp = slice(sl.start, sl.start + nprobe)
         ctxs[0].reconstruct_device(lb, see[sp], gl[sp], l0[sp], three[:nprobe], h, 12.0, a.npsflin,
                                    None, None, psm.data_ptr(), pf.data_ptr())
         ctxs[0].sync()
@@ -372,7 +417,7 @@ def main():
                 nprobe = min(rows, 4096 // nl if nl <= 512 else 8)
                 pf = torch.zeros((nprobe, nl, NFIT), dtype=torch.float64, device=dev)
                 psm = torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev)
-                sp = slice(rank * rows, rank * rows + nprobe)
+                sp = slice(sl.start, sl.start + nprobe)
                 ctxs[0].reconstruct_device(lb, see[sp], gl[sp], l0[sp], three[:nprobe], h, 12.0, a.npsflin,
                                            None, None, psm.data_ptr(), pf.data_ptr())
                 ctxs[0].sync()
@@ -383,6 +428,59 @@ def main():
         except Exception:       # the FFT kernels ran (several directions, or otf_mfma = 0)
             mf_work = None
     R['close']()
+
+    def apply_options(c, precision):
+        if a.chunk:
+            c.set_option('chunk_tasks', a.chunk)
+        if a.streams:
+            c.set_option('streams', a.streams)
+        if a.prune_eps >= 0 and precision == 'mixed':
+            c.set_option('prune_eps', a.prune_eps)
+
+    # ---- what a caller of compute_psf_from_sparta gets: one synchronous call per step, the fit
+    # table and the stamp sum copied to (pageable) host memory -- PCIe inclusive, never `value`
+    host_leg = None
+    nhost = (min(a.steps, 50) if a.host_steps < 0 else a.host_steps) if world == 1 else 0
+    if nhost > 0:
+        c = Context(dim=dim, pixscale=ps, precision=a.precision, device=local)
+        apply_options(c, a.precision)
+        for _ in range(3):
+            c.reconstruct(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, want_psf=False)
+        t0 = time.perf_counter()
+        for _ in range(nhost):
+            rh = c.reconstruct(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, want_psf=False)
+        dth = time.perf_counter() - t0
+        c.close()
+        host_leg = {'value': round(rows * nl * nhost / dth, 1), 'unit': 'PSFs/sec', 'steps': nhost,
+                    'ms_per_call': round(dth / nhost * 1e3, 4),
+                    'outputs': 'fit table [rows][nl][16] + stamp sum [nl][40][40] (float64) in host memory, '
+                               'call synchronous: what compute_psf_from_sparta hands back (psfrec.py:978, '
+                               '1104-1113)'}
+        if cpu_fits is not None:
+            n = cpu_fits.shape[0]
+            host_leg['parity'] = {'rows_checked': n,
+                                  'max_abs_err_fwhm_arcsec': float(np.abs(rh['fit'][:n, :, 5] * ps - cpu_fits[:, :, 3]).max()),
+                                  'max_abs_err_beta': float(np.abs(rh['fit'][:n, :, 4] - cpu_fits[:, :, 4]).max()),
+                                  'tolerance': 1e-4}
+
+    # ---- the reference's own grid (compute_psf hard-codes dim = 1280, pixscale 0.2: psfrec.py:954-955, 659)
+    native = None
+    if nnat > 0:
+        Rn = make_runner('mixed', 1, dim=1280, ps=0.2, lb=lb_nat)
+        for _ in range(8):
+            Rn['step']()
+        dtn, _ = Rn['timed'](nnat)
+        fitn = Rn['fits'][0].cpu().numpy()
+        Rn['close']()
+        native = {'value': round(rows * nl * nnat / dtn, 1), 'unit': 'PSFs/sec', 'steps': nnat,
+                  'ms_per_step': round(dtn / nnat * 1e3, 4),
+                  'workload': '%d rows x %d lambda (490-930 nm), 1280^2 grid, pixscale 0.2' % (rows, nl)}
+        if nat_fits is not None:
+            n = nat_fits.shape[0]
+            native['parity'] = {'rows_checked': n, 'wavelengths_checked': [float(lb_nat[i]) for i in nat_sel],
+                                'max_abs_err_fwhm_arcsec': float(np.abs(fitn[:n][:, nat_sel, 5] * 0.2 - nat_fits[:, :, 3]).max()),
+                                'max_abs_err_beta': float(np.abs(fitn[:n][:, nat_sel, 4] - nat_fits[:, :, 4]).max()),
+                                'tolerance': 1e-4}
 
     # ---- the dominant kernel with one call in flight (no other kernel beside it on the GPU): what
     # the kernel itself achieves, as opposed to its share of the GPU in the pipelined run
@@ -410,7 +508,7 @@ def main():
         dt3, _ = R3['timed'](nunp)
         fit3 = R3['fits'][0].cpu().numpy()
         R3['close']()
-        unpruned = {'value': round(world * rows * nl * nunp / dt3, 1), 'unit': 'PSFs/sec', 'steps': nunp,
+        unpruned = {'value': round(total_rows * nl * nunp / dt3, 1), 'unit': 'PSFs/sec', 'steps': nunp,
                     'ms_per_step': round(dt3 / nunp * 1e3, 4),
                     'max_abs_diff_fwhm_px_vs_pruned': float(np.abs(fit3[:, :, 5] - fitg[:, :, 5]).max()),
                     'max_abs_diff_beta_vs_pruned': float(np.abs(fit3[:, :, 4] - fitg[:, :, 4]).max())}
@@ -425,14 +523,14 @@ def main():
         dt2, _ = R2['timed'](nf64)
         fit2 = R2['fits'][0].cpu().numpy()
         R2['close']()
-        f64 = {'value': round(world * rows * nl * nf64 / dt2, 1), 'unit': 'PSFs/sec',
+        f64 = {'value': round(total_rows * nl * nf64 / dt2, 1), 'unit': 'PSFs/sec',
                'steps': nf64, 'ms_per_step': round(dt2 / nf64 * 1e3, 4), 'dtype': 'f64'}
         if cpu_fits is not None and rank == 0:
             f64['parity'] = parity_block(fit2, cpu_fits.shape[0])
     gc.enable()
 
     if rank == 0:
-        npsf = world * rows * nl * a.steps
+        npsf = total_rows * nl * a.steps
         ndir = a.npsflin ** 2
         ms, nlaunch = prof[dominant]
         chunk = a.chunk or 'auto'
@@ -476,14 +574,16 @@ def main():
                          'ceil(nl/2) per row) x 5 N log2 N flops per complex N-point transform; HIP events on '
                          'the launch stream, timed region')
         achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0
-        util = (load_json('r02_kernel_util.json') or load_json('r01_kernel_util.json') or {})
+        util_name = next((n for n in ('r03_kernel_util.json', 'r02_kernel_util.json', 'r01_kernel_util.json')
+                          if load_json(n)), None)
+        util = load_json(util_name) if util_name else {}
         kkey = 'k_otf_mfma' if mf_work is not None else 'k_' + dominant
-        u = util.get(kkey) if (dim, mixed) == (512, True) else None
-        tj = load_json('r02_traffic.json') or load_json('r01_traffic.json')
+        u = next((v for k, v in util.items() if k.startswith(kkey)), None) if (dim, mixed) == (512, True) else None
+        tj = load_json('r03_traffic.json') or load_json('r02_traffic.json') or load_json('r01_traffic.json')
         traffic = None
         traffic_step = None
         if tj and (dim, nl, rows, a.npsflin, mixed) == (512, 35, 100, 1, True):
-            k = tj['kernels'].get(kkey, {})
+            k = next((v for kk, v in tj['kernels'].items() if kk.startswith(kkey)), {})
             if k.get('fetch_kib') is not None and k.get('write_kib') is not None:
                 per_unit = (k['fetch_kib'] + k['write_kib']) * 1024.0 / tj['units_per_launch']
                 traffic = per_unit * units_per_launch
@@ -499,17 +599,21 @@ def main():
             'metric': 'PSFs/sec (row x lambda) on %d^2 grid, %d lambda' % (dim, nl),
             'value': round(npsf / dt, 1), 'unit': 'PSFs/sec', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': round(step_s * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': ('f64 PSD->structure function, per-lambda OTF f32 -> split-fp16 MFMA (fp32 accumulate), '
                       'f64 fit' if mf_work is not None else
                       'f64 PSD->structure function, f32 per-lambda OTF/FFT, f64 fit') if mixed else 'f64',
             'data': 'synthetic',
-            'config': {'workload': '%d synthetic SPARTA rows/GPU x %d lambda (%.0f-%.0f nm), '
-                                   '%d^2 grid, pixscale %.5f, npsflin=%d%s' % (
-                                       rows, nl, lb[0], lb[-1], dim, ps, a.npsflin,
+            'config': {'workload': ('%d-row synthetic SPARTA table row-sharded over %d GPUs (%s rows per GPU)'
+                                    % (total_rows, world, '/'.join(str(b - a_) for a_, b in bounds))
+                                    if strong else '%d synthetic SPARTA rows/GPU' % rows) +
+                                   ' x %d lambda (%.0f-%.0f nm), %d^2 grid, pixscale %.5f, npsflin=%d%s' % (
+                                       nl, lb[0], lb[-1], dim, ps, a.npsflin,
                                        ' (BASELINE.json configs[1])'
-                                       if (rows, nl, dim, a.npsflin) == (100, 35, 512, 1) else ''),
-                       'rows_per_gpu': rows, 'nl': nl, 'dim': dim, 'npsflin': a.npsflin,
+                                       if (world, rows, nl, dim, a.npsflin) == (1, 100, 35, 512, 1) else
+                                       ' (BASELINE.json configs[2])'
+                                       if strong and (total_rows, nl, dim, a.npsflin) == (1000, 35, 512, 1) else ''),
+                       'rows_total': total_rows, 'rows_per_gpu': rows, 'nl': nl, 'dim': dim, 'npsflin': a.npsflin,
                        'chunk_tasks': chunk, 'parallelism': 'rows sharded x%d' % world},
             # The dominant kernel is the per-wavelength stage: on the matrix
             # cores in mixed mode with one direction, LDS FFTs on the vector pipe otherwise.
@@ -538,8 +642,7 @@ def main():
                          'valu_issue': u and u.get('valu_issue'),
                          'mfma_busy': u and u.get('mfma_busy'),
                          'lds_busy': u and u.get('lds_array_busy'),
-                         'pmc_source': u and 'profiles/ kernel_util.json (scripts/prof_table.sh, '
-                                             'one step in flight)'},
+                         'pmc_source': u and 'profiles/%s (scripts/prof_table.sh, one step in flight)' % util_name},
             # whole step against HBM: algorithmic bytes of the restructured pipeline, what the
             # PMC counters saw, and the ratio (wasted re-reads / padding / fp64 intermediates)
             'roofline_hbm': {'model_bytes_per_step': model_step, 'model_terms': model,
@@ -566,6 +669,19 @@ def main():
             'host_library_ms_per_call': round(host_lib_s * 1e3, 4),
             'build_id': load_lib().mpsfr_build_id().decode(),
         }
+        if len(rep_dt) > 1:
+            vals = [npsf / d for d in rep_dt]
+            out['timed_region_repeats'] = {'count': len(rep_dt), 'seconds_each': round(dt, 4),
+                                           'value_min': round(min(vals), 1), 'value_max': round(max(vals), 1),
+                                           'value_median': round(float(np.median(vals)), 1),
+                                           'note': '`value` is the first region; the others repeat the same K steps '
+                                                   'behind the same barrier + synchronize brackets'}
+        if host_leg is not None:
+            out['value_host_outputs'] = host_leg['value']
+            out['host_outputs'] = host_leg
+        if native is not None:
+            out['value_native1280'] = native['value']
+            out['native1280'] = native
         if f64 is not None:
             out['value_f64'] = f64['value']
             out['f64'] = f64

@@ -77,9 +77,30 @@ def build_library(force=False, verbose=True, out=None, extra_flags=()):
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
     if not variant:
+        lint_library(target)
         with open(STAMP, 'w') as fh:
             fh.write(build_id + '\n')
     return target
+
+
+def lint_library(lib):
+    """Static hazard check of the emitted ISA (tools/isa_lint.py): hipcc pads nothing inside an
+    inline-asm statement, so a build whose instruction placement exposes a hazard must not ship.
+    MPSFR_SKIP_ISA_LINT=1 skips it (kernel experiments)."""
+    if os.environ.get('MPSFR_SKIP_ISA_LINT'):
+        return
+    import importlib.util
+    tool = os.path.join(os.path.dirname(HERE), 'tools', 'isa_lint.py')
+    if not os.path.exists(tool):
+        return
+    spec = importlib.util.spec_from_file_location('isa_lint', tool)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    findings, _, _ = mod.lint_library(lib)
+    if findings:
+        os.remove(lib)
+        raise RuntimeError('ISA hazard lint failed for %s:\n%s' % (
+            lib, '\n'.join('%s %s: %s' % f for f in findings[:20])))
 
 
 if __name__ == '__main__':

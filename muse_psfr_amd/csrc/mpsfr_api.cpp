@@ -92,7 +92,12 @@ struct mpsfr_ctx {
         hipEvent_t done = nullptr;       // after the lane's last chunk of the most recent call
         bool busy = false;               // `done` has been recorded
         DevBuf C, s00, D0t, Tq, pre, fin, dmin, dblk, vkeep, dminb, order, mown, muni, msched, mpart;
-        const void* outs[3] = {nullptr, nullptr, nullptr};   // device outputs of its latest call
+        // device outputs of its most recent calls: `done` is recorded behind every call of the lane,
+        // so waiting for it covers all of them (a caller that rotates more buffer sets than lanes
+        // must still get the calls that share a buffer in order)
+        static constexpr int NHIST = 8;
+        const void* outs[NHIST][3] = {};
+        unsigned nouts = 0;
     };
     static constexpr int MAX_LANES = 4;
     Lane lane[MAX_LANES];
@@ -487,12 +492,37 @@ int mpsfr_wait_event(mpsfr_ctx* c, void* hip_event) {
     return MPSFR_OK;
 }
 
+static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const double* gl,
+                            const double* l0, const uint8_t* three_lgs, const double h[2],
+                            double wind_speed, int npsflin, int nl, const double* lbda_nm,
+                            const uint8_t* mask_rec, const uint8_t* mask_res, double* psf_out,
+                            double* psf_sum_out, double* fit_out, int on_device);
+
 int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const double* gl,
                       const double* l0, const uint8_t* three_lgs, const double h[2],
                       double wind_speed, int npsflin, int nl, const double* lbda_nm,
                       const uint8_t* mask_rec, const uint8_t* mask_res, double* psf_out,
                       double* psf_sum_out, double* fit_out, int on_device) {
     if (!c) return fail(MPSFR_E_INVALID, "ctx is NULL");
+    // A call that fails leaves the pipelining state as it found it: the lane rotation and the ring
+    // of parameter slots do not advance, and an event registered with mpsfr_wait_event is consumed
+    // (the caller may destroy it after the call, whatever the outcome).
+    const unsigned lane_rr0 = c->lane_rr, stage0 = c->stage_next;
+    const int rc = reconstruct_impl(c, ntask, seeing, gl, l0, three_lgs, h, wind_speed, npsflin, nl, lbda_nm,
+                                    mask_rec, mask_res, psf_out, psf_sum_out, fit_out, on_device);
+    if (rc != MPSFR_OK) {
+        c->lane_rr = lane_rr0;
+        c->stage_next = stage0;
+        c->wait_next = nullptr;
+    }
+    return rc;
+}
+
+static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const double* gl,
+                            const double* l0, const uint8_t* three_lgs, const double h[2],
+                            double wind_speed, int npsflin, int nl, const double* lbda_nm,
+                            const uint8_t* mask_rec, const uint8_t* mask_res, double* psf_out,
+                            double* psf_sum_out, double* fit_out, int on_device) {
     const auto t_enter = std::chrono::steady_clock::now();
     if (ntask < 1 || !seeing || !gl || !l0 || !h || !lbda_nm)
         return fail(MPSFR_E_INVALID, "ntask < 1 or NULL input array");
@@ -655,8 +685,9 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
             const mpsfr_ctx::Lane& o = c->lane[k];
             if (&o == &lane_of(j) || !o.busy) continue;
             bool same = false;
-            for (int a = 0; a < 3; ++a)
-                for (int b = 0; b < 3; ++b) same = same || (outs[a] && outs[a] == o.outs[b]);
+            for (int hsl = 0; hsl < mpsfr_ctx::Lane::NHIST; ++hsl)
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) same = same || (outs[a] && outs[a] == o.outs[hsl][b]);
             if (same) HIPCHK(hipStreamWaitEvent(ls, o.done, 0));
         }
     }
@@ -776,9 +807,9 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         {   // 16 lines of padding behind D: the last m-tile of the matrix-core kernel reads past line
             // N/2 (where its telescope table is -inf); fresh memory is zeroed so that what it reads
             // there is always a finite number
-            const void* before = ln.D0t.p;
+            const size_t cap_before = ln.D0t.cap;       // (a reallocation may return the same address)
             if ((rc = ensure(c, ln.D0t, ((size_t)TC * ndir * H1 + 16) * N * rsize(c)))) return rc;
-            if (ln.D0t.p != before) HIPCHK(hipMemset(ln.D0t.p, 0, ln.D0t.cap));
+            if (ln.D0t.cap != cap_before) HIPCHK(hipMemset(ln.D0t.p, 0, ln.D0t.cap));
         }
         if (!mf && (rc = ensure(c, ln.Tq, (size_t)TC * nl * H1 * NSH * 2 * rsize(c)))) return rc;
         if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * (c->f64 ? 8 : 4)))) return rc;
@@ -927,7 +958,8 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         mpsfr_ctx::Lane& ln = lane_of(j);
         HIPCHK(hipEventRecord(ln.done, ln.stream));
         ln.busy = true;
-        for (int a = 0; a < 3; ++a) ln.outs[a] = outs[a];
+        for (int a = 0; a < 3; ++a) ln.outs[ln.nouts % mpsfr_ctx::Lane::NHIST][a] = outs[a];
+        ln.nouts += 1;
         HIPCHK(hipStreamWaitEvent(s, ln.done, 0));
     }
     if (psf_sum_out && NL > 1) {       // add the per-lane sums in lane order

@@ -212,7 +212,7 @@ __device__ __forceinline__ void otf_pair(f2 cc, f2 d, f2 t, unsigned* hi, unsign
 }
 
 // MULTI: several directions.  A staged tile is then ndir x D | log2 tel ((ndir + 1) x 2 KB), a sweep
-// takes as many m-tiles as fit the staging buffer (tpg: three at four directions, one at nine), and
+// takes as many m-tiles as fit the 52 KB staging buffer (tpg: five at four directions, two at nine), and
 // the OTF tile costs ndir exponentials per element -- the vector pipe, not the loads, sets the pace.
 template <bool MULTI>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -256,7 +256,12 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
     const bool lv = wave < per && grp * per + wave < a.nl;
     const int l = lv ? grp * per + wave : lmax;
     const float kLog2e = 1.44269504088896340736f;
-    const float c2 = (float)a.lp[l].c * kLog2e, c2u = (float)a.lp[lmax].c * kLog2e;
+    const float c2 = (float)a.lp[l].c * kLog2e;
+    // the staging mask of the group is that of its LONGEST wavelength (the bound grows with the
+    // wavelength), whichever member that is: the caller's wavelengths come in any order
+    double cu = a.lp[lmax].c;
+    for (int j = grp * per; j < lmax; ++j) cu = fmax(cu, a.lp[j].c);
+    const float c2u = (float)cu * kLog2e;
     const f2 cc = {c2, c2};
     const int npair = (a.nl + 1) / 2;
     const int nv = a.vkeep != nullptr ? a.vkeep[(size_t)task * npair + (l >> 1)] : H1;

@@ -384,14 +384,17 @@ __global__ void __launch_bounds__(256) k_vkeep(int H1, int nks, int ndir, int nl
     // segments of the half plane, so that the serial walk is one pass over the segment sums and
     // one inside a segment (a single thread over all lines put 257 dependent steps on the chain
     // of every call).
-    constexpr int SEG = 8, MAXP = 2048;
+    constexpr int SEG = 8, MAXP = 2048;                  // nl <= 4096
     __shared__ float seg[32][SEG];                       // 32 pairs per sweep
+    __shared__ int svk[MAXP];
     const int slen = (H1 + SEG - 1) / SEG;
     for (int p0 = 0; p0 < npair; p0 += 32) {
         const int pr = p0 + (int)(threadIdx.x >> 3), sg = threadIdx.x & 7;
         const bool on = pr < npair;
-        const int l = on ? (2 * pr + 1 < nl ? 2 * pr + 1 : 2 * pr) : 0;       // the longer wavelength
-        const float c2 = (float)lp[l].c * 1.44269504088896340736f;
+        // the pair is bounded by its LONGER wavelength, whichever of the two that is (c < 0 rises
+        // with the wavelength; the caller's wavelengths come in any order)
+        const int la = on ? 2 * pr : 0, lb = on && 2 * pr + 1 < nl ? 2 * pr + 1 : la;
+        const float c2 = (float)fmax(lp[la].c, lp[lb].c) * 1.44269504088896340736f;
         float part = 0.f;
         for (int v = min(H1, (sg + 1) * slen) - 1; v >= sg * slen; --v)
             part += __builtin_amdgcn_exp2f(fmaf(c2, sa[v], sb[v]));
@@ -411,12 +414,18 @@ __global__ void __launch_bounds__(256) k_vkeep(int H1, int nks, int ndir, int nl
                 }
                 sum = next;
             }
-            vkeep[task * npair + pr] = fixed > 0 ? min(fixed, H1) : vk;   // fixed: experiments
+            svk[pr] = fixed > 0 ? min(fixed, H1) : vk;   // fixed: experiments
         }
         __syncthreads();
     }
-    (void)MAXP;
-    // (monotone in the pair index: c2 rises with the wavelength, so every term of the sum does)
+    // The consumers (per_lambda.hip, otf_mfma.hip) stage and loop to the LAST pair of a wavelength
+    // group and rely on vkeep growing with the pair index.  With ascending wavelengths it does (c2
+    // rises with the wavelength, so every term of the sum does); for any other order the running
+    // maximum makes it so -- keeping more lines than needed is always safe.
+    if (threadIdx.x == 0)
+        for (int pr = 1; pr < npair; ++pr) svk[pr] = max(svk[pr], svk[pr - 1]);
+    __syncthreads();
+    for (int pr = threadIdx.x; pr < npair; pr += 256) vkeep[task * npair + pr] = svk[pr];
 }
 
 // K_TASK_ORDER: the tasks of a chunk by descending lines kept at the longest wavelength (ties by

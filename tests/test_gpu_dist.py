@@ -81,3 +81,14 @@ def test_bench_starts_its_own_ranks():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['value'] > 0 and out['scaling'] == 'weak'
     assert 0 < out['roofline']['frac'] <= 1
+    assert out['config']['rows_total'] == 24 and out['timed_region_repeats']['count'] > 1
+    # the default at N > 1: one table row-sharded over the ranks (BASELINE.json configs[2], here 31 rows)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4',
+                        '--warmup', '1', '--table-rows', '31', '--dim', '128', '--nl', '5',
+                        '--f64-steps', '0', '--profile-steps', '0', '--unpruned-steps', '0', '--min-seconds', '0'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][0])
+    assert out['scaling'] == 'strong' and out['config']['rows_total'] == 31
+    assert 'row-sharded over 2 GPUs (16/15 rows per GPU)' in out['config']['workload']
+    assert abs(out['value'] - 31 * 5 * 4 / (out['ms_per_step'] * 4e-3)) < 1e-3 * out['value']

@@ -726,3 +726,32 @@ def test_line_pruning_is_off_in_f64_mode(api):
     with pytest.raises(api.MpsfrError):
         ctx.set_option('prune_eps', 0.1)
     ctx.close()
+
+
+@pytest.mark.parametrize('opts', [{}, {'mf_kernel': 1}, {'otf_mfma': 0}])
+def test_wavelengths_in_any_order(api, opts):
+    """The reference takes the wavelengths in any order (psfrec.py:667 loops over them as given); the
+    pruning of the per-wavelength stage bounds pairs and groups of wavelengths by their longest
+    member, which must not be assumed to be the last one."""
+    see, gl, l0 = api.synthetic_rows(5)
+    see[0], gl[0], l0[0] = 0.45, 0.9, 28.0
+    lb = np.linspace(465, 930, 11)
+    perm = np.array([7, 0, 10, 3, 5, 1, 9, 2, 8, 4, 6])
+    ps = api.grid_pixscale(512)
+    res = []
+    for order in (np.arange(11), perm, np.arange(11)[::-1]):
+        ctx = api.Context(dim=512, pixscale=ps, precision='mixed')
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        r = ctx.reconstruct(lb[order], see, gl, l0, np.zeros(5, np.uint8), H)
+        ctx.close()
+        inv = np.argsort(order)
+        res.append((r['psf'][:, inv], r['fit'][:, inv]))
+    peak = res[0][0].max(axis=(2, 3), keepdims=True)
+    for psf, fit in res[1:]:
+        if 'otf_mfma' in opts:      # two wavelengths share a complex transform: the pairing changes the rounding
+            assert (np.abs(psf - res[0][0]) / peak).max() < 2e-6
+            assert np.abs(fit[:, :, 4] - res[0][1][:, :, 4]).max() < 2e-5
+        else:                       # every stamp is computed on its own: bit for bit
+            np.testing.assert_array_equal(psf, res[0][0])
+            np.testing.assert_array_equal(fit, res[0][1])

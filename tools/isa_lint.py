@@ -12,6 +12,11 @@ instruction of every kernel (it cannot tell compiler instructions from asm ones,
 
   R1  an SGPR written by a VECTOR instruction (v_readfirstlane, v_readlane, v_cmp, carry-outs)
       is not read by a vector-memory instruction (base, soffset, descriptor) within 5 wait states;
+  R1s the same for an LDS-DMA load (which only inline asm issues, with scalar operands the compiler
+      may have produced any way it likes, a v_readlane of a spilled SGPR included), in the strict
+      form the statements are written to: NO vector instruction at all in the 5 wait states
+      before it on any path -- so that the statement is safe wherever the scheduler puts it, not
+      only where it happens to stand in this build (the opening s_nop 4 of every load statement);
   R2  M0 is not written in the wait state before an LDS-DMA instruction that uses it;
   R3  a VGPR written by a (non-MFMA) vector instruction is not read by a v_mfma_* as A, B or C
       within 2 wait states;
@@ -202,6 +207,15 @@ def lint_kernel(name, code):
                     return bool(pj.dst_regs() & sregs) and False
                 walk_back(code, preds, i, 5, v1)
         if ins.is_lds_dma():
+            def v1s(j, between, i=i):
+                pj = code[j]
+                if pj.is_valu() or pj.is_mfma():
+                    out.append(('R1s', name, '%r: vector instruction %r %d wait state(s) before an LDS-DMA load '
+                                             '(its statement must open with s_nop 4)' % (code[i], pj, between)))
+                    return True
+                return False
+            walk_back(code, preds, i, 5, v1s)
+
             def v2(j, between, i=i):
                 pj = code[j]
                 if ('m0',) in pj.dst_regs():
