@@ -691,6 +691,12 @@ def main():
         if cpu is not None:
             out['cpu_baseline'] = cpu
             out['parity'] = parity_block(fitg, cpu_fits.shape[0])
+            pm = load_json('r03_parity_margins.json')
+            if pm and 'wide_parameter_range_vs_oracle' in pm.get('tests', {}):
+                # worst case of tests/test_gpu_parity.py::test_wide_parameter_range_against_the_oracle
+                # (seeing 0.3-2.5", GL 0.02-0.98, L0 8.1-29.9 m), recorded by the test run on the GPU
+                out['parity']['wide_parameter_range'] = dict(
+                    pm['tests']['wide_parameter_range_vs_oracle'], source='profiles/r03_parity_margins.json')
             out['speedup_vs_cpu_baseline'] = round(out['value'] / cpu['value'], 1)
         print(json.dumps(out), flush=True)
     if world > 1:

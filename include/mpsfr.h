@@ -157,6 +157,11 @@ const char* mpsfr_profile_name(int kernel_id);
 int mpsfr_profile_get(mpsfr_ctx* ctx, int kernel_id, double* total_ms, long* launches);
 int mpsfr_profile_reset(mpsfr_ctx* ctx);
 
+/* Number of HIP devices visible to the process (0 if there is none or the runtime fails): what the
+ * drop-in Python layer fans a large SPARTA table out over, one context and one host thread per
+ * device -- the reference's joblib fan-out over worker processes (psfrec.py:1082-1083). */
+int mpsfr_device_count(void);
+
 /* Library/ABI version (major*100 + minor). */
 int mpsfr_version(void);
 

@@ -86,6 +86,8 @@ def load():
     lib.mpsfr_profile_reset.restype = C.c_int
     lib.mpsfr_version.argtypes = []
     lib.mpsfr_version.restype = C.c_int
+    lib.mpsfr_device_count.argtypes = []
+    lib.mpsfr_device_count.restype = C.c_int
     lib.mpsfr_build_id.argtypes = []
     lib.mpsfr_build_id.restype = C.c_char_p
     _lib = lib
@@ -96,7 +98,12 @@ EXPORTS = ['mpsfr_create', 'mpsfr_destroy', 'mpsfr_last_error', 'mpsfr_set_optio
            'mpsfr_reconstruct', 'mpsfr_fit_stamps', 'mpsfr_sync', 'mpsfr_stream', 'mpsfr_wait_event',
            'mpsfr_host_time', 'mpsfr_debug_fetch',
            'mpsfr_profile_count', 'mpsfr_profile_name', 'mpsfr_profile_get',
-           'mpsfr_profile_reset', 'mpsfr_version', 'mpsfr_build_id']
+           'mpsfr_profile_reset', 'mpsfr_version', 'mpsfr_build_id', 'mpsfr_device_count']
+
+
+def device_count():
+    """HIP devices visible to this process (0 without a GPU)."""
+    return int(load().mpsfr_device_count())
 
 
 def _check(rc):

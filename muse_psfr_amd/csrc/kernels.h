@@ -66,15 +66,14 @@ void launch_tel_otf(hipStream_t s, int N, const uint64_t* d_rows, int words, dou
                     void* d_tel, bool f64out);
 void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp,
                        const double* d_aotab, double cfit, void* d_C, const void* d_tw64);
-void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00);
+// d_zero: 17 ints the kernel sets to zero (the work-list counters of launch_mf_prep), or nullptr
+void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00, int* d_zero = nullptr);
 void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,
                         double scale2, void* d_D0t, bool f64out, const void* d_tw64);
 // Pruning of the per-wavelength stage (stage_a.hip, "Line pruning"): minima of D per line
 // ([ntd][N/2+1]) and per block of 16 lines x 32 columns ([ntd][nmt][N/32]), then the lines to keep
 // per (task, wavelength pair) and the block minima over the directions
-// d_zero: 17 ints the kernel sets to zero (the work-list counters of launch_mf_masks), or nullptr
-void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk,
-                 int* d_zero = nullptr);
+void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk);
 void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax);
 void launch_vkeep(hipStream_t s, int N, int ntask, int ndir, int nl, const LamPar* d_lp,
                   const float* d_dline, const float* d_dblk, const float* d_tlmax, float thr_sum,
@@ -106,11 +105,11 @@ size_t mf2_uni_bytes(int N, int ntask, int nl);
 size_t mf2_sched_bytes(int N, int ntask, int nl);
 size_t mf2_part_bytes(int N, int ntask, int nl);
 void mf2_groups(int nl, int permax, int* per, int* ngr);
-// K_MF_MASKS: block masks and the work lists of launch_otf_mfma2; d_sched[0..16] must be zero
-// (launch_dmin does that)
-void launch_mf_masks(hipStream_t s, int N, int ntask, int nl, int permax, const LamPar* d_lp,
-                     const float* d_dminb, const float* d_tlb, float thr, float thr_mid, void* d_own,
-                     void* d_uni, void* d_sched);
+// K_MF_PREP: block masks and the work lists of launch_otf_mfma2 from the block minima of launch_dmin
+// (d_dminb = nullptr: no pruning); d_sched[0..16] must be zero (launch_dc_sum does that)
+void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const LamPar* d_lp,
+                    const float* d_dminb, const float* d_tlb, float thr, float thr_mid, void* d_own,
+                    void* d_uni, void* d_sched);
 // K_OTF_MFMA2 (persistent, ncu workgroups) + K_MF_FINISH
 void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int ncu, const void* d_D0t,
                       const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,

@@ -344,7 +344,13 @@ extern "C" {
 
 const char* mpsfr_last_error(void) { return g_err.c_str(); }
 
-int mpsfr_version(void) { return 101; }
+int mpsfr_version(void) { return 102; }
+
+int mpsfr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
 
 #ifndef MPSFR_BUILD_ID
 #define MPSFR_BUILD_ID "unstamped"
@@ -867,17 +873,21 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         }
         {
             ProfScope ps(c, K_DC_SUM, ls);
-            launch_dc_sum(ls, N, ntd, ln.C.p, (double*)ln.s00.p);
+            launch_dc_sum(ls, N, ntd, ln.C.p, (double*)ln.s00.p, mf2 ? (int*)ln.msched.p : nullptr);
         }
         {
             ProfScope ps(c, K_COLFFT_DPHI, ls);
             launch_colfft_dphi(ls, N, ntd, ln.C.p, (const double*)ln.s00.p, scale2, ln.D0t.p,
                                c->f64, c->tw64.p);
         }
-        if (prune && mf2) {
-            // thin-wave kernel: block minima only (its masks need no line bounds, otf_mfma2.hip)
+        if (mf2) {
+            // thin-wave kernel: block minima (one direction: they are the minima over the directions),
+            // then masks and work lists (otf_mfma2.hip); no line bounds needed
             ProfScope ps(c, K_MF_PREP, ls);
-            launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p, (int*)ln.msched.p);
+            if (prune) launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p);
+            launch_mf_prep(ls, N, tc, nl, c->mf_permax, d_lp, prune ? (const float*)ln.dblk.p : nullptr, (const float*)c->tlb.p,
+                           thr_blk, (prune && c->mf_floor) ? (float)c->mf_mid_log2 : -1.0e30f, ln.mown.p,
+                           ln.muni.p, ln.msched.p);
         } else if (prune) {
             ProfScope ps(c, mf ? K_MF_PREP : K_VKEEP, ls);
             launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p);
@@ -888,16 +898,6 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         }
         const int* d_vkeep = prune ? (const int*)ln.vkeep.p : nullptr;
         if (mf2) {
-            {
-                ProfScope ps(c, K_MF_PREP, ls);
-                // (without pruning K_DMIN, which resets the counters of the work list, has not run)
-                if (!prune) HIPCHK(hipMemsetAsync(ln.msched.p, 0, 17 * sizeof(int), ls));
-                // one direction: the block minima of K_DMIN are the minima over the directions
-                launch_mf_masks(ls, N, tc, nl, c->mf_permax, d_lp, prune ? (const float*)ln.dblk.p : nullptr,
-                                (const float*)c->tlb.p, thr_blk,
-                                (prune && c->mf_floor) ? (float)c->mf_mid_log2 : -1.0e30f, ln.mown.p, ln.muni.p,
-                                ln.msched.p);
-            }
             ProfScope ps(c, K_OTF_MFMA, ls);
             launch_otf_mfma2(ls, N, tc, nl, c->mf_permax, c->ncu, ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
                              c->gtab.p, ln.mown.p, ln.muni.p, ln.msched.p, ln.mpart.p, ln.pre.p,

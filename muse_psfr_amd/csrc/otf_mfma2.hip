@@ -48,11 +48,14 @@ constexpr int kStage2 = kT2 * 4096;     // one staging buffer: 8 x (D 2 KB | log
 constexpr int kSlab = 6 * 1024;         // E slab of one wavelength and k-step: 3 column tiles x (hi | lo)
 
 // ------------------------------------------------------------------------------------------
-// K_MF_MASKS: one workgroup per (task, wavelength group), one wave per wavelength, lane = k-step.
+// K_MF_PREP: one workgroup of 16 waves per task: the block masks of every wavelength and the work
+// items, from the block minima of D (K_DMIN, stage_a.hip; a version that computed them here, one
+// workgroup reading all of a task's D, took 43 us against 12 + 6: a single CU draws 30 GB/s).
+// One wave per wavelength, lane = k-step:
 //   own[task][l][mt][2]   bit ks of word 0: block (mt, ks) is a full block of wavelength l;
 //                         word 1: a mid block (see the file comment)
 //   uni[task][grp][mt]    bit ks: some wavelength of the group keeps the block (what the workgroup
-//                         stages)
+//                         of K_OTF_MFMA2 stages)
 //   ksum[task][l][sw], kuni[task][grp][sw]   the k-steps with work, per sweep of eight m-tiles
 //   gsw[task][grp]        bit sw: the sweep has work
 //   items[cls][]          the work lists of K_OTF_MFMA2: {task, grp, sweep, sweeps of the (task, grp)} of
@@ -67,7 +70,7 @@ constexpr int kSlab = 6 * 1024;         // E slab of one wavelength and k-step: 
 struct MaskArgs {
     int N, nl, per, ngr;
     const LamPar* lp;
-    const float* dminb;      // [ntask][nmt][nks] or nullptr
+    const float* dminb;      // [ntask][nmt][nks] block minima of D (K_DMIN), or nullptr = no pruning
     const float* tlb;        // [nmt][nks]
     float thr, thr_mid;
     u64* own;
@@ -75,81 +78,99 @@ struct MaskArgs {
     u64* ksum;
     u64* kuni;
     int* gsw;
-    int* sched;              // [0..15] items per work class (zeroed by K_DMIN), [16] queue head of K_OTF_MFMA2
+    int* sched;              // [0..15] items per work class (zeroed by K_DC_SUM), [16] queue head of K_OTF_MFMA2
     int4* items;             // [16][cap]
     int cap;                 // ntask ngr nsw
 };
 
-__global__ void __launch_bounds__(512) k_mf_masks(const MaskArgs a) {
-    __shared__ u64 s_any[2][8][kT2];                 // [sweep parity][wavelength slot][m-tile of the sweep]
-    const int grp = blockIdx.x, task = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+constexpr int kPrepWaves = 16;
+constexpr int kMaxNmt = 1280 / 2 / MTL + 1, kMaxNks = 1280 / KBL;      // 41, 40
+
+__global__ void __launch_bounds__(64 * kPrepWaves) k_mf_prep(const MaskArgs a) {
+    constexpr int MAXL = 1024;                       // wavelength factors staged in LDS (more: from memory)
+    constexpr int MAXI = 512;                        // items of a task listed through LDS (more: directly)
+    __shared__ float s_dm[kMaxNmt * kMaxNks], s_tb[kMaxNmt * kMaxNks], s_c2[MAXL];
+    __shared__ u64 s_any[kPrepWaves][kMaxNmt + 7];
+    __shared__ int4 s_item[MAXI];
+    __shared__ int s_nitem;
+    const int task = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int N = a.N, nks = mf_nks(N), nmt = mf_nmt(N), nsw = (nmt + kT2 - 1) / kT2;
-    const int l = grp * a.per + w;
-    const bool lv = l < a.nl;
+    for (int e = threadIdx.x; e < nmt * nks; e += 64 * kPrepWaves) {
+        s_dm[e] = a.dminb != nullptr ? a.dminb[(size_t)task * nmt * nks + e] : 0.f;
+        s_tb[e] = a.tlb[e];
+    }
+    for (int e = threadIdx.x; e < min(a.nl, MAXL); e += 64 * kPrepWaves)
+        s_c2[e] = (float)a.lp[e].c * 1.44269504088896340736f;
+    if (threadIdx.x == 0) s_nitem = 0;
+    __syncthreads();
+    // rounds of gpr wavelength groups, one wave per wavelength
+    const int gpr = kPrepWaves / a.per;
+    const int gi = w / a.per, slot = w - gi * a.per;
     const int kk = min(lane, nks - 1);
-    const float c2 = (float)a.lp[lv ? l : a.nl - 1].c * 1.44269504088896340736f;
-    float dm[kT2], tb[kT2];
-    auto fetch = [&](int sw) {
-#pragma unroll
-        for (int g = 0; g < kT2; ++g) {
-            const int mt = min(sw * kT2 + g, nmt - 1);
-            dm[g] = a.dminb != nullptr ? a.dminb[((size_t)task * nmt + mt) * nks + kk] : 0.f;
-            tb[g] = a.tlb[mt * nks + kk];
-        }
-    };
-    fetch(0);
-    int sweeps = 0, mywork = 0;                       // (wave 0) lane sw keeps the blocks staged in sweep sw
-    for (int sw = 0; sw < nsw; ++sw) {
-        u64 any[kT2], ks_l = 0;
-#pragma unroll
-        for (int g = 0; g < kT2; ++g) {
-            const int mt = sw * kT2 + g;
-            const float e = fmaf(c2, dm[g], tb[g]);
-            const bool keep = lv && lane < nks && mt < nmt && (a.dminb == nullptr || e > a.thr);
-            const bool full = keep && (a.dminb == nullptr || e > a.thr_mid);
-            const u64 bf = __ballot(full), bm = __ballot(keep && !full);
-            if (lane == 0 && lv && mt < nmt) {
-                u64* o = a.own + (((size_t)task * a.nl + l) * nmt + mt) * 2;
-                o[0] = bf;
-                o[1] = bm;
+    for (int g0 = 0; g0 < a.ngr; g0 += gpr) {
+        const int grp = g0 + gi, l = grp * a.per + slot;
+        const bool gv = gi < gpr && grp < a.ngr, lv = gv && l < a.nl;
+        if (gv) {
+            const float c2 = !lv ? 0.f : l < MAXL ? s_c2[l] : (float)a.lp[l].c * 1.44269504088896340736f;
+            u64 myf = 0, mym = 0;                    // lane mt keeps the two words of m-tile mt
+            for (int mt = 0; mt < nmt; ++mt) {
+                const float e = fmaf(c2, s_dm[mt * nks + kk], s_tb[mt * nks + kk]);
+                const bool keep = lv && lane < nks && (a.dminb == nullptr || e > a.thr);
+                const bool full = keep && (a.dminb == nullptr || e > a.thr_mid);
+                const u64 bf = __ballot(full), bm = __ballot(keep && !full);
+                if (lane == mt) { myf = bf; mym = bm; }
             }
-            any[g] = bf | bm;
-            ks_l |= any[g];
-        }
-        if (sw + 1 < nsw) fetch(sw + 1);             // in flight behind the exchange below
-        if (lane == 0) {
-            if (lv) a.ksum[((size_t)task * a.nl + l) * nsw + sw] = ks_l;
+            if (lane < nmt) {
+                if (lv) {                            // one coalesced store of the wavelength's words
+                    ulonglong2* o = reinterpret_cast<ulonglong2*>(a.own + ((size_t)task * a.nl + l) * nmt * 2) + lane;
+                    *o = make_ulonglong2(myf, mym);
+                }
+                s_any[w][lane] = myf | mym;
+            }
+            u64 ks_l = lane < nmt ? (myf | mym) : 0;
 #pragma unroll
-            for (int g = 0; g < kT2; ++g) s_any[sw & 1][w][g] = any[g];
+            for (int o = 1; o < kT2; o <<= 1) ks_l |= __shfl_xor(ks_l, o, 64);
+            if (lv && (lane & 7) == 0 && (lane >> 3) < nsw) a.ksum[((size_t)task * a.nl + l) * nsw + (lane >> 3)] = ks_l;
         }
         __syncthreads();
-        if (w == 0) {                                // lanes 0..7: the group's union per m-tile
+        if (gv && slot == 0) {                       // the group's first wave: lane = m-tile
             u64 u = 0;
-            if (lane < kT2)
-                for (int j = 0; j < a.per; ++j) u |= s_any[sw & 1][j][lane];
-            if (lane < kT2 && sw * kT2 + lane < nmt) a.uni[((size_t)task * a.ngr + grp) * nmt + sw * kT2 + lane] = u;
+            if (lane < nmt)
+                for (int j = 0; j < a.per; ++j) u |= s_any[w + j][lane];
+            if (lane < nmt) a.uni[((size_t)task * a.ngr + grp) * nmt + lane] = u;
             u64 ku = u;
             int pc = __builtin_popcountll(u);
 #pragma unroll
-            for (int o = 1; o < kT2; o <<= 1) {
+            for (int o = 1; o < kT2; o <<= 1) {      // over the eight m-tiles of a sweep
                 ku |= __shfl_xor(ku, o, 64);
                 pc += __shfl_xor(pc, o, 64);
             }
-            if (lane == 0) a.kuni[((size_t)task * a.ngr + grp) * nsw + sw] = ku;
-            if (ku != 0) sweeps |= 1 << sw;          // (uniform over the lanes 0..7)
-            if (lane == sw) mywork = pc;
+            const bool lead = (lane & 7) == 0 && (lane >> 3) < nsw;
+            if (lead) a.kuni[((size_t)task * a.ngr + grp) * nsw + (lane >> 3)] = ku;
+            const u64 has = __ballot(lead && ku != 0);     // bit 8 sw
+            int sweeps = 0;
+#pragma unroll
+            for (int sw = 0; sw < 8; ++sw) sweeps |= (int)((has >> (8 * sw)) & 1) << sw;
+            if (lane == 0) a.gsw[task * a.ngr + grp] = sweeps;
+            if (lead && ku != 0) {
+                // the item, with its work class in .w's upper half: filed after the last round, all
+                // atomics of the task in flight together
+                const int4 it = make_int4(task, grp, lane >> 3, __builtin_popcount(sweeps) | (min(15, pc >> 3) << 16));
+                const int k = atomicAdd(&s_nitem, 1);
+                if (k < MAXI) {
+                    s_item[k] = it;
+                } else {
+                    const int cls = it.w >> 16;
+                    a.items[(size_t)cls * a.cap + atomicAdd(a.sched + cls, 1)] = make_int4(it.x, it.y, it.z, it.w & 0xffff);
+                }
+            }
         }
-        // (s_any is double buffered by sweep parity: the next sweep writes the other half, and the
-        // one after that comes behind the next barrier)
+        __syncthreads();                             // s_any is rewritten by the next round
     }
-    if (w == 0) {
-        sweeps = __builtin_amdgcn_readfirstlane(sweeps);
-        if (lane == 0) a.gsw[task * a.ngr + grp] = sweeps;
-        if (lane < nsw && ((sweeps >> lane) & 1)) {     // one lane per sweep: the atomics overlap
-            const int cls = min(15, mywork >> 3);
-            const int k = atomicAdd(a.sched + cls, 1);
-            a.items[(size_t)cls * a.cap + k] = make_int4(task, grp, lane, __builtin_popcount(sweeps));
-        }
+    for (int k = threadIdx.x; k < min(s_nitem, MAXI); k += 64 * kPrepWaves) {
+        const int4 it = s_item[k];
+        const int cls = it.w >> 16;
+        a.items[(size_t)cls * a.cap + atomicAdd(a.sched + cls, 1)] = make_int4(it.x, it.y, it.z, it.w & 0xffff);
     }
 }
 
@@ -626,10 +647,11 @@ SchedPtrs sched_ptrs(void* d_sched, int ntask, int nl) {
 }
 }  // namespace
 
-// masks of every (task, wavelength) and the work lists (d_sched[0..16] must be zero: launch_dmin)
-void launch_mf_masks(hipStream_t s, int N, int ntask, int nl, int permax, const LamPar* d_lp,
-                     const float* d_dminb, const float* d_tlb, float thr, float thr_mid, void* d_own,
-                     void* d_uni, void* d_sched) {
+// masks of every (task, wavelength) and the work lists (d_sched[0..16] must be zero: launch_dc_sum
+// does that).  d_dminb = nullptr: no pruning.
+void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const LamPar* d_lp,
+                    const float* d_dminb, const float* d_tlb, float thr, float thr_mid, void* d_own,
+                    void* d_uni, void* d_sched) {
     MaskArgs a;
     a.N = N; a.nl = nl;
     mf2_groups(nl, permax, &a.per, &a.ngr);
@@ -641,7 +663,7 @@ void launch_mf_masks(hipStream_t s, int N, int ntask, int nl, int permax, const 
     const SchedPtrs p = sched_ptrs(d_sched, ntask, nl);
     a.gsw = p.gsw; a.sched = p.sched; a.items = p.items;
     a.cap = ntask * a.ngr * (int)mf2_nsw(N);
-    hipLaunchKernelGGL(k_mf_masks, dim3(a.ngr, ntask), dim3(64 * a.per), 0, s, a);
+    hipLaunchKernelGGL(k_mf_prep, dim3(ntask), dim3(64 * kPrepWaves), 0, s, a);
 }
 
 void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int ncu, const void* d_D0t,

@@ -212,10 +212,12 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
 // with su >= 40 stand for two rows.
 template <int N>
 __global__ void __launch_bounds__(256) k_dc_sum(const cx<double>* __restrict__ C,
-                                                double* __restrict__ s00) {
+                                                double* __restrict__ s00, int* __restrict__ zero17) {
     constexpr int NR = psd_rows<N>();
     __shared__ double part[4];
     const int td = blockIdx.x;
+    // the counters of the matrix-core stage's work lists (K_MF_PREP, K_OTF_MFMA2) start from zero
+    if (zero17 != nullptr && td == 0 && threadIdx.x < 17) zero17[threadIdx.x] = 0;
     double s = 0.0;
     for (int r = threadIdx.x; r < NR; r += 256)
         s += (r >= NAO ? 2.0 : 1.0) * C[(size_t)td * (N / 2 + 1) * NR + r].x;
@@ -294,14 +296,11 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
 // minima cost inside K_COLFFT_DPHI, whose column transforms then wait for the reductions.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_dmin(int N, const float* __restrict__ D0t,
-                                              float* __restrict__ dline, float* __restrict__ dblk,
-                                              int* __restrict__ zero2) {
+                                              float* __restrict__ dline, float* __restrict__ dblk) {
     constexpr int MAXKS = 1280 / 32;
     __shared__ int sblk[MAXKS], sline[16];          // bits of non-negative floats: integer order
     const int H1 = N / 2 + 1, nks = N / 32, nmt = (H1 + 15) / 16;
     const int mt = blockIdx.x, td = blockIdx.y;
-    // the counters of the matrix-core stage's work list (K_MF_MASKS, K_OTF_MFMA2) start from zero
-    if (zero2 != nullptr && mt == 0 && td == 0 && threadIdx.x < 17) zero2[threadIdx.x] = 0;
     if (threadIdx.x < MAXKS) sblk[threadIdx.x] = 0x7f800000;
     if (threadIdx.x < 16) sline[threadIdx.x] = 0x7f800000;
     __syncthreads();
@@ -477,10 +476,10 @@ void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d
     })
 }
 
-void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00) {
+void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00, int* d_zero) {
     DISPATCH_N(N, {
         hipLaunchKernelGGL(k_dc_sum<NN>, dim3(ntd), dim3(256), 0, s, (const cx<double>*)d_C,
-                           d_s00);
+                           d_s00, d_zero);
     })
 }
 
@@ -488,10 +487,9 @@ void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax)
     hipLaunchKernelGGL(k_tel_linemax, dim3(N / 2 + 1), dim3(256), 0, s, N, (const float*)d_tel, d_tlmax);
 }
 
-void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk,
-                 int* d_zero2) {
+void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk) {
     hipLaunchKernelGGL(k_dmin, dim3((N / 2 + 1 + 15) / 16, ntd), dim3(256), 0, s, N, (const float*)d_D0t,
-                       d_dline, d_dblk, d_zero2);
+                       d_dline, d_dblk);
 }
 
 void launch_task_order(hipStream_t s, int ntask, int nl, const int* d_vkeep, int* d_order) {

@@ -102,9 +102,10 @@ def host_cutoff_masks():
 _contexts = {}
 
 
-def get_context(dim=1280, pixscale=0.2, dimpsf=40, precision='mixed', device=0):
-    """Cached GPU context for (dim, pixscale, dimpsf, precision, device)."""
-    key = (int(dim), float(pixscale), int(dimpsf), precision, int(device))
+def get_context(dim=1280, pixscale=0.2, dimpsf=40, precision='mixed', device=0, replica=0):
+    """Cached GPU context for (dim, pixscale, dimpsf, precision, device); `replica` > 0: a further
+    context on the same device (fan-out tests run two shards on one GPU)."""
+    key = (int(dim), float(pixscale), int(dimpsf), precision, int(device), int(replica))
     if key not in _contexts:
         _contexts[key] = Context(dim=dim, pixscale=pixscale, dimpsf=dimpsf, precision=precision,
                                  device=device)
@@ -121,16 +122,65 @@ def _resolve_masks(cutoff_masks):
     return cutoff_masks
 
 
+# Fan-out over several GPUs pays from this many tasks per device (a 100-row batch takes 0.3 ms)
+FANOUT_MIN_TASKS_PER_DEVICE = 32
+
+
+def _fanout_devices(devices, device, ntask, n_jobs):
+    """The devices a batch of `ntask` tasks runs on.  devices=None: every visible GPU when the
+    batch is large enough and the caller did not ask for one job (n_jobs = 1; n_jobs > 1 caps the
+    number of devices, like it caps the reference's worker processes, psfrec.py:1082); an explicit
+    list is taken as given (repeats allowed: several contexts on one GPU)."""
+    if devices is not None:
+        devs = [int(d) for d in devices]
+        if not devs:
+            raise ValueError('devices must not be empty')
+        return devs
+    if n_jobs == 1:
+        return [int(device)]
+    from ._lib import device_count
+    n = device_count()
+    if n_jobs is not None and n_jobs > 1:
+        n = min(n, int(n_jobs))
+    n = min(n, ntask // FANOUT_MIN_TASKS_PER_DEVICE)
+    if n <= 1:
+        return [int(device)]
+    return list(range(n))
+
+
 def _reconstruct(lbda, tasks, npsflin, h, dim, dimpsf, pixscale, precision, cutoff_masks, device,
-                 want_psf=True):
-    ctx = get_context(dim, pixscale, dimpsf, precision, device)
+                 want_psf=True, devices=None, n_jobs=1):
     see = np.array([t[0] for t in tasks], dtype=float)
     gl = np.array([t[1] for t in tasks], dtype=float)
     l0 = np.array([t[2] for t in tasks], dtype=float)
     three = np.array([1 if t[3] else 0 for t in tasks], dtype=np.uint8)
+    masks = _resolve_masks(cutoff_masks)
+    devs = _fanout_devices(devices, device, len(tasks), n_jobs)
+
+    def run(dev, replica, a, b):
+        ctx = get_context(dim, pixscale, dimpsf, precision, dev, replica)
+        return ctx.reconstruct(lbda, see[a:b], gl[a:b], l0[a:b], three[a:b], h, npsflin=npsflin,
+                               masks=masks, want_psf=want_psf)
     try:
-        return ctx.reconstruct(lbda, see, gl, l0, three, h, npsflin=npsflin,
-                               masks=_resolve_masks(cutoff_masks), want_psf=want_psf)
+        if len(devs) == 1:
+            return run(devs[0], 0, 0, len(tasks))
+        # Row shards over the devices, one host thread and one context per device (ctypes releases
+        # the GIL for the call): the reference's joblib fan-out (psfrec.py:1082-1083).  Per-task
+        # results do not depend on the sharding; the stamp sums are added in device order.
+        from concurrent.futures import ThreadPoolExecutor
+        from .distributed import shard_bounds
+        bounds = [bd for bd in shard_bounds(len(tasks), len(devs)) if bd[1] > bd[0]]
+        replica = [devs[:i].count(d) for i, d in enumerate(devs)]
+        with ThreadPoolExecutor(len(bounds)) as pool:
+            futs = [pool.submit(run, devs[i], replica[i], a, b) for i, (a, b) in enumerate(bounds)]
+            parts = [f.result() for f in futs]
+        out = {'fit': np.concatenate([p['fit'] for p in parts], axis=0),
+               'psf': np.concatenate([p['psf'] for p in parts], axis=0) if want_psf else None}
+        psum = parts[0]['psf_sum'].copy()
+        for p in parts[1:]:
+            psum += p['psf_sum']
+        out['psf_sum'] = psum
+        return out
     except MpsfrError as e:
         if e.code == E_GRID:
             # the reference fails here with a ValueError from scipy's interpn (psfrec.py:663-683)
@@ -217,13 +267,16 @@ def _table_hdu(cols, meta, name):
 def compute_psf_from_sparta(filename, extname='SPARTA_ATM_DATA', npsflin=1, lmin=490, lmax=930,
                             nl=35, lbda=None, h=(100, 10000), n_jobs=-1, plot=False,
                             mean_of_lgs=True, verbose=True, *, dim=1280, dimpsf=40, pixscale=0.2,
-                            precision='mixed', cutoff_masks='host', device=0):
+                            precision='mixed', cutoff_masks='host', device=0, devices=None):
     """Reconstruct a PSF from SPARTA data (psfrec.py:981-1120).
 
     ``filename`` is a FITS path or an already opened HDUList.  Returns an HDUList with
     PRIMARY, a copy of the SPARTA extension, FIT_ROWS, FIT_MEAN and PSF_MEAN -- or ``None``
-    (with a 'No valid values' warning) when no row has a valid laser.  ``n_jobs`` is accepted for
-    compatibility; the rows are processed as one GPU batch."""
+    (with a 'No valid values' warning) when no row has a valid laser.  The rows are processed as one
+    GPU batch -- or, like the reference's ``n_jobs`` worker processes (psfrec.py:1082-1083), as one
+    batch per GPU: ``devices=None`` takes every visible GPU when the table has at least
+    FANOUT_MIN_TASKS_PER_DEVICE tasks per device (``n_jobs`` = 1 keeps one device, ``n_jobs`` > 1 caps
+    their number); ``devices=[...]`` names them.  The per-row results do not depend on the split."""
     fits, _ = _astropy()
     io_mod = fits if fits is not None else _minifits
     opened = False
@@ -292,7 +345,7 @@ def compute_psf_from_sparta(filename, extname='SPARTA_ATM_DATA', npsflin=1, lmin
                 logger.info('Using three lasers mode')
 
     r = _reconstruct(lbda, to_compute, npsflin, h, dim, dimpsf, pixscale, precision, cutoff_masks,
-                     device, want_psf=False)
+                     device, want_psf=False, devices=devices, n_jobs=n_jobs)
     ntask, nlam = len(to_compute), lbda.size
 
     # FIT_ROWS: the per-task tables stacked (psfrec.py:1086-1101)

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 tag=$1; shift
 OUT=$PWD/gpurun_out/trace_$tag; mkdir -p $OUT
 for kv in "$@"; do export "$kv"; done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 10 --warmup 2 --cpu-rows 0 --f64-steps 0 --profile-steps 0 --unpruned-steps 0 --streams 1 > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 10 --warmup 2 --cpu-rows 0 --f64-steps 0 --profile-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --streams 1 > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }
 f=$(ls $OUT/*/*kernel_stats.csv | head -1); cp $f $OUT/kernel_stats.csv
 python3 - "$OUT/kernel_stats.csv" <<'PY'
 import csv, sys

