@@ -73,8 +73,10 @@ void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const do
 // Pruning of the per-wavelength stage (stage_a.hip, "Line pruning"): minima of D per line
 // ([ntd][N/2+1]) and per block of 16 lines x 32 columns ([ntd][nmt][N/32]), then the lines to keep
 // per (task, wavelength pair) and the block minima over the directions
-void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk);
-void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax);
+// (f64: D / the telescope OTF are double; the minima are rounded down, the maxima up)
+void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk,
+                 bool f64 = false);
+void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax, bool f64 = false);
 void launch_vkeep(hipStream_t s, int N, int ntask, int ndir, int nl, const LamPar* d_lp,
                   const float* d_dline, const float* d_dblk, const float* d_tlmax, float thr_sum,
                   int* d_vkeep, int fixed, float* d_dminb);
@@ -135,10 +137,11 @@ void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, c
 void launch_conv(hipStream_t s, int ntask, int nl, const void* d_pre, const void* d_ktt,
                  const void* d_kmuse, double* d_fin, bool f64);
 void launch_khat(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
-                 void* d_khat);
+                 void* d_khat, bool f64 = false);
 // fin_f32 / stamps_f32: the final stamps are float (inside the pipeline) instead of double
+// f64: double stamps in and out, fp64 transforms, khat tables of complex double
 void launch_conv_fft(hipStream_t s, int ntask, int nl, const void* d_pre, const void* d_khat_tt,
-                     const void* d_khat_muse, void* d_fin, bool fin_f32);
+                     const void* d_khat_muse, void* d_fin, bool fin_f32, bool f64 = false);
 void launch_fit(hipStream_t s, int nstamp, const void* d_stamps, bool stamps_f32, double* d_fit,
                 bool f64);
 void launch_stamp_sum(hipStream_t s, int ntask, int nl, const void* d_fin, bool fin_f32, double* d_sum,

@@ -72,6 +72,7 @@ struct mpsfr_ctx {
     bool fft_conv = true;   // mixed mode: convolutions through 64-point FFTs
     int prune_fixed = 0;         // experiments: transform exactly this many lines (wrong results)
     double prune_eps = 1.0e-9;   // mixed mode: line pruning of the per-wavelength stage (0 = off)
+    double prune_eps_f64 = 1.0e-13;  // f64 mode: the same, far below what its 1e-11 stamps resolve
     bool otf_mfma = true;        // mixed mode: per-wavelength stage on the matrix cores (otf_mfma.hip)
     bool mf_floor = true;        // matrix-core stage: skip blocks below the fp16 representation floor
     int mf_kernel = 2;           // 2: thin-wave kernel with precision tiers (otf_mfma2.hip, one direction); 1: otf_mfma.hip
@@ -325,9 +326,10 @@ int build_constant_tables(mpsfr_ctx* c) {
         launch_tel_otf(c->stream, N, (const uint64_t*)c->rows.p, words, (double)pupsum, c->tel.p,
                        c->f64);
     }
-    if (!c->f64) {      // log2 of the line maxima of the telescope OTF (line pruning, stage_a.hip)
-        if ((rc = ensure(c, c->tlmax, (size_t)(H + 1) * sizeof(float)))) return rc;
-        launch_tel_linemax(c->stream, N, c->tel.p, (float*)c->tlmax.p);
+    // log2 of the line maxima of the telescope OTF (line pruning, stage_a.hip)
+    if ((rc = ensure(c, c->tlmax, (size_t)(H + 1) * sizeof(float)))) return rc;
+    launch_tel_linemax(c->stream, N, c->tel.p, (float*)c->tlmax.p, c->f64);
+    if (!c->f64) {
         // log2 of the telescope OTF and of its block maxima (otf_mfma.hip)
         if ((rc = ensure(c, c->tl2, mf_tl2_bytes(N)))) return rc;
         if ((rc = ensure(c, c->tlb, mf_tlb_bytes(N)))) return rc;
@@ -445,6 +447,9 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         c->nlanes = (int)value;
     } else if (!strcmp(key, "prune_fixed")) {
         c->prune_fixed = (int)value;
+    } else if (!strcmp(key, "prune_eps_f64")) {
+        if (!(value >= 0.0) || value > 1.0e-6) return fail(MPSFR_E_INVALID, "prune_eps_f64 must be in [0, 1e-6]");
+        c->prune_eps_f64 = value;
     } else if (!strcmp(key, "prune_eps")) {
         if (!(value >= 0.0) || value > 1.0e-3) return fail(MPSFR_E_INVALID, "prune_eps must be in [0, 1e-3]");
         c->prune_eps = value;
@@ -660,8 +665,8 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     }
     if (!sl.staged) HIPCHK(hipEventCreateWithFlags(&sl.staged, hipEventDisableTiming));
     if (!sl.call_done) HIPCHK(hipEventCreateWithFlags(&sl.call_done, hipEventDisableTiming));
-    const bool use_fft_conv = !c->f64 && c->fft_conv;
-    const size_t ksz = use_fft_conv ? (size_t)KHAT * 2 * sizeof(float) : (size_t)KS * KS * rsize(c);
+    const bool use_fft_conv = c->fft_conv;      // (f64 mode: the same transforms in fp64)
+    const size_t ksz = use_fft_conv ? (size_t)KHAT * 2 * rsize(c) : (size_t)KS * KS * rsize(c);
     if ((rc = ensure(c, sl.params, blob))) return rc;
     if ((rc = ensure(c, sl.ktt, (size_t)ntask * ksz))) return rc;
     char* hb = (char*)sl.host;
@@ -762,7 +767,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
                 if (mf) launch_mf_tables(s0, N, nl, d_lp, c->tw64.p, c->etab.p, c->gtab.p);
             }
             ProfScope ps(c, K_MOFFAT_KERNELS, s0);
-            if (use_fft_conv) launch_khat(s0, nl, d_gam + ntask, d_alp + ntask, c->kmuse.p);
+            if (use_fft_conv) launch_khat(s0, nl, d_gam + ntask, d_alp + ntask, c->kmuse.p, c->f64);
             else launch_moffat_kernels(s0, nl, d_gam + ntask, d_alp + ntask, c->kmuse.p, c->f64);
             c->cache_lbda = lb_key;
             c->cache_lbda_mode = use_fft_conv ? 1 : 0;
@@ -785,7 +790,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         // the column-transform kernel both LOWER the two-lane throughput, by 2-4 %: the short
         // serial kernels keep the two lanes out of phase.)
         ProfScope ps(c, K_MOFFAT_KERNELS, s0);
-        if (use_fft_conv) launch_khat(s0, ntask, d_gam, d_alp, sl.ktt.p);   // [n][33][64] complex
+        if (use_fft_conv) launch_khat(s0, ntask, d_gam, d_alp, sl.ktt.p, c->f64);   // [n][33][64] complex
         else launch_moffat_kernels(s0, ntask, d_gam, d_alp, sl.ktt.p, c->f64);
     }
 
@@ -794,12 +799,13 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     // Line pruning of the per-wavelength stage (mixed mode): the trailing lines of the OTF half
     // plane that together weigh less than eps of the PSF peak are neither transformed nor read
     // by the second pass (stage_a.hip, "Line pruning").
-    const bool prune = !c->f64 && c->prune_eps > 0.0;
+    const double eps_prune = c->f64 ? c->prune_eps_f64 : c->prune_eps;
+    const bool prune = eps_prune > 0.0;
     // matrix-core path: half of eps for the lines, half for the 16 x 32 blocks inside them (every
     // element of a dropped block is below 2^thr_blk; both half planes, all directions)
-    const float thr_sum = prune ? (float)((mf ? 0.5 : 1.0) * c->prune_eps / (2.0 * N * ndir)) : 0.f;
+    const float thr_sum = prune ? (float)((mf ? 0.5 : 1.0) * eps_prune / (2.0 * N * ndir)) : 0.f;
     float thr_blk = (prune && mf)
-        ? (float)std::log2(0.5 * c->prune_eps / (2.0 * ndir * 16 * 32 * mf_block_count(N))) : 0.f;
+        ? (float)std::log2(0.5 * eps_prune / (2.0 * ndir * 16 * 32 * mf_block_count(N))) : 0.f;
     // Representation floor of the split-fp16 operands: the OTF is generated times 2^15, so an element
     // below 2^-29 of OTF[0][0] has both fp16 halves in the subnormal range, which the matrix cores
     // flush to zero -- a block whose bound is below 2^-29.01 contributes exactly nothing, and skipping
@@ -890,7 +896,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
                            ln.muni.p, ln.msched.p);
         } else if (prune) {
             ProfScope ps(c, mf ? K_MF_PREP : K_VKEEP, ls);
-            launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p);
+            launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p, c->f64);
             launch_vkeep(ls, N, tc, ndir, nl, d_lp, (const float*)ln.dmin.p, (const float*)ln.dblk.p,
                          (const float*)c->tlmax.p, thr_sum, (int*)ln.vkeep.p, c->prune_fixed,
                          mf ? (float*)ln.dminb.p : nullptr);
@@ -920,14 +926,14 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         }
         // final stamps: straight into the caller's device buffer (double), else a lane workspace --
         // float when the FFT convolution produces them and nobody outside reads them
-        const bool fin_f32 = use_fft_conv && !d_fin_all && !(psf_out && !dev_out);
+        const bool fin_f32 = use_fft_conv && !c->f64 && !d_fin_all && !(psf_out && !dev_out);
         void* d_fin = d_fin_all ? (void*)(d_fin_all + (size_t)t0 * nl * per_stamp) : ln.fin.p;
         {
             ProfScope ps(c, K_CONV, ls);
             const size_t koff = (size_t)t0 * ksz;
             if (use_fft_conv)
                 launch_conv_fft(ls, tc, nl, ln.pre.p, (const char*)sl.ktt.p + koff,
-                                c->kmuse.p, d_fin, fin_f32);
+                                c->kmuse.p, d_fin, fin_f32, c->f64);
             else
                 launch_conv(ls, tc, nl, ln.pre.p, (const char*)sl.ktt.p + koff,
                             c->kmuse.p, (double*)d_fin, c->f64);
@@ -1104,8 +1110,8 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
         for (size_t i = 0; i < n; ++i) out[i] = (double)tmp[i];
         return (long)n;
     } else if (!strcmp(what, "vkeep")) {
-        if (c->f64 || !(c->prune_eps > 0.0) || c->last_mf2)
-            return fail(MPSFR_E_INVALID, "line pruning is off (f64 mode, prune_eps = 0, or the block-masked "
+        if (!c->last_pruned || c->last_mf2)
+            return fail(MPSFR_E_INVALID, "no line pruning in the last call (prune_eps = 0, or the block-masked "
                                          "matrix-core kernel ran)");
         n = (size_t)c->last_chunk_tasks * ((c->last_nl + 1) / 2);
         if (n > capacity) return fail(MPSFR_E_INVALID, "capacity %zu < %zu", capacity, n);

@@ -491,7 +491,7 @@ k_otf_r16(int ndir, int nl, const float* __restrict__ D0t, const float* __restri
 template <typename R, int N>
 __global__ void __launch_bounds__(256)
 k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
-          R* __restrict__ pre) {
+          R* __restrict__ pre, const int* __restrict__ vkeep) {
     constexpr int VW = 8, VB = 4 * VW, TI = 3, TJ = 5, NV = N / 2 + 1;
     constexpr int NPQ = NSH * NS;                 // 840 (P, Q) pairs
     static_assert(NSH == 7 * TI && NS == 8 * TJ, "tile map");
@@ -510,6 +510,8 @@ k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
     const int i0 = TI * (act ? lane >> 3 : 0), j0 = TJ * (lane & 7);
     const cx<R>* Tp = Tq + ((size_t)task * nl + l) * tq_block<R>(N);
     const cx<R>* Gp = G + (size_t)l * g_lines(N) * NS;
+    // line pruning (stage_a.hip): lines at and beyond vkeep[task][pair] were never written
+    const int nv = vkeep != nullptr ? min(NV, vkeep[(size_t)task * ((nl + 1) / 2) + (l >> 1)]) : NV;
     R accP[TI][TJ], accQ[TI][TJ];
 #pragma unroll
     for (int a = 0; a < TI; ++a)
@@ -521,7 +523,7 @@ k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
 #pragma unroll
         for (int k = 0; k < NET; ++k) {
             const int e = threadIdx.x + k * 256;
-            rt[k] = (e < VB * NSH && v0 * NSH + e < NV * NSH) ? Tp[(size_t)v0 * NSH + e]
+            rt[k] = (e < VB * NSH && v0 * NSH + e < nv * NSH) ? Tp[(size_t)v0 * NSH + e]
                                                             : cx<R>{(R)0, (R)0};
         }
 #pragma unroll
@@ -531,7 +533,7 @@ k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
         }
     };
     fetch(0);
-    for (int v0 = 0; v0 < NV; v0 += VB) {
+    for (int v0 = 0; v0 < nv; v0 += VB) {
 #pragma unroll
         for (int k = 0; k < NET; ++k) {
             const int e = threadIdx.x + k * 256;
@@ -540,7 +542,7 @@ k_colpass(int nl, const cx<R>* __restrict__ Tq, const cx<R>* __restrict__ G,
 #pragma unroll
         for (int k = 0; k < NEG; ++k) (&sG[0][0])[threadIdx.x + k * 256] = rg[k];
         __syncthreads();
-        if (v0 + VB < NV) fetch(v0 + VB);      // prefetch the next block behind the FMAs
+        if (v0 + VB < nv) fetch(v0 + VB);      // prefetch the next block behind the FMAs
 #pragma unroll
         for (int vb = 0; vb < VW; ++vb) {
             const int vr = wave * VW + vb;
@@ -886,7 +888,7 @@ void launch_colpass(hipStream_t s, int N, int ntask, int nl, const void* d_Tq, c
     DISPATCH_N(N, {
         if (f64)
             hipLaunchKernelGGL((k_colpass<double, NN>), grid, dim3(256), 0, s, nl,
-                               (const cx<double>*)d_Tq, (const cx<double>*)d_G, (double*)d_pre);
+                               (const cx<double>*)d_Tq, (const cx<double>*)d_G, (double*)d_pre, d_vkeep);
         else
             hipLaunchKernelGGL((k_colpass_m<NN>), dim3(nl, (ntask + 2) / 3), dim3(256), 0, s, ntask,
                                nl, (const cx<float>*)d_Tq, (const cx<float>*)d_G, (float*)d_pre, d_vkeep);

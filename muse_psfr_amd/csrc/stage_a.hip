@@ -295,8 +295,27 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
 // written, read back from the cache hierarchy at ~10 us per 52 MB) costs a third of what the same
 // minima cost inside K_COLFFT_DPHI, whose column transforms then wait for the reductions.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_dmin(int N, const float* __restrict__ D0t,
+// (T = float: mixed mode; T = double: f64 mode -- the minima are rounded DOWN to float, so that the
+// bounds built from them stay upper bounds)
+template <typename T> struct DminVec;
+template <> struct DminVec<float> {
+    typedef float4 V;
+    static constexpr int W = 4;
+    static __device__ __forceinline__ float vmin(const V& d) {
+        return fminf(fminf(d.x, d.y), fminf(d.z, d.w));
+    }
+};
+template <> struct DminVec<double> {
+    typedef double2 V;
+    static constexpr int W = 2;
+    static __device__ __forceinline__ float vmin(const V& d) { return __double2float_rd(fmin(d.x, d.y)); }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_dmin(int N, const T* __restrict__ D0t,
                                               float* __restrict__ dline, float* __restrict__ dblk) {
+    using DV = DminVec<T>;
+    constexpr int VPB = 32 / DV::W;                  // consecutive vectors of one block of 32 columns
     constexpr int MAXKS = 1280 / 32;
     __shared__ int sblk[MAXKS], sline[16];          // bits of non-negative floats: integer order
     const int H1 = N / 2 + 1, nks = N / 32, nmt = (H1 + 15) / 16;
@@ -304,18 +323,16 @@ __global__ void __launch_bounds__(256) k_dmin(int N, const float* __restrict__ D
     if (threadIdx.x < MAXKS) sblk[threadIdx.x] = 0x7f800000;
     if (threadIdx.x < 16) sline[threadIdx.x] = 0x7f800000;
     __syncthreads();
-    const int nq = N / 4;                            // float4 per line
-    const float4* src = reinterpret_cast<const float4*>(D0t + ((size_t)td * H1 + 16 * mt) * N);
+    const int nq = N / DV::W;                        // vectors per line
+    const typename DV::V* src = reinterpret_cast<const typename DV::V*>(D0t + ((size_t)td * H1 + 16 * mt) * N);
     const int nline = min(16, H1 - 16 * mt);
     for (int f = threadIdx.x; f < nline * nq; f += 256) {
-        const float4 d = src[f];
-        float m = fmaxf(fminf(fminf(d.x, d.y), fminf(d.z, d.w)), 0.f);
-        // eight consecutive float4 are one block of 32 columns (nq is a multiple of 8)
-        m = fminf(m, __shfl_xor(m, 1, 64));
-        m = fminf(m, __shfl_xor(m, 2, 64));
-        m = fminf(m, __shfl_xor(m, 4, 64));
-        if ((threadIdx.x & 7) == 0) {
-            const int line = f / nq, kb = (f - line * nq) >> 3;
+        float m = fmaxf(DV::vmin(src[f]), 0.f);
+        // VPB consecutive vectors are one block of 32 columns (nq is a multiple of VPB)
+#pragma unroll
+        for (int o = 1; o < VPB; o <<= 1) m = fminf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & (VPB - 1)) == 0) {
+            const int line = f / nq, kb = (f - line * nq) / VPB;
             atomicMin(&sblk[kb], __float_as_int(m));
             atomicMin(&sline[line], __float_as_int(m));
         }
@@ -337,12 +354,14 @@ __global__ void __launch_bounds__(256) k_dmin(int N, const float* __restrict__ D
 // with seeing-limited PSFs most of the half plane is far below fp32 resolution (bench workload:
 // 46 % of the lines survive eps = 1e-9; 81 % are not identically zero in fp32).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_tel_linemax(int N, const float* __restrict__ telT,
+template <typename T>
+__global__ void __launch_bounds__(256) k_tel_linemax(int N, const T* __restrict__ telT,
                                                      float* __restrict__ tlmax) {
     __shared__ float part[4];
     const int v = blockIdx.x;
     float m = 0.f;
-    for (int u = threadIdx.x; u < N; u += 256) m = fmaxf(m, telT[(size_t)v * N + u]);
+    // (double: rounded UP to float -- the bound stays an upper bound)
+    for (int u = threadIdx.x; u < N; u += 256) m = fmaxf(m, __double2float_ru((double)telT[(size_t)v * N + u]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
@@ -483,13 +502,19 @@ void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00
     })
 }
 
-void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax) {
-    hipLaunchKernelGGL(k_tel_linemax, dim3(N / 2 + 1), dim3(256), 0, s, N, (const float*)d_tel, d_tlmax);
+void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax, bool f64) {
+    if (f64)
+        hipLaunchKernelGGL(k_tel_linemax<double>, dim3(N / 2 + 1), dim3(256), 0, s, N, (const double*)d_tel, d_tlmax);
+    else
+        hipLaunchKernelGGL(k_tel_linemax<float>, dim3(N / 2 + 1), dim3(256), 0, s, N, (const float*)d_tel, d_tlmax);
 }
 
-void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk) {
-    hipLaunchKernelGGL(k_dmin, dim3((N / 2 + 1 + 15) / 16, ntd), dim3(256), 0, s, N, (const float*)d_D0t,
-                       d_dline, d_dblk);
+void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk, bool f64) {
+    const dim3 grid((N / 2 + 1 + 15) / 16, ntd);
+    if (f64)
+        hipLaunchKernelGGL(k_dmin<double>, grid, dim3(256), 0, s, N, (const double*)d_D0t, d_dline, d_dblk);
+    else
+        hipLaunchKernelGGL(k_dmin<float>, grid, dim3(256), 0, s, N, (const float*)d_D0t, d_dline, d_dblk);
 }
 
 void launch_task_order(hipStream_t s, int ntask, int nl, const int* d_vkeep, int* d_order) {

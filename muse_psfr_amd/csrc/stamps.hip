@@ -199,152 +199,165 @@ __constant__ float2 kTw64[64] = {
     {9.807852804e-01f, 1.950903220e-01f}, {9.951847267e-01f, 9.801714033e-02f},
 };
 
+template <typename R>
 struct Tw64 {
-    cx<float> w[7];
+    cx<R> w[7];
     __device__ __forceinline__ void init(int t) {
 #pragma unroll
         for (int q = 1; q < 8; ++q) {
-            const float2 v = kTw64[(q * t) & 63];
-            w[q - 1] = {v.x, v.y};
+            if constexpr (sizeof(R) == 4) {
+                const float2 v = kTw64[(q * t) & 63];
+                w[q - 1] = {v.x, v.y};
+            } else {                 // f64 mode: the table has float digits only
+                double sn, cs;
+                sincospi(-(double)((q * t) & 63) / 32.0, &sn, &cs);
+                w[q - 1] = {cs, sn};
+            }
         }
     }
 };
 
-__device__ __forceinline__ cx<float> conjf(cx<float> a) { return {a.x, -a.y}; }
+template <typename R>
+__device__ __forceinline__ cx<R> conjf(cx<R> a) { return {a.x, -a.y}; }
 
 // rows ra = 2 slot, rb = ra + 1 of a real image, x[e] = (row ra, row rb) at column t + 8 e (zero
 // beyond the image) -> half spectra in F
-__device__ __forceinline__ void cf_rows_forward(const cx<float>* x, cx<float> (*F)[CFP],
-                                                cx<float>* buf, const Tw64& tw, int slot, int t) {
+template <typename R>
+__device__ __forceinline__ void cf_rows_forward(const cx<R>* x, cx<R> (*F)[CFP],
+                                                cx<R>* buf, const Tw64<R>& tw, int slot, int t) {
     const int ra = 2 * slot, rb = ra + 1;
-    const cx<float>* res = fft_forward_regs<float, CF, true>(x, buf, buf, tw.w, t);
+    const cx<R>* res = fft_forward_regs<R, CF, true>(x, buf, buf, tw.w, t);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int k = t + 8 * e;
-        const cx<float> zk = res[lds_out<CF, 8>(k)], zm = res[lds_out<CF, 8>((CF - k) % CF)];
+        const cx<R> zk = res[lds_out<CF, 8>(k)], zm = res[lds_out<CF, 8>((CF - k) % CF)];
         if (k == 0) {
-            const cx<float> zn = res[lds_out<CF, 8>(CFH)];
+            const cx<R> zn = res[lds_out<CF, 8>(CFH)];
             F[ra][0] = {zk.x, zn.x};      // (DC, Nyquist) of row ra, both real
             F[rb][0] = {zk.y, zn.y};
         } else {
-            F[ra][k] = {0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
-            F[rb][k] = {0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};
+            F[ra][k] = {(R)0.5 * (zk.x + zm.x), (R)0.5 * (zk.y - zm.y)};
+            F[rb][k] = {(R)0.5 * (zk.y + zm.y), -(R)0.5 * (zk.x - zm.x)};
         }
     }
 }
 
 // column `slot` of F (rows < nrow_in non-zero) -> forward transform along the rows, in `buf`
-__device__ __forceinline__ const cx<float>* cf_col_forward(cx<float> (*F)[CFP], int nrow_in,
-                                                           cx<float>* buf, const Tw64& tw,
-                                                           int slot, int t) {
-    cx<float> x[8];
+template <typename R>
+__device__ __forceinline__ const cx<R>* cf_col_forward(cx<R> (*F)[CFP], int nrow_in,
+                                                       cx<R>* buf, const Tw64<R>& tw,
+                                                       int slot, int t) {
+    cx<R> x[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int r = t + 8 * e;
-        x[e] = r < nrow_in ? F[r][slot] : cx<float>{0.f, 0.f};
+        x[e] = r < nrow_in ? F[r][slot] : cx<R>{(R)0, (R)0};
     }
-    return fft_forward_regs<float, CF, true>(x, buf, buf, tw.w, t);
+    return fft_forward_regs<R, CF, true>(x, buf, buf, tw.w, t);
 }
 
 // split the packed column 0 spectrum into the DC column and the Nyquist column at kx
-__device__ __forceinline__ void cf_split0(const cx<float>* res, int kx, cx<float>& a0,
-                                          cx<float>& a32) {
-    const cx<float> p = res[lds_out<CF, 8>(kx)], pm = res[lds_out<CF, 8>((CF - kx) % CF)];
-    a0 = {0.5f * (p.x + pm.x), 0.5f * (p.y - pm.y)};
-    a32 = {0.5f * (p.y + pm.y), -0.5f * (p.x - pm.x)};
+template <typename R>
+__device__ __forceinline__ void cf_split0(const cx<R>* res, int kx, cx<R>& a0,
+                                          cx<R>& a32) {
+    const cx<R> p = res[lds_out<CF, 8>(kx)], pm = res[lds_out<CF, 8>((CF - kx) % CF)];
+    a0 = {(R)0.5 * (p.x + pm.x), (R)0.5 * (p.y - pm.y)};
+    a32 = {(R)0.5 * (p.y + pm.y), -(R)0.5 * (p.x - pm.x)};
 }
 
 // TF: type of the final stamps -- float inside the pipeline (their values are float anyway: the fit
 // and the stamp sum read half the bytes), double when they go straight into the caller's psf_out.
-template <typename TF>
+// R: arithmetic type (float: mixed mode; double: f64 mode, 74 KB of LDS).
+template <typename R, typename TF>
 __global__ void __launch_bounds__(256)
-k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ khat_tt,
-           const cx<float>* __restrict__ khat_muse, TF* __restrict__ fin) {
-    __shared__ cx<float> F[CF][CFP];
-    __shared__ cx<float> bufs[CFH][CFB];
+k_conv_fft(int nl, const R* __restrict__ pre, const cx<R>* __restrict__ khat_tt,
+           const cx<R>* __restrict__ khat_muse, TF* __restrict__ fin) {
+    extern __shared__ __align__(16) unsigned char conv_smem[];
+    cx<R> (*F)[CFP] = reinterpret_cast<cx<R> (*)[CFP]>(conv_smem);
+    cx<R> (*bufs)[CFB] = reinterpret_cast<cx<R> (*)[CFB]>(conv_smem + sizeof(cx<R>) * CF * CFP);
     const int l = blockIdx.x, task = blockIdx.y;
     const int slot = threadIdx.x >> 3, t = threadIdx.x & 7;
-    Tw64 tw;
+    Tw64<R> tw;
     tw.init(t);
-    const float* src = pre + ((size_t)task * nl + l) * NS * NS;
-    cx<float>* buf = bufs[slot];
+    const R* src = pre + ((size_t)task * nl + l) * NS * NS;
+    cx<R>* buf = bufs[slot];
     // The image never sits in LDS: a slot reads its row pair of the input from global memory, and
     // the rows it produces in the first convolution are exactly the ones it transforms in the
     // second (taken from its own line buffer).
-    cx<float> x[8];
+    cx<R> x[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = t + 8 * e;
         const bool in = c < NS && slot < NS / 2;
-        x[e] = {in ? src[2 * slot * NS + c] : 0.f, in ? src[(2 * slot + 1) * NS + c] : 0.f};
+        x[e] = {in ? src[2 * slot * NS + c] : (R)0, in ? src[(2 * slot + 1) * NS + c] : (R)0};
     }
     for (int pass = 0; pass < 2; ++pass) {
-        const cx<float>* __restrict__ kh = pass == 0 ? khat_tt + (size_t)task * (CFH + 1) * CF
+        const cx<R>* __restrict__ kh = pass == 0 ? khat_tt + (size_t)task * (CFH + 1) * CF
                                                      : khat_muse + (size_t)l * (CFH + 1) * CF;
         // the thread's kernel-spectrum values, fetched now so that the row transforms hide the
         // latency (slot 0 also carries the Nyquist column)
-        cx<float> khv[8], khn[8];
+        cx<R> khv[8], khn[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             khv[e] = kh[slot * CF + t + 8 * e];
-            khn[e] = slot == 0 ? kh[CFH * CF + t + 8 * e] : cx<float>{0.f, 0.f};
+            khn[e] = slot == 0 ? kh[CFH * CF + t + 8 * e] : cx<R>{(R)0, (R)0};
         }
         __syncthreads();        // F is free: the inverse rows of the previous pass have read it
         if (slot < NS / 2) cf_rows_forward(x, F, buf, tw, slot, t);
         __syncthreads();
         {   // columns: forward, multiply by the kernel spectrum, inverse (conjugation trick)
-            const cx<float>* res = cf_col_forward(F, NS, buf, tw, slot, t);
-            cx<float> y[8];
+            const cx<R>* res = cf_col_forward(F, NS, buf, tw, slot, t);
+            cx<R> y[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int kx = t + 8 * e;
-                cx<float> v;
+                cx<R> v;
                 if (slot == 0) {
-                    cx<float> a0, a32;
+                    cx<R> a0, a32;
                     cf_split0(res, kx, a0, a32);
-                    const cx<float> b0 = cmul(a0, khv[e]), b32 = cmul(a32, khn[e]);
+                    const cx<R> b0 = cmul(a0, khv[e]), b32 = cmul(a32, khn[e]);
                     v = {b0.x - b32.y, b0.y + b32.x};
                 } else {
                     v = cmul(res[lds_out<CF, 8>(kx)], khv[e]);
                 }
-                y[e] = conjf(v);
+                y[e] = conjf<R>(v);
             }
-            const cx<float>* r2 = fft_forward_regs<float, CF, true>(y, buf, buf, tw.w, t);
+            const cx<R>* r2 = fft_forward_regs<R, CF, true>(y, buf, buf, tw.w, t);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int r = t + 8 * e;
-                if (r >= KS / 2 && r < KS / 2 + NS) F[r][slot] = conjf(r2[lds_out<CF, 8>(r)]);
+                if (r >= KS / 2 && r < KS / 2 + NS) F[r][slot] = conjf<R>(r2[lds_out<CF, 8>(r)]);
             }
         }
         __syncthreads();
         if (slot < NS / 2) {   // inverse rows, two output rows per complex transform
             const int ra = KS / 2 + 2 * slot, rb = ra + 1;
-            cx<float> z[8];
+            cx<R> z[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = t + 8 * e;
                 const int kk = k <= CFH ? k : CF - k;
-                cx<float> a, b;
+                cx<R> a, b;
                 if (kk == 0) {
-                    a = {F[ra][0].x, 0.f};
-                    b = {F[rb][0].x, 0.f};
+                    a = {F[ra][0].x, (R)0};
+                    b = {F[rb][0].x, (R)0};
                 } else if (kk == CFH) {
-                    a = {F[ra][0].y, 0.f};
-                    b = {F[rb][0].y, 0.f};
+                    a = {F[ra][0].y, (R)0};
+                    b = {F[rb][0].y, (R)0};
                 } else {
                     a = F[ra][kk];
                     b = F[rb][kk];
-                    if (k > CFH) { a = conjf(a); b = conjf(b); }
+                    if (k > CFH) { a = conjf<R>(a); b = conjf<R>(b); }
                 }
                 z[e] = {a.x - b.y, -(a.y + b.x)};      // conj(A + iB)
             }
-            const cx<float>* res = fft_forward_regs<float, CF, true>(z, buf, buf, tw.w, t);
+            const cx<R>* res = fft_forward_regs<R, CF, true>(z, buf, buf, tw.w, t);
             // y_a = Re conj(res) = res.x, y_b = Im conj(res) = -res.y at columns [20, 60)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int c = t + 8 * e;
                 if (c >= KS / 2 && c < KS / 2 + NS) {
-                    const cx<float> v = res[lds_out<CF, 8>(c)];
+                    const cx<R> v = res[lds_out<CF, 8>(c)];
                     const int i = 2 * slot, j = c - KS / 2;
                     if (pass == 1) {
                         TF* out = fin + ((size_t)task * nl + l) * NS * NS;
@@ -357,8 +370,8 @@ k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = t + 8 * e;
-                    const cx<float> v = res[lds_out<CF, 8>(c < NS ? c + KS / 2 : 0)];
-                    x[e] = c < NS ? cx<float>{v.x, -v.y} : cx<float>{0.f, 0.f};
+                    const cx<R> v = res[lds_out<CF, 8>(c < NS ? c + KS / 2 : 0)];
+                    x[e] = c < NS ? cx<R>{v.x, -v.y} : cx<R>{(R)0, (R)0};
                 }
             }
         }
@@ -367,17 +380,19 @@ k_conv_fft(int nl, const float* __restrict__ pre, const cx<float>* __restrict__ 
 
 // K_KHAT: spectrum of astropy's Moffat2DKernel(gamma, alpha, 41, 41) (psfrec.py:916, 927) on the
 // 64x64 frame, transposed half plane khat[k][kx], with the 1/4096 of the inverse folded in.
+template <typename R>
 __global__ void __launch_bounds__(256)
 k_khat(const double* __restrict__ gam, const double* __restrict__ alp,
-       cx<float>* __restrict__ khat) {
-    __shared__ float ker[KS * KS];
-    __shared__ cx<float> F[CF][CFP];
-    __shared__ cx<float> bufs[CFH][CFB];
+       cx<R>* __restrict__ khat) {
+    extern __shared__ __align__(16) unsigned char conv_smem[];
+    cx<R> (*F)[CFP] = reinterpret_cast<cx<R> (*)[CFP]>(conv_smem);
+    cx<R> (*bufs)[CFB] = reinterpret_cast<cx<R> (*)[CFB]>(conv_smem + sizeof(cx<R>) * CF * CFP);
+    R* ker = reinterpret_cast<R*>(conv_smem + sizeof(cx<R>) * (CF * CFP + CFH * CFB));
     __shared__ double part[4];
     __shared__ double tot;
     const int kid = blockIdx.x;
     const int slot = threadIdx.x >> 3, t = threadIdx.x & 7;
-    Tw64 tw;
+    Tw64<R> tw;
     tw.init(t);
     const double g2 = gam[kid] * gam[kid], al = alp[kid];
     constexpr int NV = (KS * KS + 255) / 256;
@@ -405,41 +420,41 @@ k_khat(const double* __restrict__ gam, const double* __restrict__ alp,
 #pragma unroll
     for (int m = 0; m < NV; ++m) {
         const int e = threadIdx.x + m * 256;
-        if (e < KS * KS) ker[e] = (float)(vals[m] * inv);
+        if (e < KS * KS) ker[e] = (R)(vals[m] * inv);
     }
     __syncthreads();
     // rows (41 of them, pitch 41): reuse the row-pair transform with a 41-wide image
     if (slot < (KS + 1) / 2) {
         const int ra = 2 * slot, rb = ra + 1;
-        cx<float> x[8];
+        cx<R> x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = t + 8 * e;
-            x[e] = {(c < KS) ? ker[ra * KS + c] : 0.f, (c < KS && rb < KS) ? ker[rb * KS + c] : 0.f};
+            x[e] = {(c < KS) ? ker[ra * KS + c] : (R)0, (c < KS && rb < KS) ? ker[rb * KS + c] : (R)0};
         }
-        const cx<float>* res = fft_forward_regs<float, CF, true>(x, bufs[slot], bufs[slot], tw.w, t);
+        const cx<R>* res = fft_forward_regs<R, CF, true>(x, bufs[slot], bufs[slot], tw.w, t);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = t + 8 * e;
-            const cx<float> zk = res[lds_out<CF, 8>(k)], zm = res[lds_out<CF, 8>((CF - k) % CF)];
+            const cx<R> zk = res[lds_out<CF, 8>(k)], zm = res[lds_out<CF, 8>((CF - k) % CF)];
             if (k == 0) {
-                const cx<float> zn = res[lds_out<CF, 8>(CFH)];
+                const cx<R> zn = res[lds_out<CF, 8>(CFH)];
                 F[ra][0] = {zk.x, zn.x};
                 F[rb][0] = {zk.y, zn.y};
             } else {
-                F[ra][k] = {0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
-                F[rb][k] = {0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};
+                F[ra][k] = {(R)0.5 * (zk.x + zm.x), (R)0.5 * (zk.y - zm.y)};
+                F[rb][k] = {(R)0.5 * (zk.y + zm.y), -(R)0.5 * (zk.x - zm.x)};
             }
         }
     }
     __syncthreads();
-    const cx<float>* res = cf_col_forward(F, KS, bufs[slot], tw, slot, t);
-    cx<float>* out = khat + (size_t)kid * (CFH + 1) * CF;
+    const cx<R>* res = cf_col_forward(F, KS, bufs[slot], tw, slot, t);
+    cx<R>* out = khat + (size_t)kid * (CFH + 1) * CF;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int kx = t + 8 * e;
         if (slot == 0) {
-            cx<float> a0, a32;
+            cx<R> a0, a32;
             cf_split0(res, kx, a0, a32);
             out[kx] = a0;
             out[CFH * CF + kx] = a32;
@@ -820,7 +835,7 @@ constexpr int fit_min_waves() { return sizeof(RE) == 4 ? MPSFR_FIT_WAVES : 2; }
 
 template <typename RE, typename TS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fit_min_waves<RE>())))
-k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit) {
+k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit, double polish_tol) {
     constexpr int NPX = NS * NS / 64;                     // 25 pixels per lane
     static_assert(NPX * 64 == NS * NS, "the lane map assumes 1600 pixels");
     using S = RE;                                         // type of the LM state
@@ -964,7 +979,7 @@ k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit) {
             for (int k = 0; k < 5; ++k) vd[k] += dx[k];
             ++it;
             polish_chi2 = rel < 1.0e-3 ? np.chi2 : -1.0;
-            if (rel < MPSFR_POLISH_TOL) break;      // error after this step ~ 1e-3 rel
+            if (rel < polish_tol) break;            // error after this step ~ 1e-2 rel
         }
     }
     // Outputs in (a, n).  The covariance comes from the normal matrix of the last LM iteration (in
@@ -1059,20 +1074,41 @@ void launch_conv(hipStream_t s, int ntask, int nl, const void* d_pre, const void
     }
 }
 
+template <typename R>
+constexpr size_t conv_smem_bytes(bool with_kernel) {
+    return sizeof(cx<R>) * (CF * CFP + CFH * CFB) + (with_kernel ? sizeof(R) * KS * KS : 0);
+}
+
 void launch_khat(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
-                 void* d_khat) {
+                 void* d_khat, bool f64) {
     if (nker <= 0) return;
-    hipLaunchKernelGGL(k_khat, dim3(nker), dim3(256), 0, s, d_gamma, d_alpha, (cx<float>*)d_khat);
+    if (f64) {
+        allow_smem(k_khat<double>, conv_smem_bytes<double>(true));
+        hipLaunchKernelGGL(k_khat<double>, dim3(nker), dim3(256), conv_smem_bytes<double>(true), s, d_gamma,
+                           d_alpha, (cx<double>*)d_khat);
+    } else {
+        hipLaunchKernelGGL(k_khat<float>, dim3(nker), dim3(256), conv_smem_bytes<float>(true), s, d_gamma,
+                           d_alpha, (cx<float>*)d_khat);
+    }
 }
 
 void launch_conv_fft(hipStream_t s, int ntask, int nl, const void* d_pre, const void* d_khat_tt,
-                     const void* d_khat_muse, void* d_fin, bool fin_f32) {
-    if (fin_f32)
-        hipLaunchKernelGGL(k_conv_fft<float>, dim3(nl, ntask), dim3(256), 0, s, nl, (const float*)d_pre,
-                           (const cx<float>*)d_khat_tt, (const cx<float>*)d_khat_muse, (float*)d_fin);
-    else
-        hipLaunchKernelGGL(k_conv_fft<double>, dim3(nl, ntask), dim3(256), 0, s, nl, (const float*)d_pre,
-                           (const cx<float>*)d_khat_tt, (const cx<float>*)d_khat_muse, (double*)d_fin);
+                     const void* d_khat_muse, void* d_fin, bool fin_f32, bool f64) {
+    const dim3 grid(nl, ntask);
+    if (f64) {          // double stamps in, double arithmetic, double stamps out
+        allow_smem((k_conv_fft<double, double>), conv_smem_bytes<double>(false));
+        hipLaunchKernelGGL((k_conv_fft<double, double>), grid, dim3(256), conv_smem_bytes<double>(false), s, nl,
+                           (const double*)d_pre, (const cx<double>*)d_khat_tt, (const cx<double>*)d_khat_muse,
+                           (double*)d_fin);
+    } else if (fin_f32) {
+        hipLaunchKernelGGL((k_conv_fft<float, float>), grid, dim3(256), conv_smem_bytes<float>(false), s, nl,
+                           (const float*)d_pre, (const cx<float>*)d_khat_tt, (const cx<float>*)d_khat_muse,
+                           (float*)d_fin);
+    } else {
+        hipLaunchKernelGGL((k_conv_fft<float, double>), grid, dim3(256), conv_smem_bytes<float>(false), s, nl,
+                           (const float*)d_pre, (const cx<float>*)d_khat_tt, (const cx<float>*)d_khat_muse,
+                           (double*)d_fin);
+    }
 }
 
 void launch_fit(hipStream_t s, int nstamp, const void* d_stamps, bool stamps_f32, double* d_fit,
@@ -1082,15 +1118,22 @@ void launch_fit(hipStream_t s, int nstamp, const void* d_stamps, bool stamps_f32
     // wave sums meeting in LDS measured 1.8x slower at 3500 stamps: every wave repeats the 5x5
     // solves and the iterations serialise on barriers.)
     const dim3 grid((nstamp + 3) / 4);
-    if (f64)
+    // f64 mode: the same float Levenberg-Marquardt iterations find the basin (they cost a third of
+    // fp64 ones), and the polish with the fp64 gradient of the fp64 stamps runs on until its steps
+    // are below 1e-8 (error ~1e-10 of the parameters): the minimum is the root of the fp64 gradient
+    // either way.  MPSFR_FIT_F64_LM=1 builds keep the all-fp64 iterations.
+#ifndef MPSFR_FIT_F64_LM
+#define MPSFR_FIT_F64_LM 0
+#endif
+    if (f64 && MPSFR_FIT_F64_LM)
         hipLaunchKernelGGL((k_fit<double, double>), grid, dim3(256), 0, s, nstamp,
-                           (const double*)d_stamps, d_fit);
+                           (const double*)d_stamps, d_fit, 0.0);
     else if (stamps_f32)
         hipLaunchKernelGGL((k_fit<float, float>), grid, dim3(256), 0, s, nstamp, (const float*)d_stamps,
-                           d_fit);
+                           d_fit, (double)MPSFR_POLISH_TOL);
     else
         hipLaunchKernelGGL((k_fit<float, double>), grid, dim3(256), 0, s, nstamp,
-                           (const double*)d_stamps, d_fit);
+                           (const double*)d_stamps, d_fit, f64 ? 1.0e-8 : (double)MPSFR_POLISH_TOL);
 }
 
 void launch_stamp_sum(hipStream_t s, int ntask, int nl, const void* d_fin, bool fin_f32, double* d_sum,

@@ -733,14 +733,36 @@ def test_matrix_core_stage_against_the_fft_stage(api, dim, npl):
     assert work['mfma'][1] <= work['mfma_all'][1]
 
 
-def test_line_pruning_is_off_in_f64_mode(api):
-    ctx = api.Context(dim=128, pixscale=api.grid_pixscale(128), precision='f64')
-    ctx.reconstruct([700.0], [1.0], [0.7], [25.0], [0], H)
-    with pytest.raises(api.MpsfrError):
-        ctx.debug_fetch('vkeep', (1, 1))
-    with pytest.raises(api.MpsfrError):
-        ctx.set_option('prune_eps', 0.1)
-    ctx.close()
+def test_line_pruning_in_f64_mode(api):
+    """f64 mode prunes the trailing lines of the half plane as well, with its own bound
+    (prune_eps_f64, default 1e-13 of the PSF peak -- two decades under the 1e-11 its stamps reach
+    against the oracle): no stamp pixel moves by more than that, most of a broad PSF's half plane
+    is dropped, and the mixed-mode option keeps its own range."""
+    see, gl, l0 = np.array([0.45, 1.6, 1.0]), np.array([0.9, 0.3, 0.7]), np.array([28.0, 9.0, 25.0])
+    lb = np.array([465.0, 700.0, 930.0])
+    ps = api.grid_pixscale(512)
+    out = {}
+    for key, eps in (('pruned', None), ('all', 0.0)):
+        ctx = api.Context(dim=512, pixscale=ps, precision='f64')
+        if eps is not None:
+            ctx.set_option('prune_eps_f64', eps)
+        out[key] = ctx.reconstruct(lb, see, gl, l0, np.zeros(3, np.uint8), H)
+        if key == 'pruned':
+            vk = ctx.debug_fetch('vkeep', (3, 2))
+            with pytest.raises(api.MpsfrError):
+                ctx.set_option('prune_eps', 0.1)
+            with pytest.raises(api.MpsfrError):
+                ctx.set_option('prune_eps_f64', 1e-3)
+        else:
+            with pytest.raises(api.MpsfrError):
+                ctx.debug_fetch('vkeep', (3, 2))
+        ctx.close()
+    a, b = out['all'], out['pruned']
+    peak = a['psf'].max(axis=(2, 3), keepdims=True)
+    assert (np.abs(b['psf'] - a['psf']) / peak).max() < 2e-13
+    assert np.abs(b['fit'][:, :, 4] - a['fit'][:, :, 4]).max() < 1e-9
+    assert vk.min() >= 1 and vk.max() <= 257 and np.all(np.diff(vk, axis=1) >= 0)
+    assert vk[1, 0] < 0.35 * 257 and vk[1].max() < vk[0].max()
 
 
 @pytest.mark.parametrize('opts', [{}, {'mf_kernel': 1}, {'otf_mfma': 0}])
