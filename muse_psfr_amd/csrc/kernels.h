@@ -45,7 +45,6 @@ enum KernelId {
     K_AO_TABLES = 0,
     K_TEL_OTF,
     K_PSD_ROWFFT,
-    K_DC_SUM,
     K_COLFFT_DPHI,
     K_GTABLE,
     K_MOFFAT_KERNELS,
@@ -64,12 +63,16 @@ void launch_ao_tables(hipStream_t s, const AoGeom& g, const uint8_t* d_mask_rec,
                       const uint8_t* d_mask_res, double* d_tab);
 void launch_tel_otf(hipStream_t s, int N, const uint64_t* d_rows, int words, double pupsum,
                     void* d_tel, bool f64out);
+// d_dcpart: [ntd][psd_rowfft_groups(N)] the workgroups' shares of the PSD sum (bg[0,0], psfrec.py:721),
+// added by launch_colfft_dphi; f64: the f64 mode (two Newton steps in x^(-11/6) instead of one)
+int psd_rowfft_groups(int N);
 void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp,
-                       const double* d_aotab, double cfit, void* d_C, const void* d_tw64);
+                       const double* d_aotab, double cfit, void* d_C, const void* d_tw64,
+                       double* d_dcpart, bool f64);
 // d_zero: 17 ints the kernel sets to zero (the work-list counters of launch_mf_prep), or nullptr
-void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00, int* d_zero = nullptr);
-void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,
-                        double scale2, void* d_D0t, bool f64out, const void* d_tw64);
+void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_dcpart,
+                        double scale2, void* d_D0t, bool f64out, const void* d_tw64,
+                        int* d_zero = nullptr);
 // Pruning of the per-wavelength stage (stage_a.hip, "Line pruning"): minima of D per line
 // ([ntd][N/2+1]) and per block of 16 lines x 32 columns ([ntd][nmt][N/32]), then the lines to keep
 // per (task, wavelength pair) and the block minima over the directions
@@ -101,14 +104,14 @@ void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const vo
                      void* d_pre, const int* d_order = nullptr, void* d_clk = nullptr);
 // Second generation of the matrix-core stage (otf_mfma2.hip, one direction): block masks per
 // (task, wavelength) in two precision tiers, then the thin-wave kernel.  permax: wavelengths per
-// workgroup (8: 16 waves of 128 registers; 6: 12 waves of 168).
+// workgroup (7: 14 waves of 128 registers; 6: 12 waves of 168).
 size_t mf2_own_bytes(int N, int ntask, int nl);
 size_t mf2_uni_bytes(int N, int ntask, int nl);
 size_t mf2_sched_bytes(int N, int ntask, int nl);
 size_t mf2_part_bytes(int N, int ntask, int nl);
 void mf2_groups(int nl, int permax, int* per, int* ngr);
 // K_MF_PREP: block masks and the work lists of launch_otf_mfma2 from the block minima of launch_dmin
-// (d_dminb = nullptr: no pruning); d_sched[0..16] must be zero (launch_dc_sum does that)
+// (d_dminb = nullptr: no pruning); d_sched[0..16] must be zero (launch_colfft_dphi does that)
 void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const LamPar* d_lp,
                     const float* d_dminb, const float* d_tlb, float thr, float thr_mid, void* d_own,
                     void* d_uni, void* d_sched);

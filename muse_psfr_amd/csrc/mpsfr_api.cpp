@@ -44,7 +44,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 const char* kKernelNames[K_COUNT] = {
-    "ao_tables", "tel_otf", "psd_rowfft", "dc_sum", "colfft_dphi", "gtable",
+    "ao_tables", "tel_otf", "psd_rowfft", "colfft_dphi", "gtable",
     "moffat_kernels", "otf_rowfft", "colpass", "conv", "fit", "stamp_sum", "vkeep", "otf_mfma", "mf_prep"};
 
 struct DevBuf {
@@ -76,7 +76,7 @@ struct mpsfr_ctx {
     bool otf_mfma = true;        // mixed mode: per-wavelength stage on the matrix cores (otf_mfma.hip)
     bool mf_floor = true;        // matrix-core stage: skip blocks below the fp16 representation floor
     int mf_kernel = 2;           // 2: thin-wave kernel with precision tiers (otf_mfma2.hip, one direction); 1: otf_mfma.hip
-    int mf_permax = 6;           // wavelengths per workgroup of the thin-wave kernel (6: 12 waves, 8: 16 waves)
+    int mf_permax = 6;           // wavelengths per workgroup of the thin-wave kernel (6: 12 waves, 7: 14 waves)
     double mf_mid_log2 = -18.01; // blocks below 2^this need no low half of the OTF (see otf_mfma2.hip)
     bool mf_clock = false;       // experiments: phase time stamps of the matrix-core kernel
     DevBuf mfclk;
@@ -461,7 +461,7 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         if (value != 1.0 && value != 2.0) return fail(MPSFR_E_INVALID, "mf_kernel must be 1 or 2");
         c->mf_kernel = (int)value;
     } else if (!strcmp(key, "mf_permax")) {
-        if (value != (int)value || value < 1.0 || value > 8.0) return fail(MPSFR_E_INVALID, "mf_permax must be 1..8");
+        if (value != (int)value || value < 1.0 || value > 7.0) return fail(MPSFR_E_INVALID, "mf_permax must be 1..7");
         c->mf_permax = (int)value;
     } else if (!strcmp(key, "mf_mid_log2")) {
         c->mf_mid_log2 = value;
@@ -815,7 +815,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         mpsfr_ctx::Lane& ln = lane_of(j);
         // row FFTs of the PSD: only the N/2 + 40 distinct rows are stored (K_PSD_ROWFFT)
         if ((rc = ensure(c, ln.C, (size_t)TC * ndir * (N / 2 + NAO / 2) * H1 * 2 * sizeof(double)))) return rc;
-        if ((rc = ensure(c, ln.s00, (size_t)TC * ndir * sizeof(double)))) return rc;
+        if ((rc = ensure(c, ln.s00, (size_t)TC * ndir * psd_rowfft_groups(N) * sizeof(double)))) return rc;
         {   // 16 lines of padding behind D: the last m-tile of the matrix-core kernel reads past line
             // N/2 (where its telescope table is -inf); fresh memory is zeroed so that what it reads
             // there is always a finite number
@@ -875,16 +875,12 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         {
             ProfScope ps(c, K_PSD_ROWFFT, ls);
             launch_psd_rowfft(ls, N, ntd, ndir, d_tp + t0, (const double*)c->aotab.p, cfit, ln.C.p,
-                              c->tw64.p);
-        }
-        {
-            ProfScope ps(c, K_DC_SUM, ls);
-            launch_dc_sum(ls, N, ntd, ln.C.p, (double*)ln.s00.p, mf2 ? (int*)ln.msched.p : nullptr);
+                              c->tw64.p, (double*)ln.s00.p, c->f64);
         }
         {
             ProfScope ps(c, K_COLFFT_DPHI, ls);
             launch_colfft_dphi(ls, N, ntd, ln.C.p, (const double*)ln.s00.p, scale2, ln.D0t.p,
-                               c->f64, c->tw64.p);
+                               c->f64, c->tw64.p, mf2 ? (int*)ln.msched.p : nullptr);
         }
         if (mf2) {
             // thin-wave kernel: block minima (one direction: they are the minima over the directions),

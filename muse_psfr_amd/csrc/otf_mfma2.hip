@@ -48,9 +48,10 @@ constexpr int kStage2 = kT2 * 4096;     // one staging buffer: 8 x (D 2 KB | log
 constexpr int kSlab = 6 * 1024;         // E slab of one wavelength and k-step: 3 column tiles x (hi | lo)
 
 // ------------------------------------------------------------------------------------------
-// K_MF_PREP: one workgroup of 16 waves per task: the block masks of every wavelength and the work
-// items, from the block minima of D (K_DMIN, stage_a.hip; a version that computed them here, one
-// workgroup reading all of a task's D, took 43 us against 12 + 6: a single CU draws 30 GB/s).
+// K_MF_PREP: one workgroup per (task, wavelength group): the block masks of the group's wavelengths
+// and its work items, from the block minima of D (K_DMIN, stage_a.hip; a version that computed them
+// here, one workgroup reading all of a task's D, took 43 us against 12 + 6: a single CU draws
+// 30 GB/s; one workgroup per task walking its groups in rounds took 16 us, all of it latency).
 // One wave per wavelength, lane = k-step:
 //   own[task][l][mt][2]   bit ks of word 0: block (mt, ks) is a full block of wavelength l;
 //                         word 1: a mid block (see the file comment)
@@ -78,101 +79,82 @@ struct MaskArgs {
     u64* ksum;
     u64* kuni;
     int* gsw;
-    int* sched;              // [0..15] items per work class (zeroed by K_DC_SUM), [16] queue head of K_OTF_MFMA2
+    int* sched;              // [0..15] items per work class (zeroed by K_COLFFT_DPHI), [16] queue head of K_OTF_MFMA2
     int4* items;             // [16][cap]
     int cap;                 // ntask ngr nsw
 };
 
-constexpr int kPrepWaves = 16;
 constexpr int kMaxNmt = 1280 / 2 / MTL + 1, kMaxNks = 1280 / KBL;      // 41, 40
 
-__global__ void __launch_bounds__(64 * kPrepWaves) k_mf_prep(const MaskArgs a) {
-    constexpr int MAXL = 1024;                       // wavelength factors staged in LDS (more: from memory)
-    constexpr int MAXI = 512;                        // items of a task listed through LDS (more: directly)
-    __shared__ float s_dm[kMaxNmt * kMaxNks], s_tb[kMaxNmt * kMaxNks], s_c2[MAXL];
-    __shared__ u64 s_any[kPrepWaves][kMaxNmt + 7];
-    __shared__ int4 s_item[MAXI];
-    __shared__ int s_nitem;
-    const int task = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// one workgroup per (wavelength group, task): wave = wavelength slot of the group, lane = k-step
+__global__ void __launch_bounds__(64 * 8) k_mf_prep(const MaskArgs a) {
+    __shared__ float s_dm[kMaxNmt * kMaxNks], s_tb[kMaxNmt * kMaxNks];
+    __shared__ u64 s_any[8][kMaxNmt + 7];
+    const int grp = blockIdx.x, task = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int N = a.N, nks = mf_nks(N), nmt = mf_nmt(N), nsw = (nmt + kT2 - 1) / kT2;
-    for (int e = threadIdx.x; e < nmt * nks; e += 64 * kPrepWaves) {
+    const int nthr = 64 * a.per;
+    for (int e = threadIdx.x; e < nmt * nks; e += nthr) {
         s_dm[e] = a.dminb != nullptr ? a.dminb[(size_t)task * nmt * nks + e] : 0.f;
         s_tb[e] = a.tlb[e];
     }
-    for (int e = threadIdx.x; e < min(a.nl, MAXL); e += 64 * kPrepWaves)
-        s_c2[e] = (float)a.lp[e].c * 1.44269504088896340736f;
-    if (threadIdx.x == 0) s_nitem = 0;
+    const int l = grp * a.per + w;
+    const bool lv = l < a.nl;
+    const float c2 = lv ? (float)a.lp[l].c * 1.44269504088896340736f : 0.f;
     __syncthreads();
-    // rounds of gpr wavelength groups, one wave per wavelength
-    const int gpr = kPrepWaves / a.per;
-    const int gi = w / a.per, slot = w - gi * a.per;
     const int kk = min(lane, nks - 1);
-    for (int g0 = 0; g0 < a.ngr; g0 += gpr) {
-        const int grp = g0 + gi, l = grp * a.per + slot;
-        const bool gv = gi < gpr && grp < a.ngr, lv = gv && l < a.nl;
-        if (gv) {
-            const float c2 = !lv ? 0.f : l < MAXL ? s_c2[l] : (float)a.lp[l].c * 1.44269504088896340736f;
-            u64 myf = 0, mym = 0;                    // lane mt keeps the two words of m-tile mt
-            for (int mt = 0; mt < nmt; ++mt) {
-                const float e = fmaf(c2, s_dm[mt * nks + kk], s_tb[mt * nks + kk]);
-                const bool keep = lv && lane < nks && (a.dminb == nullptr || e > a.thr);
-                const bool full = keep && (a.dminb == nullptr || e > a.thr_mid);
-                const u64 bf = __ballot(full), bm = __ballot(keep && !full);
-                if (lane == mt) { myf = bf; mym = bm; }
-            }
-            if (lane < nmt) {
-                if (lv) {                            // one coalesced store of the wavelength's words
-                    ulonglong2* o = reinterpret_cast<ulonglong2*>(a.own + ((size_t)task * a.nl + l) * nmt * 2) + lane;
-                    *o = make_ulonglong2(myf, mym);
-                }
-                s_any[w][lane] = myf | mym;
-            }
-            u64 ks_l = lane < nmt ? (myf | mym) : 0;
-#pragma unroll
-            for (int o = 1; o < kT2; o <<= 1) ks_l |= __shfl_xor(ks_l, o, 64);
-            if (lv && (lane & 7) == 0 && (lane >> 3) < nsw) a.ksum[((size_t)task * a.nl + l) * nsw + (lane >> 3)] = ks_l;
-        }
-        __syncthreads();
-        if (gv && slot == 0) {                       // the group's first wave: lane = m-tile
-            u64 u = 0;
-            if (lane < nmt)
-                for (int j = 0; j < a.per; ++j) u |= s_any[w + j][lane];
-            if (lane < nmt) a.uni[((size_t)task * a.ngr + grp) * nmt + lane] = u;
-            u64 ku = u;
-            int pc = __builtin_popcountll(u);
-#pragma unroll
-            for (int o = 1; o < kT2; o <<= 1) {      // over the eight m-tiles of a sweep
-                ku |= __shfl_xor(ku, o, 64);
-                pc += __shfl_xor(pc, o, 64);
-            }
-            const bool lead = (lane & 7) == 0 && (lane >> 3) < nsw;
-            if (lead) a.kuni[((size_t)task * a.ngr + grp) * nsw + (lane >> 3)] = ku;
-            const u64 has = __ballot(lead && ku != 0);     // bit 8 sw
-            int sweeps = 0;
-#pragma unroll
-            for (int sw = 0; sw < 8; ++sw) sweeps |= (int)((has >> (8 * sw)) & 1) << sw;
-            if (lane == 0) a.gsw[task * a.ngr + grp] = sweeps;
-            if (lead && ku != 0) {
-                // the item, with its work class in .w's upper half: filed after the last round, all
-                // atomics of the task in flight together
-                const int4 it = make_int4(task, grp, lane >> 3, __builtin_popcount(sweeps) | (min(15, pc >> 3) << 16));
-                const int k = atomicAdd(&s_nitem, 1);
-                if (k < MAXI) {
-                    s_item[k] = it;
-                } else {
-                    const int cls = it.w >> 16;
-                    a.items[(size_t)cls * a.cap + atomicAdd(a.sched + cls, 1)] = make_int4(it.x, it.y, it.z, it.w & 0xffff);
-                }
-            }
-        }
-        __syncthreads();                             // s_any is rewritten by the next round
+    u64 myf = 0, mym = 0;                    // lane mt keeps the two words of m-tile mt
+    for (int mt = 0; mt < nmt; ++mt) {
+        const float e = fmaf(c2, s_dm[mt * nks + kk], s_tb[mt * nks + kk]);
+        const bool keep = lv && lane < nks && (a.dminb == nullptr || e > a.thr);
+        const bool full = keep && (a.dminb == nullptr || e > a.thr_mid);
+        const u64 bf = __ballot(full), bm = __ballot(keep && !full);
+        if (lane == mt) { myf = bf; mym = bm; }
     }
-    for (int k = threadIdx.x; k < min(s_nitem, MAXI); k += 64 * kPrepWaves) {
-        const int4 it = s_item[k];
-        const int cls = it.w >> 16;
-        a.items[(size_t)cls * a.cap + atomicAdd(a.sched + cls, 1)] = make_int4(it.x, it.y, it.z, it.w & 0xffff);
+    if (lane < nmt) {
+        if (lv) {                            // one coalesced store of the wavelength's words
+            ulonglong2* o = reinterpret_cast<ulonglong2*>(a.own + ((size_t)task * a.nl + l) * nmt * 2) + lane;
+            *o = make_ulonglong2(myf, mym);
+        }
+        s_any[w][lane] = myf | mym;
+    }
+    u64 ks_l = lane < nmt ? (myf | mym) : 0;
+#pragma unroll
+    for (int o = 1; o < kT2; o <<= 1) ks_l |= __shfl_xor(ks_l, o, 64);
+    if (lv && (lane & 7) == 0 && (lane >> 3) < nsw) a.ksum[((size_t)task * a.nl + l) * nsw + (lane >> 3)] = ks_l;
+    __syncthreads();
+    if (w == 0) {                            // the group's first wave: lane = m-tile
+        u64 u = 0;
+        if (lane < nmt)
+            for (int j = 0; j < a.per; ++j) u |= s_any[j][lane];
+        if (lane < nmt) a.uni[((size_t)task * a.ngr + grp) * nmt + lane] = u;
+        u64 ku = u;
+        int pc = __builtin_popcountll(u);
+#pragma unroll
+        for (int o = 1; o < kT2; o <<= 1) {      // over the eight m-tiles of a sweep
+            ku |= __shfl_xor(ku, o, 64);
+            pc += __shfl_xor(pc, o, 64);
+        }
+        const bool lead = (lane & 7) == 0 && (lane >> 3) < nsw;
+        if (lead) a.kuni[((size_t)task * a.ngr + grp) * nsw + (lane >> 3)] = ku;
+        const u64 has = __ballot(lead && ku != 0);     // bit 8 sw
+        int sweeps = 0;
+#pragma unroll
+        for (int sw = 0; sw < 8; ++sw) sweeps |= (int)((has >> (8 * sw)) & 1) << sw;
+        if (lane == 0) a.gsw[task * a.ngr + grp] = sweeps;
+        if (lead && ku != 0) {               // file the item in its work class
+            const int cls = min(15, pc >> 3);
+            a.items[(size_t)cls * a.cap + atomicAdd(a.sched + cls, 1)] =
+                make_int4(task, grp, lane >> 3, __builtin_popcount(sweeps));
+        }
     }
 }
+
+// Which lanes of the second-pass result tiles the epilogue (write_stamp) reads: columns
+// 16 jt + lr < 21; of R2x rows 0..4 (lane groups lk = 0, 1), of R2y rows 8..12 (lk = 2, 3).  Only
+// those travel through memory between K_OTF_MFMA2 and K_MF_FINISH (half of the 8 KB per sweep).
+__device__ __forceinline__ bool part_col(int jt, int lr) { return 16 * jt + lr < NSH; }
+__device__ __forceinline__ bool part_r2x(int lk) { return lk < 2; }
+__device__ __forceinline__ bool part_r2y(int lk) { return lk >= 2; }
 
 // the 64-bit word that lane `src` (wave-uniform) holds, into scalar registers
 __device__ __forceinline__ u64 lane_word(u64 w, int src) {
@@ -263,9 +245,13 @@ k_otf_mfma2(const Mf2Args a) {
     const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
     const int nw = 2 * per;
     const char* ttab = reinterpret_cast<const char*>(a.tl2);
-    // the item number travels through a word of staging buffer 1, which no load touches before
-    // the first barrier of the k-loop (every wave has read it by then)
-    volatile int* s_item = reinterpret_cast<volatile int*>(smem + kStage2);
+    // The item number travels through a word of LDS behind the staging buffers and slabs.  The queue
+    // runs a little ahead: the number of the next item is drawn during the last k-step of the current
+    // one, its descriptor is loaded behind the second pass and its masks behind the epilogue, so
+    // that an item starts without the three dependent memory round trips (atomic, descriptor,
+    // masks: 13 % of a wave's lifetime when they sat at the head of every item).  (Drawn a whole
+    // item ahead, the queue balances worse: the launch ended 12 us later on its last workgroups.)
+    volatile int* s_next = reinterpret_cast<volatile int*>(smem + 2 * kStage2 + 2 * per * kSlab);
     // the 16 lists as one queue, heaviest class first: item i of the queue is entry i - first[c] of
     // the class c with first[c] <= i < first[c] + count[c]
     // (lane c < 16 keeps the bounds of class c)
@@ -285,17 +271,46 @@ k_otf_mfma2(const Mf2Args a) {
 #else
 #define MF2_NOW() 0ull
 #endif
+    // descriptor {task, group, sweep, sweeps of the (task, group)} of queue item `item`
+    auto load_item = [&](int item) -> int4 {
+        const int cls = __builtin_ctzll(__ballot(lane0 < 16 && item >= cfirst && item < cfirst + ccnt));
+        const int ipos = item - __builtin_amdgcn_readlane(cfirst, cls);
+        return a.items[(size_t)cls * a.cap + ipos];
+    };
+    // The masks of a sweep (K_MF_MASKS) with ONE load instruction: lane 8 k + g holds, for m-tile
+    // g0 + g, the group's staging mask (k = 0), this wavelength's full blocks (1) and mid blocks
+    // (2); lane 24 the k-steps in which the wavelength has work, lane 25 the group's k-steps.
+    auto load_masks = [&](int task, int grp, int sw, float* c2) -> u64 {
+        const int half = wave0 >= per ? 1 : 0, slot = wave0 - half * per;
+        const int l = grp * per + slot;
+        const bool lv = l < a.nl;
+        const int lc = lv ? l : a.nl - 1;
+        *c2 = (float)a.lp[lc].c * 1.44269504088896340736f;
+        const int g = lane0 & 7, mt = sw * kT2 + g, kind = lane0 >> 3;
+        const size_t tl_ = (size_t)task * a.nl + lc, tg_ = (size_t)task * ngr + grp;
+        u64 mw = 0;
+        if (kind == 0) { if (mt < nmt_all) mw = a.uni[tg_ * nmt_all + mt]; }
+        else if (kind < 3) { if (mt < nmt_all && lv) mw = a.own[(tl_ * nmt_all + mt) * 2 + kind - 1]; }
+        else if (lane0 == 24) { if (lv) mw = a.ksum[tl_ * nsw + sw]; }
+        else if (lane0 == 25) mw = a.kuni[tg_ * nsw + sw];
+        return mw;
+    };
+    if (threadIdx.x == 0) *s_next = atomicAdd(a.sched + 16, 1);
+    __syncthreads();
+    int item = __builtin_amdgcn_readfirstlane(*s_next);
+    int4 it = make_int4(0, 0, 0, 0);
+    u64 mw = 0;
+    float c2 = 0.f;
+    if (item < nitems) {
+        it = load_item(item);
+        mw = load_masks(__builtin_amdgcn_readfirstlane(it.x), __builtin_amdgcn_readfirstlane(it.y),
+                        __builtin_amdgcn_readfirstlane(it.z), &c2);
+    }
 
-    for (;;) {
+    while (item < nitems) {
 #if MPSFR_MF_CLOCK
         const unsigned long long ti0 = MF2_NOW();
 #endif
-        if (threadIdx.x == 0) *s_item = atomicAdd(a.sched + 16, 1);
-        __syncthreads();
-        const int item = __builtin_amdgcn_readfirstlane(*s_item);
-        if (item >= nitems) break;
-        const int cls = __builtin_ctzll(__ballot(lane0 < 16 && item >= cfirst && item < cfirst + ccnt));
-        const int ipos = item - __builtin_amdgcn_readlane(cfirst, cls);
         // Everything derived from the lane and wave numbers is recomputed per item: hoisted out of
         // this loop the two dozen addresses and constants live across it and spill (the reloads sat
         // on the serial path of every item's epilogue).
@@ -310,29 +325,15 @@ k_otf_mfma2(const Mf2Args a) {
         // the last m-tile read the finite padding behind D (log2 tel = -inf there).
         const unsigned voff = (unsigned)((lr * N + 8 * lk) * sizeof(float)), voff16 = voff + 16;
         const unsigned voffb = (unsigned)lane * 16;
-        const int4 it = a.items[(size_t)cls * a.cap + ipos];
         const int task = __builtin_amdgcn_readfirstlane(it.x), grp = __builtin_amdgcn_readfirstlane(it.y);
         const int sw = __builtin_amdgcn_readfirstlane(it.z), nsweeps = __builtin_amdgcn_readfirstlane(it.w);
         const int g0 = sw * kT2;
         const int l = grp * per + slot;
         const bool lv = l < a.nl;
         const int lc = lv ? l : a.nl - 1;
-        const float c2 = (float)a.lp[lc].c * 1.44269504088896340736f;
         const char* dtask = reinterpret_cast<const char*>(a.D0t + (size_t)task * H1 * N);
         const char* etab = reinterpret_cast<const char*>(a.E + (size_t)lc * nks * NCT * 2 * 64);
         const h4* Gl = a.G + (size_t)lc * nmt_all * NJT * 2 * 2 * 64 + lane;
-        // The masks of the sweep (K_MF_MASKS) with ONE load instruction: lane 8 k + g holds, for m-tile
-        // g0 + g, the group's staging mask (k = 0), this wavelength's full blocks (1) and mid blocks
-        // (2); lane 24 the k-steps in which the wavelength has work, lane 25 the group's k-steps.
-        u64 mw = 0;
-        {
-            const int g = lane & 7, mt = g0 + g, kind = lane >> 3;
-            const size_t tl_ = (size_t)task * a.nl + lc, tg_ = (size_t)task * ngr + grp;
-            if (kind == 0) { if (mt < nmt_all) mw = a.uni[tg_ * nmt_all + mt]; }
-            else if (kind < 3) { if (mt < nmt_all && lv) mw = a.own[(tl_ * nmt_all + mt) * 2 + kind - 1]; }
-            else if (lane == 24) { if (lv) mw = a.ksum[tl_ * nsw + sw]; }
-            else if (lane == 25) mw = a.kuni[tg_ * nsw + sw];
-        }
         const u64 kuni = lane_word(mw, 25);            // != 0: K_MF_MASKS lists no empty item
         const u64 sany = lane_word(mw, 24);
         u64 of[kTW], om[kTW];              // this wave's tiles 2 i + half: full / mid blocks
@@ -380,14 +381,18 @@ k_otf_mfma2(const Mf2Args a) {
         u64 rest = kuni;
         int buf = 0;
         stage(__builtin_ctzll(rest), 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (lgkmcnt: the first thread's store of the next item's number)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #if MPSFR_MF_CLOCK
         const unsigned long long tk0 = MF2_NOW();
 #endif
-        while (rest != 0) {
+        for (;;) {
             const int ks = __builtin_ctzll(rest);
             rest &= rest - 1;
+            // the next item's number is drawn during the last k-step (the atomic is in flight behind
+            // its tile steps) and read behind the barrier that ends the k-loop
+            if (rest == 0 && threadIdx.x == 0) *s_next = atomicAdd(a.sched + 16, 1);
             unsigned fb = 0, mb = 0;
 #pragma unroll
             for (int i = 0; i < kTW; ++i) {
@@ -461,6 +466,7 @@ k_otf_mfma2(const Mf2Args a) {
             const unsigned long long tw0 = MF2_NOW();
             t_tiles += tw0 - ts1;
 #endif
+            if (rest == 0) break;       // the last k-step's tail is below
             // the next k-step's tiles and slabs have landed, and nobody reads this k-step's any more
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #if MPSFR_MF_CLOCK
@@ -473,21 +479,12 @@ k_otf_mfma2(const Mf2Args a) {
 #endif
             buf ^= 1;
         }
-#if MPSFR_MF_CLOCK
-        const unsigned long long tk1 = MF2_NOW();
-        t_kloop += tk1 - tk0;
-#endif
-        // second pass: the accumulator tile (rows = lines on registers / lane groups, column on
-        // the lane) is the A operand of a 16x16x16 product that sums over its rows; the G fragments
-        // of the next tile the wave needs are in flight behind the products of the current one
-        f4 P0[NJT], Q0[NJT], R2x[NJT], R2y[NJT];
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            P0[jt] = f4{0.f, 0.f, 0.f, 0.f};
-            Q0[jt] = f4{0.f, 0.f, 0.f, 0.f};
-            R2x[jt] = f4{0.f, 0.f, 0.f, 0.f};
-            R2y[jt] = f4{0.f, 0.f, 0.f, 0.f};
-        }
+        // Tail of the last k-step: no load is in flight (the wait returns at once; it is there for the
+        // static check of tools/isa_lint.py, which cannot know that), and the wave has finished its LDS
+        // reads before the barrier that frees the staging buffers.  The next item's masks and the G
+        // fragments of the second pass's first tile are requested BEFORE that barrier: they land while
+        // the wave waits for the others.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         unsigned tbits = 0;
 #pragma unroll
         for (int i = 0; i < kTW; ++i) tbits |= (unsigned)((of[i] | om[i]) != 0) << i;
@@ -502,6 +499,29 @@ k_otf_mfma2(const Mf2Args a) {
                     for (int hl = 0; hl < 2; ++hl) gq[jt][xy][hl] = Gm[((jt * 2 + xy) * 2 + hl) * 64];
         };
         if (tbits != 0) fetch_g(__builtin_ctz(tbits));
+#if MPSFR_MF_CLOCK
+        const unsigned long long tw1l = MF2_NOW();
+#endif
+        __builtin_amdgcn_s_barrier();
+        const int item_next = __builtin_amdgcn_readfirstlane(*s_next);
+        int4 it_next = make_int4(0, 0, 0, 0);
+        if (item_next < nitems) it_next = load_item(item_next);     // lands during the second pass
+#if MPSFR_MF_CLOCK
+        const unsigned long long tk1 = MF2_NOW();
+        t_wbar += tk1 - tw1l;
+        t_kloop += tk1 - tk0;
+#endif
+        // second pass: the accumulator tile (rows = lines on registers / lane groups, column on
+        // the lane) is the A operand of a 16x16x16 product that sums over its rows; the G fragments
+        // of the next tile the wave needs are in flight behind the products of the current one
+        f4 P0[NJT], Q0[NJT], R2x[NJT], R2y[NJT];
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            P0[jt] = f4{0.f, 0.f, 0.f, 0.f};
+            Q0[jt] = f4{0.f, 0.f, 0.f, 0.f};
+            R2x[jt] = f4{0.f, 0.f, 0.f, 0.f};
+            R2y[jt] = f4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int i = 0; i < kTW; ++i) {
             if (!((tbits >> i) & 1)) continue;
@@ -532,6 +552,12 @@ k_otf_mfma2(const Mf2Args a) {
                 R2y[jt] = mm16(R2y[jt], th[2], tw[2], gc[jt][1][0], gc[jt][1][1]);
             }
         }
+        // the next item's masks: in flight behind the epilogue
+        u64 mw_next = 0;
+        float c2_next = 0.f;
+        if (item_next < nitems)
+            mw_next = load_masks(__builtin_amdgcn_readfirstlane(it_next.x), __builtin_amdgcn_readfirstlane(it_next.y),
+                                 __builtin_amdgcn_readfirstlane(it_next.z), &c2_next);
 #if MPSFR_MF_CLOCK
         const unsigned long long t_red = MF2_NOW();
         t_pass2 += t_red - tk1;
@@ -565,14 +591,19 @@ k_otf_mfma2(const Mf2Args a) {
                 f4* pt = a.part + (((size_t)task * a.nl + l) * nsw + sw) * (4 * NJT * 64) + lane;
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt) {
+                    if (!part_col(jt, lr)) continue;
                     pt[(0 * NJT + jt) * 64] = P0[jt];
                     pt[(1 * NJT + jt) * 64] = Q0[jt];
-                    pt[(2 * NJT + jt) * 64] = R2x[jt];
-                    pt[(3 * NJT + jt) * 64] = R2y[jt];
+                    if (part_r2x(lk)) pt[(2 * NJT + jt) * 64] = R2x[jt];
+                    if (part_r2y(lk)) pt[(3 * NJT + jt) * 64] = R2y[jt];
                 }
             }
         }
         __syncthreads();           // the tiles in LDS have been read: the next item may stage over them
+        item = item_next;
+        it = it_next;
+        mw = mw_next;
+        c2 = c2_next;
 #if MPSFR_MF_CLOCK
         t_tail += MF2_NOW() - t_red;
 #endif
@@ -589,7 +620,8 @@ k_otf_mfma2(const Mf2Args a) {
 }
 
 // K_MF_FINISH: the stamps of the (task, group)s with several sweeps: their partial tiles added in
-// sweep order, then the epilogue of K_OTF_MFMA2.  One wave per (task, wavelength).
+// sweep order, then the epilogue of K_OTF_MFMA2.  One wave per (task, wavelength).  (One workgroup
+// per (task, group) with a wave per wavelength measured slower: 9.3 us against 7.7.)
 __global__ void __launch_bounds__(64) k_mf_finish(int N, int nl, int per, int ngr, const int* __restrict__ gsw,
                                                   const f4* __restrict__ part, float* __restrict__ pre) {
     const int l = blockIdx.x, task = blockIdx.y, lane = threadIdx.x;
@@ -603,8 +635,11 @@ __global__ void __launch_bounds__(64) k_mf_finish(int N, int nl, int per, int ng
         const f4* pt = part + (((size_t)task * nl + l) * nsw + sw) * (4 * NJT * 64) + lane;
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
-            const f4 p = pt[(0 * NJT + jt) * 64], q = pt[(1 * NJT + jt) * 64];
-            const f4 x = pt[(2 * NJT + jt) * 64], y = pt[(3 * NJT + jt) * 64];
+            const f4 z = {0.f, 0.f, 0.f, 0.f};
+            const bool col = part_col(jt, lane & 15);
+            const f4 p = col ? pt[(0 * NJT + jt) * 64] : z, q = col ? pt[(1 * NJT + jt) * 64] : z;
+            const f4 x = col && part_r2x(lane >> 4) ? pt[(2 * NJT + jt) * 64] : z;
+            const f4 y = col && part_r2y(lane >> 4) ? pt[(3 * NJT + jt) * 64] : z;
             P0[jt] = first ? p : P0[jt] + p;
             Q0[jt] = first ? q : Q0[jt] + q;
             R2x[jt] = first ? x : R2x[jt] + x;
@@ -629,9 +664,10 @@ size_t mf2_sched_bytes(int N, int ntask, int nl) {
 }
 size_t mf2_part_bytes(int N, int ntask, int nl) { return (size_t)ntask * nl * mf2_nsw(N) * 4 * NJT * 64 * sizeof(f4); }
 
-// wavelength groups of at most `permax` (8: 16 waves at 128 registers; 6: 12 waves at 168), as even
-// as possible
+// wavelength groups of at most `permax` (7: 14 waves at 128 registers; 6: 12 waves at 168), as even
+// as possible.  (Eight would fill the 160 KB of LDS to the last byte and leave no word for the queue.)
 void mf2_groups(int nl, int permax, int* per, int* ngr) {
+    if (permax > 7) permax = 7;
     *ngr = (nl + permax - 1) / permax;
     *per = (nl + *ngr - 1) / *ngr;
 }
@@ -647,7 +683,7 @@ SchedPtrs sched_ptrs(void* d_sched, int ntask, int nl) {
 }
 }  // namespace
 
-// masks of every (task, wavelength) and the work lists (d_sched[0..16] must be zero: launch_dc_sum
+// masks of every (task, wavelength) and the work lists (d_sched[0..16] must be zero: launch_colfft_dphi
 // does that).  d_dminb = nullptr: no pruning.
 void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const LamPar* d_lp,
                     const float* d_dminb, const float* d_tlb, float thr, float thr_mid, void* d_own,
@@ -663,7 +699,7 @@ void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const L
     const SchedPtrs p = sched_ptrs(d_sched, ntask, nl);
     a.gsw = p.gsw; a.sched = p.sched; a.items = p.items;
     a.cap = ntask * a.ngr * (int)mf2_nsw(N);
-    hipLaunchKernelGGL(k_mf_prep, dim3(ntask), dim3(64 * kPrepWaves), 0, s, a);
+    hipLaunchKernelGGL(k_mf_prep, dim3(a.ngr, ntask), dim3(64 * a.per), 0, s, a);
 }
 
 void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int ncu, const void* d_D0t,
@@ -690,12 +726,12 @@ void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int n
     // one persistent workgroup per CU (its LDS admits no second one), never more than there can be items
     const int maxitems = ntask * a.ngr * (int)mf2_nsw(N);
     const int nwg = ncu < maxitems ? ncu : maxitems;
-    const size_t sm = 2 * (size_t)kStage2 + 2 * (size_t)a.per * kSlab;
+    const size_t sm = 2 * (size_t)kStage2 + 2 * (size_t)a.per * kSlab + 64;     // + the queue word
     if (permax > 6) {
-        allow_smem(k_otf_mfma2<4>, 2 * (size_t)kStage2 + 2 * (size_t)8 * kSlab);
+        allow_smem(k_otf_mfma2<4>, 2 * (size_t)kStage2 + 2 * (size_t)7 * kSlab + 64);
         hipLaunchKernelGGL(k_otf_mfma2<4>, dim3(nwg), dim3(128 * a.per), sm, s, a);
     } else {
-        allow_smem(k_otf_mfma2<3>, 2 * (size_t)kStage2 + 2 * (size_t)6 * kSlab);
+        allow_smem(k_otf_mfma2<3>, 2 * (size_t)kStage2 + 2 * (size_t)6 * kSlab + 64);
         hipLaunchKernelGGL(k_otf_mfma2<3>, dim3(nwg), dim3(128 * a.per), sm, s, a);
     }
     hipLaunchKernelGGL(k_mf_finish, dim3(nl, ntask), dim3(64), 0, s, N, nl, a.per, a.ngr, (const int*)p.gsw,

@@ -121,15 +121,38 @@ __global__ void __launch_bounds__(256) k_tel_otf(int N, const uint64_t* __restri
 template <int N>
 constexpr int psd_rows() { return N / 2 + NAO / 2; }
 
+// Lines per workgroup of the two fp64 line-FFT kernels of stage A.  A 1280-point fp64 line is 22.5 KB
+// of LDS (padded) and a wave: with the plan's two lines per workgroup (plus the twiddle table, 68 KB)
+// two workgroups = FOUR waves fit a CU, and the kernels ran at a third of the bytes per second they
+// reach at 512^2.  Six lines and the table are 157.5 KB -- one workgroup of six waves per CU, and the
+// transposed stores of K_PSD_ROWFFT come in 192-byte pieces instead of 64.
+#ifndef MPSFR_A_SLOTS_ROW
+#define MPSFR_A_SLOTS_ROW 6
+#endif
+#ifndef MPSFR_A_SLOTS_COL
+#define MPSFR_A_SLOTS_COL 6
+#endif
+// (COL: K_COLFFT_DPHI; otherwise K_PSD_ROWFFT)
+template <int N, bool COL>
+constexpr int a_slots() { return N == 1280 ? (COL ? MPSFR_A_SLOTS_COL : MPSFR_A_SLOTS_ROW) : Plan<N>::SLOTS; }
+template <int N, bool COL>
+constexpr int a_threads() { return a_slots<N, COL>() * Plan<N>::TPR; }
+template <int N, bool COL>
+constexpr size_t a_smem() {
+    return (size_t)(1 + fft_nbuf<N>() * a_slots<N, COL>()) * LineCfg<N>::NPAD * sizeof(cx<double>);
+}
+
 // x^(-11/6) = (x^(-1/6))^11 for x > 0 in the float range.  y = x^(-1/6) from a hardware
-// log2/exp2 seed (relative error e0 ~ 1e-6) and two Newton steps on y^-6 = x,
+// log2/exp2 seed (relative error e0 ~ 1e-6) and Newton steps on y^-6 = x,
 //   y <- y (7 - x y^6) / 6,   e' = -3.5 e^2   (1e-6 -> 1e-11 -> 1e-21),
 // then five multiplies: ~25 fp64 instructions against ~70 for cbrt(sqrt(x)) / x^2 (this function
 // is what K_PSD_ROWFFT spends its VALU time on: every element of every distinct PSD row).
+// (NEWTON = 1: relative error ~4e-12, mixed mode -- D is stored as fp32; 2: f64 mode)
+template <int NEWTON>
 __device__ __forceinline__ double pow_m11_6(double x) {
     double y = (double)__builtin_amdgcn_exp2f(-0.16666667f * __builtin_amdgcn_logf((float)x));
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NEWTON; ++it) {
         const double y2 = y * y, y3 = y2 * y;
         y = y * fma(-(1.0 / 6.0) * x, y3 * y3, 7.0 / 6.0);
     }
@@ -137,33 +160,42 @@ __device__ __forceinline__ double pow_m11_6(double x) {
     return (y4 * y4) * (y2 * y);
 }
 
-template <int N>
-__device__ __forceinline__ double psd_value(int su, int sv, const TaskPar& p, double cfit,
-                                            const double* __restrict__ tb) {
+// fitting term (psd_fit psfrec.py:616-626) at row su, column sv of the half-pixel grid
+template <int NEWTON>
+__device__ __forceinline__ double psd_fit_value(int su, int sv, const TaskPar& p, double cfit) {
     const double fx = sv + 0.5, fy = su + 0.5;
     const double f2 = (fx * fx + fy * fy) * (1.0 / 256.0);          // L = 16 m, psfrec.py:618
-    double psd = 0.0;
-    if (f2 >= 2.25)                                                 // f >= fc = 1.5, :624
-        psd = cfit * p.r0m53 * pow_m11_6(f2 + p.inv_l0sq);
+    return f2 >= 2.25 ? cfit * p.r0m53 * pow_m11_6<NEWTON>(f2 + p.inv_l0sq) : 0.0;   // f >= fc = 1.5, :624
+}
+
+// max(fit, AO) inside the 80 x 80 corrected zone (psfrec.py:148-149), fit elsewhere
+template <int NEWTON>
+__device__ __forceinline__ double psd_with_ao(double fit, int su, int sv, const TaskPar& p,
+                                              const double* __restrict__ tb) {
     if (su >= -NAO / 2 && su < NAO / 2 && sv >= -NAO / 2 && sv < NAO / 2) {
         const int ia = su < 0 ? su + NAO : su, ib = sv < 0 ? sv + NAO : sv;
         const double g2 = (double)(su * su + sv * sv) * (1.0 / 256.0);
-        const double vk = 0.0229 * p.r0m53 * pow_m11_6(g2 + p.inv_l0sq);   // :569-571
+        const double vk = 0.0229 * p.r0m53 * pow_m11_6<NEWTON>(g2 + p.inv_l0sq);   // :569-571
         const int o = ia * NAO + ib;
         const double ao = vk * (p.cn2_0 * tb[o] + p.cn2_1 * tb[NAO * NAO + o]) +
                           tb[2 * NAO * NAO + o];
-        psd = fmax(psd, ao);                                        // :149
+        fit = fmax(fit, ao);                                        // :149
     }
-    return psd;
+    return fit;
 }
 
-template <int N>
-__global__ void __launch_bounds__(LineCfg<N>::THREADS)
+// F64: the f64 mode (two Newton steps in x^(-11/6)).  dcpart[td][workgroup]: the workgroup's share of
+// S00 = sum of the PSD = Re sum_r C[td][r][0] (bg[0,0], psfrec.py:721; compact rows with su >= 40
+// stand for two rows) -- K_COLFFT_DPHI adds the shares in a fixed order.
+template <int N, bool F64>
+__global__ void __launch_bounds__((a_threads<N, false>()))
 k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict__ aotab,
-             double cfit, cx<double>* __restrict__ C, const cx<double>* __restrict__ twg) {
+             double cfit, cx<double>* __restrict__ C, const cx<double>* __restrict__ twg,
+             double* __restrict__ dcpart) {
     using L = LineCfg<N>;
-    constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
+    constexpr int TPR = L::TPR, SLOTS = a_slots<N, false>(), THREADS = a_threads<N, false>(), NPAD = L::NPAD;
     constexpr int EPT = N / TPR, NR = psd_rows<N>();
+    constexpr int NEWTON = F64 ? 2 : 1;
     extern __shared__ __align__(16) unsigned char smem[];
     cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
     cx<double>* bufA = tw + NPAD;
@@ -179,11 +211,36 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
     const int sua = ca - NAO / 2, sub = cb - NAO / 2;
     const double* tb = aotab + ((size_t)(p.geom * ndir + d) * 3) * (NAO * NAO);
     cx<double> x[EPT];
+    if constexpr (TPR <= 64 && EPT % 2 == 0) {
+        // The fitting term depends on the column through (sv + 1/2)^2 only: columns sv and -1-sv are
+        // equal, bit for bit.  Column c = t + e TPR has its mirror N-1-c = (TPR-1-t) + (EPT-1-e) TPR:
+        // a lane evaluates the first half of its elements and takes the others from lane TPR-1-t of
+        // its slot (x^(-11/6) is what this kernel spends its vector time on).
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int c = t + e * TPR;
-        const int sv = c < N / 2 ? c : c - N;
-        x[e] = {psd_value<N>(sua, sv, p, cfit, tb), psd_value<N>(sub, sv, p, cfit, tb)};
+        for (int e = 0; e < EPT / 2; ++e) {
+            const int sv = t + e * TPR;                          // < N/2
+            x[e] = {psd_fit_value<NEWTON>(sua, sv, p, cfit), psd_fit_value<NEWTON>(sub, sv, p, cfit)};
+        }
+#pragma unroll
+        for (int e = 0; e < EPT / 2; ++e) {
+            x[EPT - 1 - e].x = __shfl_xor(x[e].x, TPR - 1, 64);
+            x[EPT - 1 - e].y = __shfl_xor(x[e].y, TPR - 1, 64);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int c = t + e * TPR;
+            const int sv = c < N / 2 ? c : c - N;
+            x[e] = {psd_fit_value<NEWTON>(sua, sv, p, cfit), psd_fit_value<NEWTON>(sub, sv, p, cfit)};
+        }
+    }
+    if (sua < NAO / 2) {                                        // (wave-uniform when TPR >= 64)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int c = t + e * TPR;
+            const int sv = c < N / 2 ? c : c - N;
+            x[e] = {psd_with_ao<NEWTON>(x[e].x, sua, sv, p, tb), psd_with_ao<NEWTON>(x[e].y, sub, sv, p, tb)};
+        }
     }
     __syncthreads();      // twiddle table
     const cx<double>* res = fft_forward_regs<double, N, false>(x, bufA + slot * NPAD,
@@ -193,13 +250,28 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
     // over (y, row) with the row fastest, each unpacking its value from the slot buffers.
     __syncthreads();
     constexpr int RW = 2 * SLOTS;                       // rows per workgroup
+    static_assert(RW <= 64, "the DC share is summed by the first RW lanes");
     const int row0 = blockIdx.x * RW;
     cx<double>* Ct = C + (size_t)td * (N / 2 + 1) * NR;
+    auto slot_buf = [&](int rr) {
+        return (L::WSYNC ? bufA : (res == bufA + slot * NPAD ? bufA : bufB)) + (rr >> 1) * NPAD;
+    };
+    if (threadIdx.x < 64) {        // DC share: Z[0] = (sum of row a) + i (sum of row b)
+        const int rr = threadIdx.x;
+        double v = 0.0;
+        if (rr < RW && row0 + rr < NR) {
+            const cx<double> z = slot_buf(rr)[lds_out<N, 16>(0)];
+            v = (row0 + rr >= NAO ? 2.0 : 1.0) * ((rr & 1) == 0 ? z.x : z.y);
+        }
+        // (a fixed order: the lanes beyond RW hold zeros)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (threadIdx.x == 0) dcpart[(size_t)td * gridDim.x + blockIdx.x] = v;
+    }
     for (int idx = threadIdx.x; idx < (N / 2 + 1) * RW; idx += THREADS) {
         const int y = idx / RW, rr = idx - y * RW;
         if (row0 + rr >= NR) continue;
-        const cx<double>* rs = (L::WSYNC ? bufA : (res == bufA + slot * NPAD ? bufA : bufB)) +
-                               (rr >> 1) * NPAD;
+        const cx<double>* rs = slot_buf(rr);
         const cx<double> z = rs[lds_out<N, 16>(y)], zm = rs[lds_out<N, 16>(y == 0 ? 0 : N - y)];
         cx<double> o;
         if ((rr & 1) == 0) o = {0.5 * (z.x + zm.x), 0.5 * (z.y - zm.y)};
@@ -208,35 +280,17 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
     }
 }
 
-// K_DC_SUM: S00[td] = Re sum_r C[td][r][0] = sum of the PSD (bg[0,0], psfrec.py:721); compact rows
-// with su >= 40 stand for two rows.
-template <int N>
-__global__ void __launch_bounds__(256) k_dc_sum(const cx<double>* __restrict__ C,
-                                                double* __restrict__ s00, int* __restrict__ zero17) {
-    constexpr int NR = psd_rows<N>();
-    __shared__ double part[4];
-    const int td = blockIdx.x;
-    // the counters of the matrix-core stage's work lists (K_MF_PREP, K_OTF_MFMA2) start from zero
-    if (zero17 != nullptr && td == 0 && threadIdx.x < 17) zero17[threadIdx.x] = 0;
-    double s = 0.0;
-    for (int r = threadIdx.x; r < NR; r += 256)
-        s += (r >= NAO ? 2.0 : 1.0) * C[(size_t)td * (N / 2 + 1) * NR + r].x;
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) s00[td] = (part[0] + part[1]) + (part[2] + part[3]);
-}
-
 // ------------------------------------------------------------------------------------------
 // K_COLFFT_DPHI: column FFTs of C and the structure function (psfrec.py:717-722 without the
 // wavelength factor): D0t[td][y][x] = 2 scale (S00 - Re S[x][y]), y in [0, N/2], x in [0, N).
 // ------------------------------------------------------------------------------------------
 template <int N, typename RO>
-__global__ void __launch_bounds__(LineCfg<N>::THREADS)
-k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, double scale2,
-              RO* __restrict__ D0t, const cx<double>* __restrict__ twg) {
+__global__ void __launch_bounds__((a_threads<N, true>()))
+k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpart, int nparts,
+              double scale2, RO* __restrict__ D0t, const cx<double>* __restrict__ twg,
+              int* __restrict__ zero17) {
     using L = LineCfg<N>;
-    constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD;
+    constexpr int TPR = L::TPR, SLOTS = a_slots<N, true>(), THREADS = a_threads<N, true>(), NPAD = L::NPAD;
     constexpr int NR = psd_rows<N>(), NLD = (NR + TPR - 1) / TPR;
     constexpr int NYG = (N / 2 + 1 + SLOTS - 1) / SLOTS;          // groups of SLOTS columns
     extern __shared__ __align__(16) unsigned char smem[];
@@ -262,7 +316,13 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ s00, 
     };
     fetch(blockIdx.x);
     for (int i = threadIdx.x; i < N; i += THREADS) tw[lds_pad(i)] = twg[i];
-    const double dc = s00[td];
+    // the counters of the matrix-core stage's work lists (K_MF_PREP, K_OTF_MFMA2) start from zero
+    if (zero17 != nullptr && td == 0 && blockIdx.x == 0 && threadIdx.x < 17) zero17[threadIdx.x] = 0;
+    // S00 = the shares of K_PSD_ROWFFT's workgroups, added in an order fixed by N alone (every wave
+    // of every workgroup gets the same bits)
+    double dc = 0.0;
+    for (int b = threadIdx.x & 63; b < nparts; b += 64) dc += dcpart[(size_t)td * nparts + b];
+    dc = wave_sum(dc);
     for (int yg = blockIdx.x; yg < NYG; yg += gridDim.x) {
         // column y: NR contiguous compact rows; rows su >= 40 also stand for row -1-su
         cx<double>* dst = bufA + slot * NPAD;
@@ -483,22 +543,28 @@ void launch_tel_otf(hipStream_t s, int N, const uint64_t* d_rows, int words, dou
                            (float*)d_tel);
 }
 
-void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp,
-                       const double* d_aotab, double cfit, void* d_C, const void* d_tw64) {
-    DISPATCH_N(N, {
-        constexpr size_t sm = fft_smem<double, NN>(true, fft_nbuf<NN>());
-        allow_smem(k_psd_rowfft<NN>, sm);
-        constexpr int NPAIR = psd_rows<NN>() / 2, SL = LineCfg<NN>::SLOTS;
-        dim3 grid((NPAIR + SL - 1) / SL, ntd);
-        hipLaunchKernelGGL(k_psd_rowfft<NN>, grid, dim3(LineCfg<NN>::THREADS), sm, s, ndir, d_tp,
-                           d_aotab, cfit, (cx<double>*)d_C, (const cx<double>*)d_tw64);
-    })
+int psd_rowfft_groups(int N) {
+    int n = 0;
+    DISPATCH_N(N, { n = (psd_rows<NN>() / 2 + a_slots<NN, false>() - 1) / a_slots<NN, false>(); })
+    return n;
 }
 
-void launch_dc_sum(hipStream_t s, int N, int ntd, const void* d_C, double* d_s00, int* d_zero) {
+void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp,
+                       const double* d_aotab, double cfit, void* d_C, const void* d_tw64,
+                       double* d_dcpart, bool f64) {
     DISPATCH_N(N, {
-        hipLaunchKernelGGL(k_dc_sum<NN>, dim3(ntd), dim3(256), 0, s, (const cx<double>*)d_C,
-                           d_s00, d_zero);
+        constexpr size_t sm = a_smem<NN, false>();
+        constexpr int NPAIR = psd_rows<NN>() / 2, SL = a_slots<NN, false>();
+        dim3 grid((NPAIR + SL - 1) / SL, ntd);
+        if (f64) {
+            allow_smem((k_psd_rowfft<NN, true>), sm);
+            hipLaunchKernelGGL((k_psd_rowfft<NN, true>), grid, dim3(a_threads<NN, false>()), sm, s, ndir, d_tp,
+                               d_aotab, cfit, (cx<double>*)d_C, (const cx<double>*)d_tw64, d_dcpart);
+        } else {
+            allow_smem((k_psd_rowfft<NN, false>), sm);
+            hipLaunchKernelGGL((k_psd_rowfft<NN, false>), grid, dim3(a_threads<NN, false>()), sm, s, ndir, d_tp,
+                               d_aotab, cfit, (cx<double>*)d_C, (const cx<double>*)d_tw64, d_dcpart);
+        }
     })
 }
 
@@ -528,11 +594,12 @@ void launch_vkeep(hipStream_t s, int N, int ntask, int ndir, int nl, const LamPa
                        d_dblk, d_tlmax, thr_sum, d_vkeep, fixed, d_dminb);
 }
 
-void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_s00,
-                        double scale2, void* d_D0t, bool f64out, const void* d_tw64) {
+void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_dcpart,
+                        double scale2, void* d_D0t, bool f64out, const void* d_tw64, int* d_zero) {
+    const int nparts = psd_rowfft_groups(N);
     DISPATCH_N(N, {
-        constexpr int SL = LineCfg<NN>::SLOTS;
-        constexpr size_t sm = fft_smem<double, NN>(true, fft_nbuf<NN>());
+        constexpr int SL = a_slots<NN, true>();
+        constexpr size_t sm = a_smem<NN, true>();
 #ifndef MPSFR_COLFFT_ITERS
 #define MPSFR_COLFFT_ITERS 5
 #endif
@@ -540,14 +607,14 @@ void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const do
         dim3 grid((NYG + MPSFR_COLFFT_ITERS - 1) / MPSFR_COLFFT_ITERS, ntd);     // column groups per workgroup
         if (f64out) {
             allow_smem(k_colfft_dphi<NN, double>, sm);
-            hipLaunchKernelGGL((k_colfft_dphi<NN, double>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
-                               (const cx<double>*)d_C, d_s00, scale2, (double*)d_D0t,
-                               (const cx<double>*)d_tw64);
+            hipLaunchKernelGGL((k_colfft_dphi<NN, double>), grid, dim3(a_threads<NN, true>()), sm, s,
+                               (const cx<double>*)d_C, d_dcpart, nparts, scale2, (double*)d_D0t,
+                               (const cx<double>*)d_tw64, d_zero);
         } else {
             allow_smem(k_colfft_dphi<NN, float>, sm);
-            hipLaunchKernelGGL((k_colfft_dphi<NN, float>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
-                               (const cx<double>*)d_C, d_s00, scale2, (float*)d_D0t,
-                               (const cx<double>*)d_tw64);
+            hipLaunchKernelGGL((k_colfft_dphi<NN, float>), grid, dim3(a_threads<NN, true>()), sm, s,
+                               (const cx<double>*)d_C, d_dcpart, nparts, scale2, (float*)d_D0t,
+                               (const cx<double>*)d_tw64, d_zero);
         }
     })
 }

@@ -614,30 +614,42 @@ __device__ __forceinline__ void moffat_accumulate(const RE* pix, int lane, const
     // d(1/a^2)/d eta / (1/a^2) = s'/s with s' = 2^eta ln2
     const RE dKn = (s_ + (RE)1) * (RE)0.69314718055994530942 * fit_rcp<RE>(s_);
     const RE I = v[0], p0 = v[1], q0 = v[2], nsq = n * n;
-#pragma unroll 5
-    for (int m = 0; m < NPX; ++m) {
-        const int o = lane + m * 64;
-        const RE dp = (RE)(o / NS) - p0, dq = (RE)(o % NS) - q0;
-        const RE u = dp * dp + dq * dq;
+    // Pixel map of the model passes: the lane is a cell (lr, lc) of an 8 x 8 block, and the 25 blocks
+    // of the stamp are walked as 5 x 5 -- pixel (8 mo + lr, 8 mi + lc).  The coordinates are then one
+    // addition per block row and one per pixel (the row-major map lane + 64 m cost a
+    // division and a remainder by 40 per pixel, a fifth of the pass); the LDS reads stay free of bank
+    // conflicts (40 lr + lc is distinct modulo 64 over the wave).
+    const RE lrf = (RE)(lane >> 3) - p0, lcf = (RE)(lane & 7) - q0;
+    const RE* pl = pix + (lane >> 3) * NS + (lane & 7);
+    static_assert(NPX == 25 && NS == 40, "5 x 5 blocks of 8 x 8 pixels");
+#pragma unroll 1
+    for (int mo = 0; mo < 5; ++mo) {
+        const RE dp = (RE)(8 * mo) + lrf, dp2 = dp * dp;
+#pragma unroll
+        for (int mi = 0; mi < 5; ++mi) {
+        const RE dq = (RE)(8 * mi) + lcf;
+        const RE u = dq * dq + dp2;
         const RE gg = (RE)1 + u * K;
         const RE lg = fit_log<RE>(gg);
         const RE e = fit_exp<RE>(-n * lg);
-        const RE mo = I * e;
-        const RE r = mo - pix[o];
+        const RE mo_ = I * e;
+        const RE r = mo_ - pl[mo * 8 * NS + mi * 8];
         chi2 += r * r;
-        const RE cm = mo * n * fit_rcp<RE>(gg);
+        const RE cm = mo_ * n * fit_rcp<RE>(gg);
+        const RE ck = cm * (RE)2 * K;
         RE J[5];
         J[0] = e;
-        J[1] = cm * (RE)2 * K * dp;
-        J[2] = cm * (RE)2 * K * dq;
-        J[3] = cm * (RE)2 * K * u * i3;
-        J[4] = nsq * mo * lg - cm * u * K * dKn;         // d model / d eta
+        J[1] = ck * dp;
+        J[2] = ck * dq;
+        J[3] = ck * u * i3;
+        J[4] = nsq * mo_ * lg - cm * u * K * dKn;         // d model / d eta
         int k = 0;
 #pragma unroll
         for (int x = 0; x < 5; ++x) {
             g[x] += J[x] * r;
 #pragma unroll
             for (int y = x; y < 5; ++y) a[k++] += J[x] * J[y];
+        }
         }
     }
     ne.chi2 = wave_total(chi2);
@@ -653,12 +665,18 @@ __device__ __forceinline__ RE moffat_chi2(const DT* pix, int lane, const double*
     const RE I = (RE)va[0], p0 = (RE)va[1], q0 = (RE)va[2], n = (RE)va[4];
     const RE K = (RE)(1.0 / (va[3] * va[3]));
     RE c[5] = {(RE)0, (RE)0, (RE)0, (RE)0, (RE)0};
-#pragma unroll 5
-    for (int m = 0; m < NS * NS / 64; ++m) {
-        const int o = lane + m * 64;
-        const RE dp = (RE)(o / NS) - p0, dq = (RE)(o % NS) - q0;
-        const RE r = I * fit_exp<RE>(-n * fit_log<RE>((RE)1 + (dp * dp + dq * dq) * K)) - (RE)pix[o];
-        c[m % 5] += r * r;
+    const RE lrf = (RE)(lane >> 3) - p0, lcf = (RE)(lane & 7) - q0;       // pixel map: moffat_accumulate
+    const DT* pl = pix + (lane >> 3) * NS + (lane & 7);
+#pragma unroll 1
+    for (int mo = 0; mo < 5; ++mo) {
+        const RE dp = (RE)(8 * mo) + lrf;
+#pragma unroll
+        for (int mi = 0; mi < 5; ++mi) {
+            const RE dq = (RE)(8 * mi) + lcf;
+            const RE r = I * fit_exp<RE>(-n * fit_log<RE>((RE)1 + (dp * dp + dq * dq) * K)) -
+                         (RE)pl[mo * 8 * NS + mi * 8];
+            c[mi] += r * r;
+        }
     }
     return wave_total(((c[0] + c[1]) + (c[2] + c[3])) + c[4]);
 }
@@ -691,18 +709,22 @@ __device__ __forceinline__ void moffat_gradient(const TS* __restrict__ src, int 
     const double I = sgpr(v[0]), p0 = sgpr(v[1]), q0 = sgpr(v[2]);
     const float i3 = (float)sgpr(1.0 / v[3]), nf = (float)n, K2 = 2.0f * (float)K, Kf = (float)K;
     float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, c2sum = 0.f;
-#pragma unroll 5
-    for (int m = 0; m < NS * NS / 64; ++m) {
-        const int o = lane + m * 64;
-        const double dp = (double)(o / NS) - p0, dq = (double)(o % NS) - q0;
-        const double u = dp * dp + dq * dq;
+    const double lrd = (double)(lane >> 3) - p0, lcd = (double)(lane & 7) - q0;     // pixel map: moffat_accumulate
+    const TS* pl = src + (lane >> 3) * NS + (lane & 7);
+#pragma unroll 1
+    for (int mo = 0; mo < 5; ++mo) {
+        const double dp = (double)(8 * mo) + lrd, dp2 = dp * dp;
+#pragma unroll
+        for (int mi = 0; mi < 5; ++mi) {
+        const double dq = (double)(8 * mi) + lcd;
+        const double u = fma(dq, dq, dp2);
         const double gg = 1.0 + u * K;
         const double lg = lean_log(gg);
         const double e = lean_exp(-n * lg);
-        const double mo = I * e;
-        const float r = (float)(mo - (double)src[o]);
+        const double mo_ = I * e;
+        const float r = (float)(mo_ - (double)pl[mo * 8 * NS + mi * 8]);
         c2sum += r * r;
-        const float mof = (float)mo, uf = (float)u;
+        const float mof = (float)mo_, uf = (float)u;
         const float cm = mof * nf * __builtin_amdgcn_rcpf((float)gg);
         const float c2 = cm * K2 * r;
         g[0] += (float)e * r;
@@ -710,6 +732,7 @@ __device__ __forceinline__ void moffat_gradient(const TS* __restrict__ src, int 
         g[2] += c2 * (float)dq;
         g[3] += c2 * uf * i3;
         g[4] += (nsq * mof * (float)lg - cm * uf * Kf * dKn) * r;
+        }
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) gout[k] = wave_total((double)g[k]);    // lanes cancel: fp64

@@ -28,8 +28,8 @@ def test_library_builds_and_exports_the_header():
     assert lib.mpsfr_version() == 102
     from muse_psfr_amd._build import source_hash
     assert lib.mpsfr_build_id().decode() == source_hash()
-    assert lib.mpsfr_profile_count() == 15
-    assert lib.mpsfr_profile_name(7) == b'otf_rowfft' and lib.mpsfr_profile_name(13) == b'otf_mfma'
+    assert lib.mpsfr_profile_count() == 14
+    assert lib.mpsfr_profile_name(6) == b'otf_rowfft' and lib.mpsfr_profile_name(12) == b'otf_mfma'
 
 
 def test_header_constants_match_python():
