@@ -82,7 +82,16 @@ const char* mpsfr_last_error(void);
  * default 1: the per-wavelength stage as split-fp16 contractions on the matrix cores; 0: LDS
  * FFTs on the vector pipe); "profile" (0/1: bracket every kernel launch
  * with HIP events on the stream it is launched on -- the event packets cost ~8 % of a step);
- * "profile_only" (-1 = all kernels, else the kernel id of mpsfr_profile_name to time alone). */
+ * "profile_only" (-1 = all kernels, else the kernel id of mpsfr_profile_name to time alone);
+ * "prune_eps_f64" (f64 mode only, default 1e-13, at most 1e-6: the same bound for the line pruning
+ * of the reference-precision mode; 0 = everything).
+ * Experiment switches of the matrix-core stage (results do not depend on them beyond the last
+ * bits of the fp16 representation floor): "mf_kernel" (2 = thin-wave kernel with precision tiers
+ * for one direction, 1 = the blocked kernel that several directions always use), "mf_permax"
+ * (1..7 wavelengths per workgroup, default 6), "mf_floor" (default 1: blocks below the fp16
+ * representation floor are skipped), "mf_mid_log2" (default -18.01: blocks below 2^this of the
+ * OTF maximum run without the low half of the OTF), "mf_clock" (phase time stamps; builds with
+ * -DMPSFR_MF_CLOCK=1 only), "prune_fixed" (a fixed number of lines for the FFT form). */
 int mpsfr_set_option(mpsfr_ctx* ctx, const char* key, double value);
 
 /* Batched replacement of  Parallel(n_jobs)(delayed(compute_psf)(*args) ...)  (psfrec.py:1082-1083)
