@@ -123,6 +123,20 @@ int mpsfr_reconstruct(mpsfr_ctx* ctx, int ntask, const double* seeing, const dou
                       const uint8_t* mask_rec, const uint8_t* mask_res, double* psf_out,
                       double* psf_sum_out, double* fit_out, int on_device);
 
+/* The same over several devices: the reference's  Parallel(n_jobs=...)  fans the rows out over
+ * worker processes (psfrec.py:1082-1083); here the rows go in contiguous, balanced shards (the
+ * first ntask % nctx contexts take one row more) to `nctx` contexts -- normally one per device,
+ * created by the caller with the same dim, dimpsf, pixscale and precision -- one host thread per
+ * context.  Host buffers only, synchronous.  Per-row outputs are those of the single-context
+ * call; psf_sum_out adds the shards' sums in context order.  ntask < nctx: the first context
+ * takes everything. */
+int mpsfr_reconstruct_multi(mpsfr_ctx* const* ctxs, int nctx, int ntask, const double* seeing,
+                            const double* gl, const double* l0, const uint8_t* three_lgs,
+                            const double h[2], double wind_speed, int npsflin, int nl,
+                            const double* lbda_nm, const uint8_t* mask_rec,
+                            const uint8_t* mask_res, double* psf_out, double* psf_sum_out,
+                            double* fit_out);
+
 /* Replacement of fit_psf_cube (psfrec.py:861-871) on caller-provided stamps, e.g. the mean PSF
  * (psfrec.py:1105).  stamps: [nstamp][dimpsf][dimpsf] float64; fit_out: [nstamp][MPSFR_NFIT]. */
 int mpsfr_fit_stamps(mpsfr_ctx* ctx, int nstamp, const double* stamps, double* fit_out,

@@ -64,6 +64,9 @@ def load():
     lib.mpsfr_reconstruct.argtypes = [p, C.c_int, dp, dp, dp, u8p, dp, C.c_double, C.c_int,
                                       C.c_int, dp, u8p, u8p, p, p, p, C.c_int]
     lib.mpsfr_reconstruct.restype = C.c_int
+    lib.mpsfr_reconstruct_multi.argtypes = [C.POINTER(p), C.c_int, C.c_int, dp, dp, dp, u8p, dp, C.c_double,
+                                            C.c_int, C.c_int, dp, u8p, u8p, p, p, p]
+    lib.mpsfr_reconstruct_multi.restype = C.c_int
     lib.mpsfr_fit_stamps.argtypes = [p, C.c_int, p, p, C.c_int]
     lib.mpsfr_fit_stamps.restype = C.c_int
     lib.mpsfr_sync.argtypes = [p]
@@ -95,7 +98,7 @@ def load():
 
 
 EXPORTS = ['mpsfr_create', 'mpsfr_destroy', 'mpsfr_last_error', 'mpsfr_set_option',
-           'mpsfr_reconstruct', 'mpsfr_fit_stamps', 'mpsfr_sync', 'mpsfr_stream', 'mpsfr_wait_event',
+           'mpsfr_reconstruct', 'mpsfr_reconstruct_multi', 'mpsfr_fit_stamps', 'mpsfr_sync', 'mpsfr_stream', 'mpsfr_wait_event',
            'mpsfr_host_time', 'mpsfr_debug_fetch',
            'mpsfr_profile_count', 'mpsfr_profile_name', 'mpsfr_profile_get',
            'mpsfr_profile_reset', 'mpsfr_version', 'mpsfr_build_id', 'mpsfr_device_count']
@@ -190,6 +193,42 @@ class Context:
             self._h, nt, _dptr(seeing), _dptr(gl), _dptr(l0), _u8ptr(three), _dptr(hh),
             float(wind_speed), int(npsflin), nl, _dptr(lbda), _u8ptr(mrec), _u8ptr(mres),
             vp(psf), vp(psum), vp(fit), 0))
+        return dict(psf=psf, psf_sum=psum, fit=fit)
+
+    @staticmethod
+    def reconstruct_multi(ctxs, lbda, seeing, gl, l0, three_lgs=None, h=(100, 10000), wind_speed=None,
+                          npsflin=1, masks=None, want_psf=True, want_sum=True, want_fit=True):
+        """`reconstruct` with the rows in contiguous shards over several contexts (one per device,
+        one host thread each inside the library: mpsfr_reconstruct_multi) -- the reference's joblib
+        fan-out (psfrec.py:1082-1083).  Same outputs as the single-context call."""
+        ctxs = list(ctxs)
+        seeing = np.ascontiguousarray(np.atleast_1d(seeing), dtype=np.float64)
+        gl = np.ascontiguousarray(np.atleast_1d(gl), dtype=np.float64)
+        l0 = np.ascontiguousarray(np.atleast_1d(l0), dtype=np.float64)
+        lbda = np.ascontiguousarray(np.atleast_1d(lbda), dtype=np.float64)
+        nt, nl = seeing.size, lbda.size
+        three = np.zeros(nt, np.uint8) if three_lgs is None else \
+            np.ascontiguousarray(np.atleast_1d(three_lgs)).astype(np.uint8)
+        if wind_speed is None:
+            wind_speed = float(np.full_like(np.array(h), 12.5)[0])      # psfrec.py:61
+        hh = np.ascontiguousarray(h, dtype=np.float64)
+        if hh.size != 2:
+            raise ValueError('exactly two layers are supported (psfrec.py:66)')
+        mrec = mres = None
+        if masks is not None:
+            mrec = np.ascontiguousarray(masks[0]).astype(np.uint8).reshape(-1)
+            mres = np.ascontiguousarray(masks[1]).astype(np.uint8).reshape(-1)
+            assert mrec.size == DIM_AO * DIM_AO and mres.size == DIM_AO * DIM_AO
+        n = ctxs[0].dimpsf
+        psf = np.empty((nt, nl, n, n)) if want_psf else None
+        psum = np.empty((nl, n, n)) if want_sum else None
+        fit = np.empty((nt, nl, NFIT)) if want_fit else None
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        handles = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+        _check(ctxs[0].lib.mpsfr_reconstruct_multi(
+            handles, len(ctxs), nt, _dptr(seeing), _dptr(gl), _dptr(l0), _u8ptr(three), _dptr(hh),
+            float(wind_speed), int(npsflin), nl, _dptr(lbda), _u8ptr(mrec), _u8ptr(mres),
+            vp(psf), vp(psum), vp(fit)))
         return dict(psf=psf, psf_sum=psum, fit=fit)
 
     def reconstruct_device(self, lbda, seeing, gl, l0, three_lgs, h, wind_speed, npsflin, masks,

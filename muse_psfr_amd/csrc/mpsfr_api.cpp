@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "coeff_l0_table.h"
@@ -995,6 +996,54 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     // host cost of queueing the call: not the time spent waiting for the GPU to catch up
     c->host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count() - t_blocked;
     c->host_calls += 1;
+    return MPSFR_OK;
+}
+
+// Row shards over several contexts (one per device), one host thread each.
+int mpsfr_reconstruct_multi(mpsfr_ctx* const* ctxs, int nctx, int ntask, const double* seeing,
+                            const double* gl, const double* l0, const uint8_t* three_lgs,
+                            const double h[2], double wind_speed, int npsflin, int nl,
+                            const double* lbda_nm, const uint8_t* mask_rec, const uint8_t* mask_res,
+                            double* psf_out, double* psf_sum_out, double* fit_out) {
+    if (!ctxs || nctx < 1) return fail(MPSFR_E_INVALID, "need at least one context");
+    for (int k = 0; k < nctx; ++k)
+        if (!ctxs[k]) return fail(MPSFR_E_INVALID, "context %d is NULL", k);
+    if (ntask < 1 || nl < 1) return fail(MPSFR_E_INVALID, "ntask and nl must be positive");
+    if (nctx == 1 || ntask < nctx)
+        return mpsfr_reconstruct(ctxs[0], ntask, seeing, gl, l0, three_lgs, h, wind_speed, npsflin, nl,
+                                 lbda_nm, mask_rec, mask_res, psf_out, psf_sum_out, fit_out, 0);
+    const size_t per_stamp = (size_t)ctxs[0]->dimpsf * ctxs[0]->dimpsf;
+    for (int k = 1; k < nctx; ++k)
+        if (ctxs[k]->dimpsf != ctxs[0]->dimpsf || ctxs[k]->N != ctxs[0]->N)
+            return fail(MPSFR_E_INVALID, "the contexts must share dim and dimpsf");
+    // contiguous, balanced shards: the first ntask % nctx contexts get one row more
+    std::vector<int> start(nctx + 1, 0);
+    for (int k = 0; k < nctx; ++k) start[k + 1] = start[k] + ntask / nctx + (k < ntask % nctx ? 1 : 0);
+    std::vector<std::vector<double>> sums(psf_sum_out ? nctx : 0);
+    for (auto& v : sums) v.resize((size_t)nl * per_stamp);
+    std::vector<int> rcs(nctx, MPSFR_OK);
+    std::vector<std::string> errs(nctx);
+    std::vector<std::thread> th;
+    th.reserve(nctx);
+    for (int k = 0; k < nctx; ++k)
+        th.emplace_back([&, k] {
+            const int a = start[k], n = start[k + 1] - a;
+            rcs[k] = mpsfr_reconstruct(ctxs[k], n, seeing + a, gl + a, l0 + a, three_lgs ? three_lgs + a : nullptr, h,
+                                       wind_speed, npsflin, nl, lbda_nm, mask_rec, mask_res,
+                                       psf_out ? psf_out + (size_t)a * nl * per_stamp : nullptr,
+                                       psf_sum_out ? sums[k].data() : nullptr,
+                                       fit_out ? fit_out + (size_t)a * nl * NFIT : nullptr, 0);
+            if (rcs[k] != MPSFR_OK) errs[k] = g_err;        // (the message is thread-local)
+        });
+    for (auto& t : th) t.join();
+    for (int k = 0; k < nctx; ++k)
+        if (rcs[k] != MPSFR_OK) return fail(rcs[k], "context %d: %s", k, errs[k].c_str());
+    if (psf_sum_out)        // in context order: the result does not depend on which shard finished first
+        for (size_t e = 0; e < (size_t)nl * per_stamp; ++e) {
+            double t = sums[0][e];
+            for (int k = 1; k < nctx; ++k) t += sums[k][e];
+            psf_sum_out[e] = t;
+        }
     return MPSFR_OK;
 }
 

@@ -164,23 +164,13 @@ def _reconstruct(lbda, tasks, npsflin, h, dim, dimpsf, pixscale, precision, cuto
     try:
         if len(devs) == 1:
             return run(devs[0], 0, 0, len(tasks))
-        # Row shards over the devices, one host thread and one context per device (ctypes releases
-        # the GIL for the call): the reference's joblib fan-out (psfrec.py:1082-1083).  Per-task
-        # results do not depend on the sharding; the stamp sums are added in device order.
-        from concurrent.futures import ThreadPoolExecutor
-        from .distributed import shard_bounds
-        bounds = [bd for bd in shard_bounds(len(tasks), len(devs)) if bd[1] > bd[0]]
+        # Row shards over the devices, one context per device and one host thread each inside the
+        # library (mpsfr_reconstruct_multi): the reference's joblib fan-out (psfrec.py:1082-1083).
+        # Per-task results do not depend on the sharding; the stamp sums are added in device order.
         replica = [devs[:i].count(d) for i, d in enumerate(devs)]
-        with ThreadPoolExecutor(len(bounds)) as pool:
-            futs = [pool.submit(run, devs[i], replica[i], a, b) for i, (a, b) in enumerate(bounds)]
-            parts = [f.result() for f in futs]
-        out = {'fit': np.concatenate([p['fit'] for p in parts], axis=0),
-               'psf': np.concatenate([p['psf'] for p in parts], axis=0) if want_psf else None}
-        psum = parts[0]['psf_sum'].copy()
-        for p in parts[1:]:
-            psum += p['psf_sum']
-        out['psf_sum'] = psum
-        return out
+        ctxs = [get_context(dim, pixscale, dimpsf, precision, d, r) for d, r in zip(devs, replica)]
+        return Context.reconstruct_multi(ctxs, lbda, see, gl, l0, three, h, npsflin=npsflin, masks=masks,
+                                         want_psf=want_psf)
     except MpsfrError as e:
         if e.code == E_GRID:
             # the reference fails here with a ValueError from scipy's interpn (psfrec.py:663-683)

@@ -241,3 +241,29 @@ def test_fan_out_over_devices_matches_one_context(api, ref_masks):
     assert psfrec._fanout_devices(None, 0, 1000, 1) == [0]
     assert psfrec._fanout_devices(None, 0, 10, -1) == [0]
     assert psfrec._fanout_devices([1, 1], 0, 3, -1) == [1, 1]
+
+
+def test_reconstruct_multi_in_the_library(api):
+    """mpsfr_reconstruct_multi: row shards over several contexts with one host thread each inside the
+    library (here three contexts on the one GPU) against the single-context call; an error in a
+    worker thread reaches the caller; fewer rows than contexts."""
+    from muse_psfr_amd._lib import Context, MpsfrError
+    see, gl, l0 = api.synthetic_rows(23)
+    three = (np.arange(23) % 4 == 0).astype(np.uint8)
+    lb = np.linspace(500, 900, 5)
+    ps = api.grid_pixscale(256)
+    ctxs = [Context(dim=256, pixscale=ps, precision='mixed', device=0) for _ in range(3)]
+    try:
+        one = ctxs[0].reconstruct(lb, see, gl, l0, three, (100, 10000))
+        multi = Context.reconstruct_multi(ctxs, lb, see, gl, l0, three, (100, 10000))
+        np.testing.assert_array_equal(multi['psf'], one['psf'])
+        np.testing.assert_array_equal(multi['fit'], one['fit'])
+        np.testing.assert_allclose(multi['psf_sum'], one['psf_sum'], rtol=1e-13)
+        few = Context.reconstruct_multi(ctxs, lb, see[:2], gl[:2], l0[:2], three[:2], (100, 10000))
+        np.testing.assert_array_equal(few['fit'], one['fit'][:2])
+        with pytest.raises(MpsfrError) as e:       # 100 nm needs a crop far beyond the grid
+            Context.reconstruct_multi(ctxs, np.array([100.0, 700.0]), see, gl, l0, three, (100, 10000))
+        assert 'context' in str(e.value) and 'crop' in str(e.value)
+    finally:
+        for c in ctxs:
+            c.close()
