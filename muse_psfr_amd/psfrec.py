@@ -150,12 +150,17 @@ def _fanout_devices(devices, device, ntask, n_jobs):
 
 def _reconstruct(lbda, tasks, npsflin, h, dim, dimpsf, pixscale, precision, cutoff_masks, device,
                  want_psf=True, devices=None, n_jobs=1):
-    see = np.array([t[0] for t in tasks], dtype=float)
-    gl = np.array([t[1] for t in tasks], dtype=float)
-    l0 = np.array([t[2] for t in tasks], dtype=float)
-    three = np.array([1 if t[3] else 0 for t in tasks], dtype=np.uint8)
+    if isinstance(tasks, tuple) and len(tasks) == 2 and isinstance(tasks[0], np.ndarray):
+        st, t3 = tasks                  # ([ntask][3] seeing / GL / L0, [ntask] three-laser mode)
+        see, gl, l0 = (np.ascontiguousarray(st[:, k], dtype=float) for k in range(3))
+        three = np.asarray(t3).astype(np.uint8)
+    else:                               # list of (seeing, GL, L0, three_lgs_mode)
+        see = np.array([t[0] for t in tasks], dtype=float)
+        gl = np.array([t[1] for t in tasks], dtype=float)
+        l0 = np.array([t[2] for t in tasks], dtype=float)
+        three = np.array([1 if t[3] else 0 for t in tasks], dtype=np.uint8)
     masks = _resolve_masks(cutoff_masks)
-    devs = _fanout_devices(devices, device, len(tasks), n_jobs)
+    devs = _fanout_devices(devices, device, see.size, n_jobs)
 
     def run(dev, replica, a, b):
         ctx = get_context(dim, pixscale, dimpsf, precision, dev, replica)
@@ -163,7 +168,7 @@ def _reconstruct(lbda, tasks, npsflin, h, dim, dimpsf, pixscale, precision, cuto
                                masks=masks, want_psf=want_psf)
     try:
         if len(devs) == 1:
-            return run(devs[0], 0, 0, len(tasks))
+            return run(devs[0], 0, 0, see.size)
         # Row shards over the devices, one context per device and one host thread each inside the
         # library (mpsfr_reconstruct_multi): the reference's joblib fan-out (psfrec.py:1082-1083).
         # Per-task results do not depend on the sharding; the stamp sums are added in device order.
@@ -296,56 +301,55 @@ def compute_psf_from_sparta(filename, extname='SPARTA_ATM_DATA', npsflin=1, lmin
     if verbose:
         logger.info('Processing SPARTA table with %d values, njobs=%d ...', nrows, n_jobs)
 
-    laser_idx = []
-    to_compute = []
-    for irow in range(1, nrows + 1):
-        row = data[irow - 1]
-        values = np.array([[row['LGS%d_%s' % (k, col)] for col in ('SEEING', 'TUR_GND', 'L0')]
-                           for k in range(1, 5)], dtype=float)
-        # outlier rejection, psfrec.py:1049-1051
-        ok = (values[:, 1] > 0) & (values[:, 2] < MAX_L0) & (values[:, 2] > MIN_L0)
-        nb_gs = int(np.sum(ok))
-        three_lgs_mode = nb_gs < 4
-        if nb_gs == 0:
-            if verbose:
-                logger.info('%d/%d : No valid values, skipping this row', irow, nrows)
-            continue
-        elif nb_gs < 4:
-            if verbose:
+    # The rows are walked by NumPy, not by a Python loop (a 1000-row table spent as long in that loop
+    # as on the GPU): values[row][laser] = (seeing, GL, L0), the outlier rejection of psfrec.py:1049-1051,
+    # and the tasks in the reference's order -- rows ascending, lasers ascending inside a row.
+    values = np.empty((nrows, 4, 3), dtype=float)
+    for k in range(4):
+        for j, col in enumerate(('SEEING', 'TUR_GND', 'L0')):
+            values[:, k, j] = data['LGS%d_%s' % (k + 1, col)]
+    ok = (values[:, :, 1] > 0) & (values[:, :, 2] < MAX_L0) & (values[:, :, 2] > MIN_L0)
+    nb_gs = ok.sum(axis=1)
+    if verbose:
+        for irow in np.nonzero(nb_gs < 4)[0]:
+            if nb_gs[irow] == 0:
+                logger.info('%d/%d : No valid values, skipping this row', irow + 1, nrows)
+            else:
                 logger.info('%d/%d : Using only %d values out of 4 after outliers rejection',
-                            irow, nrows, nb_gs)
-        if mean_of_lgs:
-            seeing, GL, L0 = values[ok].mean(axis=0)
-            laser_idx.append(-1)
-            to_compute.append((seeing, GL, L0, three_lgs_mode))
-        else:
-            for i in np.where(ok)[0]:
-                seeing, GL, L0 = values[i]
-                laser_idx.append(int(i) + 1)
-                to_compute.append((seeing, GL, L0, three_lgs_mode))
+                            irow + 1, nrows, nb_gs[irow])
+    if mean_of_lgs:
+        rows = np.nonzero(nb_gs > 0)[0]
+        # the mean over the valid lasers, added in laser order like values[ok].mean(axis=0)
+        stats = np.where(ok[rows][:, :, None], values[rows], 0.0).sum(axis=1) / nb_gs[rows][:, None]
+        laser_idx = np.full(rows.size, -1)
+    else:
+        rows, las = np.nonzero(ok)
+        stats = values[rows, las]
+        laser_idx = las + 1
+    three = nb_gs[rows] < 4
+    to_compute = (stats, three)
 
-    if len(to_compute) == 0:
+    if len(stats) == 0:
         logger.warning('No valid values')
         return None
 
     if verbose:
-        for seeing, GL, L0, three in to_compute:
+        for (seeing, GL, L0), t3 in zip(stats, three):
             logger.info('Compute PSF with seeing=%.2f GL=%.2f L0=%.2f', seeing, GL, L0)
-            if three:
+            if t3:
                 logger.info('Using three lasers mode')
 
     r = _reconstruct(lbda, to_compute, npsflin, h, dim, dimpsf, pixscale, precision, cutoff_masks,
                      device, want_psf=False, devices=devices, n_jobs=n_jobs)
-    ntask, nlam = len(to_compute), lbda.size
+    ntask, nlam = len(stats), lbda.size
 
     # FIT_ROWS: the per-task tables stacked (psfrec.py:1086-1101)
     cols = _fit_columns(np.tile(lbda, ntask), r['fit'].reshape(ntask * nlam, -1), pixscale)
-    stats = np.array([t[:3] for t in to_compute], dtype=float)
     cols['SEEING'] = np.repeat(stats[:, 0], nlam)
     cols['GL'] = np.repeat(stats[:, 1], nlam)
     cols['L0'] = np.repeat(stats[:, 2], nlam)
     cols['row_idx'] = np.repeat(np.arange(1, ntask + 1), nlam)
-    cols['lgs_idx'] = np.repeat(np.array(laser_idx), nlam)
+    cols['lgs_idx'] = np.repeat(np.asarray(laser_idx), nlam)
     out.append(_table_hdu(cols, {}, 'FIT_ROWS'))
 
     # mean PSF over the tasks and its fit (psfrec.py:1104-1113)

@@ -99,8 +99,9 @@ def test_sparta_front_end_row_filtering(monkeypatch, caplog):
 
     def fake(lbda, tasks, npsflin, h, dim, dimpsf, pixscale, precision, cutoff_masks, device, want_psf=True,
              devices=None, n_jobs=1):
-        calls['tasks'] = list(tasks)
-        n, nl = len(tasks), len(lbda)
+        stats, three = tasks            # ([ntask][3] seeing / GL / L0, [ntask] three-laser mode)
+        calls['tasks'] = [tuple(float(x) for x in st) + (bool(t3),) for st, t3 in zip(stats, three)]
+        n, nl = len(stats), len(lbda)
         fit = np.zeros((n, nl, 16))
         fit[:, :, 3] = 2.0
         fit[:, :, 4] = 2.5
