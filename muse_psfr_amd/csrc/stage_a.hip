@@ -137,9 +137,15 @@ template <int N, bool COL>
 constexpr int a_slots() { return N == 1280 ? (COL ? MPSFR_A_SLOTS_COL : MPSFR_A_SLOTS_ROW) : Plan<N>::SLOTS; }
 template <int N, bool COL>
 constexpr int a_threads() { return a_slots<N, COL>() * Plan<N>::TPR; }
+// The pass twiddles of a thread live in registers where the plan needs at most 20 of them (every grid
+// but 1280): no table in LDS (a quarter of the LDS reads of a transform, and a fifth of the workgroup's
+// LDS -- one more workgroup per CU), and a thread fetches its 12-19 values straight from the table
+// in memory instead of the workgroup copying all N.
+template <int N>
+constexpr bool a_regtw() { return use_reg_twiddles<N>(); }
 template <int N, bool COL>
 constexpr size_t a_smem() {
-    return (size_t)(1 + fft_nbuf<N>() * a_slots<N, COL>()) * LineCfg<N>::NPAD * sizeof(cx<double>);
+    return (size_t)((a_regtw<N>() ? 0 : 1) + fft_nbuf<N>() * a_slots<N, COL>()) * LineCfg<N>::NPAD * sizeof(cx<double>);
 }
 
 // x^(-11/6) = (x^(-1/6))^11 for x > 0 in the float range.  y = x^(-1/6) from a hardware
@@ -197,14 +203,22 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
     constexpr int EPT = N / TPR, NR = psd_rows<N>();
     constexpr int NEWTON = F64 ? 2 : 1;
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool REGTW = a_regtw<N>();
     cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
-    cx<double>* bufA = tw + NPAD;
+    cx<double>* bufA = tw + (REGTW ? 0 : NPAD);
     cx<double>* bufB = bufA + SLOTS * NPAD;    // only used when a slot spans two wavefronts
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
     const int pair = blockIdx.x * SLOTS + slot;             // rows 2 pair, 2 pair + 1 (compact)
     const int td = blockIdx.y;
     const int task = td / ndir, d = td % ndir;
-    for (int i = threadIdx.x; i < N; i += THREADS) tw[lds_pad(i)] = twg[i];
+    TwRegs<double, N> twr;
+    const cx<double>* twp = tw;
+    if constexpr (REGTW) {
+        twr.init(twg, t);
+        twp = twr.w;
+    } else {
+        for (int i = threadIdx.x; i < N; i += THREADS) tw[lds_pad(i)] = twg[i];
+    }
     const TaskPar p = tp[task];
     const bool valid = 2 * pair < NR;
     const int ca = valid ? 2 * pair : 0, cb = ca + 1;       // NR is even
@@ -242,9 +256,9 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
             x[e] = {psd_with_ao<NEWTON>(x[e].x, sua, sv, p, tb), psd_with_ao<NEWTON>(x[e].y, sub, sv, p, tb)};
         }
     }
-    __syncthreads();      // twiddle table
-    const cx<double>* res = fft_forward_regs<double, N, false>(x, bufA + slot * NPAD,
-                                                               bufB + slot * NPAD, tw, t);
+    if constexpr (!REGTW) __syncthreads();      // twiddle table
+    const cx<double>* res = fft_forward_regs<double, N, REGTW>(x, bufA + slot * NPAD,
+                                                               bufB + slot * NPAD, twp, t);
     // Store transposed, Ct[td][y][compact row], so that K_COLFFT_DPHI reads whole columns
     // contiguously: the workgroup's 2*SLOTS rows of one y form a 32*SLOTS-byte segment; lanes run
     // over (y, row) with the row fastest, each unpacking its value from the slot buffers.
@@ -294,8 +308,9 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpar
     constexpr int NR = psd_rows<N>(), NLD = (NR + TPR - 1) / TPR;
     constexpr int NYG = (N / 2 + 1 + SLOTS - 1) / SLOTS;          // groups of SLOTS columns
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool REGTW = a_regtw<N>();
     cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
-    cx<double>* bufA = tw + NPAD;
+    cx<double>* bufA = tw + (REGTW ? 0 : NPAD);
     cx<double>* bufB = bufA + SLOTS * NPAD;
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
     const int td = blockIdx.y;
@@ -315,7 +330,14 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpar
         }
     };
     fetch(blockIdx.x);
-    for (int i = threadIdx.x; i < N; i += THREADS) tw[lds_pad(i)] = twg[i];
+    TwRegs<double, N> twr;
+    const cx<double>* twp = tw;
+    if constexpr (REGTW) {
+        twr.init(twg, t);
+        twp = twr.w;
+    } else {
+        for (int i = threadIdx.x; i < N; i += THREADS) tw[lds_pad(i)] = twg[i];
+    }
     // the counters of the matrix-core stage's work lists (K_MF_PREP, K_OTF_MFMA2) start from zero
     if (zero17 != nullptr && td == 0 && blockIdx.x == 0 && threadIdx.x < 17) zero17[threadIdx.x] = 0;
     // S00 = the shares of K_PSD_ROWFFT's workgroups, added in an order fixed by N alone (every wave
@@ -338,7 +360,7 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpar
         __syncthreads();
         if (yg + (int)gridDim.x < NYG) fetch(yg + gridDim.x);
         const cx<double>* res =
-            fft_forward<double, N, false>(bufA + slot * NPAD, bufB + slot * NPAD, tw, t);
+            fft_forward<double, N, REGTW>(bufA + slot * NPAD, bufB + slot * NPAD, twp, t);
         const int y = yg * SLOTS + slot;
         if (y <= N / 2) {
             RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N;
