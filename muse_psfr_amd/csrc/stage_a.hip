@@ -337,6 +337,7 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpar
         twp = twr.w;
     } else {
         for (int i = threadIdx.x; i < N; i += THREADS) tw[lds_pad(i)] = twg[i];
+        __syncthreads();        // the table is the one thing the waves of the workgroup share
     }
     // the counters of the matrix-core stage's work lists (K_MF_PREP, K_OTF_MFMA2) start from zero
     if (zero17 != nullptr && td == 0 && blockIdx.x == 0 && threadIdx.x < 17) zero17[threadIdx.x] = 0;
@@ -357,7 +358,9 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpar
                 if (su >= NAO / 2) dst[lds_pad(N - 1 - su)] = pre[k];
             }
         }
-        __syncthreads();
+        // (a slot of at most one wave stages, transforms and reads its own line: no workgroup barrier,
+        // the waves of a workgroup run free of each other)
+        fft_sync<L::WSYNC>();
         if (yg + (int)gridDim.x < NYG) fetch(yg + gridDim.x);
         const cx<double>* res =
             fft_forward<double, N, REGTW>(bufA + slot * NPAD, bufB + slot * NPAD, twp, t);
@@ -366,7 +369,7 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpar
             RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N;
             for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
         }
-        __syncthreads();            // all reads of the result are done: the buffers may be restaged
+        fft_sync<L::WSYNC>();       // all reads of the result are done: the buffers may be restaged
     }
 }
 
