@@ -1,8 +1,10 @@
 #!/bin/bash
+# GPU check of a change: tests, phase clock of the matrix-core kernel (needs variants/clock.so), bench at 1 / 2 / 3 lanes and
+# the native grid, single-lane kernel trace.  Run on the GPU box: gpurun -- bash scripts/r3_check.sh
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r3_pytest7.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -8 gpurun_out/r3_pytest7.log
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r3_pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -8 gpurun_out/r3_pytest.log
 [ $rc -ne 0 ] && exit 1
-MPSFR_LIB_PATH=variants/clock.so python scripts/mf2_clock.py > gpurun_out/mf2_clock3.txt 2>&1; cat gpurun_out/mf2_clock3.txt | grep -v amdgpu.ids
+MPSFR_LIB_PATH=variants/clock.so python scripts/mf2_clock.py > gpurun_out/mf2_clock.txt 2>&1; cat gpurun_out/mf2_clock.txt | grep -v amdgpu.ids
 B="--cpu-rows 48 --f64-steps 0 --profile-steps 10 --unpruned-steps 0 --host-steps 0 --native-steps 0"
 one() { python3 bench.py $B "$@" 2>/dev/null | python3 -c "
 import json,sys
