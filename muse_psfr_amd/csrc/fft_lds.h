@@ -270,7 +270,11 @@ struct TwRegs {
 //           never has to be staged through LDS.
 // All inputs of the thread are gathered before anything is written, so `in` may equal `out`
 // when the slot is a single wavefront (in-order LDS) -- see fft_forward.
-template <typename R, int N, int P_, bool REGTW, bool FROMREG>
+// TOREG: the pass writes nothing to LDS; its results stay in `out`, used as a register array:
+//        out[b * RADIX + q] = element (t + b TPR) % NS + ((t + b TPR) - (t + b TPR) % NS) RADIX + q NS
+//        of the pass's image -- for the LAST pass of a plan that is element t + b TPR + q N / RADIX of
+//        the transform: for every q the lanes of a slot hold consecutive elements.
+template <typename R, int N, int P_, bool REGTW, bool FROMREG, bool TOREG = false>
 __device__ __forceinline__ void fft_pass(const cx<R>* in, cx<R>* out, const cx<R>* tw, int t) {
     using P = Plan<N>;
     constexpr int RADIX = P::radix[P_];
@@ -313,6 +317,13 @@ __device__ __forceinline__ void fft_pass(const cx<R>* in, cx<R>* out, const cx<R
             }
         }
         dftr<R, RADIX>(v[b]);
+    }
+    if constexpr (TOREG) {
+#pragma unroll
+        for (int b = 0; b < NBT; ++b)
+#pragma unroll
+            for (int q = 0; q < RADIX; ++q) out[b * RADIX + q] = v[b][q];
+        return;
     }
 #pragma unroll
     for (int b = 0; b < NBT; ++b) {
@@ -357,6 +368,33 @@ __device__ __forceinline__ cx<R>* fft_forward_regs(const cx<R>* x, cx<R>* a, cx<
 template <typename R, int N, bool REGTW>
 __device__ __forceinline__ cx<R>* fft_forward(cx<R>* a, cx<R>* b, const cx<R>* tw, int t) {
     return fft_rest<R, N, REGTW, 0>(a, b, tw, t);
+}
+
+// Passes P_ .. NP-2 through LDS, the last one into registers (fft_pass, TOREG): for a consumer that
+// reads exactly the elements a thread produces, the last image never goes through LDS.
+template <typename R, int N, bool REGTW, int P_>
+__device__ __forceinline__ void fft_rest_lastreg(cx<R>* cur, cx<R>* other, const cx<R>* tw, int t, cx<R>* vout) {
+    using P = Plan<N>;
+    constexpr bool WS = LineCfg<N>::WSYNC;
+    if constexpr (P_ == P::NP - 1) {
+        fft_pass<R, N, P_, REGTW, false, true>(cur, vout, tw, t);
+    } else {
+        cx<R>* dst = WS ? cur : other;
+        fft_pass<R, N, P_, REGTW, false>(cur, dst, tw, t);
+        fft_sync<WS>();
+        fft_rest_lastreg<R, N, REGTW, P_ + 1>(dst, WS ? other : cur, tw, t, vout);
+    }
+}
+// elements per thread of the last pass's register image, and the transform index of entry (b, q)
+template <int N>
+constexpr int fft_last_radix() { return Plan<N>::radix[Plan<N>::NP - 1]; }
+template <int N>
+constexpr int fft_last_nbt() { return N / fft_last_radix<N>() / Plan<N>::TPR; }
+// Line staged in LDS buffer `a` (as for fft_forward) -> vout[fft_last_nbt * fft_last_radix]:
+// vout[b * RADIX + q] = X[t + b TPR + q N / RADIX].
+template <typename R, int N, bool REGTW>
+__device__ __forceinline__ void fft_forward_lastreg(cx<R>* a, cx<R>* b, const cx<R>* tw, int t, cx<R>* vout) {
+    fft_rest_lastreg<R, N, REGTW, 0>(a, b, tw, t, vout);
 }
 
 // LDS buffers per slot: one when a slot is a single wavefront (in-place passes), else two

@@ -362,14 +362,34 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpar
         // the waves of a workgroup run free of each other)
         fft_sync<L::WSYNC>();
         if (yg + (int)gridDim.x < NYG) fetch(yg + gridDim.x);
-        const cx<double>* res =
-            fft_forward<double, N, REGTW>(bufA + slot * NPAD, bufB + slot * NPAD, twp, t);
+        // The last pass leaves its results in registers: entry (b, q) is element t + b TPR + q N / RADIX
+        // of the transform, so for every (b, q) the lanes of the slot hold consecutive x and the stores
+        // of D are whole cache lines -- the last image never goes through LDS (a fifth of the
+        // kernel's LDS traffic).
+        // (Not at 1280: the radix-20 pass with its 20 results live beside the prefetched column does
+        // not fit the register file.)
         const int y = yg * SLOTS + slot;
-        if (y <= N / 2) {
-            RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N;
-            for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
+        if constexpr (N != 1280) {
+            constexpr int LR = fft_last_radix<N>(), LB = fft_last_nbt<N>();
+            cx<double> vout[LB * LR];
+            fft_forward_lastreg<double, N, REGTW>(bufA + slot * NPAD, bufB + slot * NPAD, twp, t, vout);
+            if (y <= N / 2) {
+                RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N + t;
+#pragma unroll
+                for (int b = 0; b < LB; ++b)
+#pragma unroll
+                    for (int q = 0; q < LR; ++q)
+                        out[b * TPR + q * (N / LR)] = (RO)(scale2 * (dc - vout[b * LR + q].x));
+            }
+        } else {
+            const cx<double>* res =
+                fft_forward<double, N, REGTW>(bufA + slot * NPAD, bufB + slot * NPAD, twp, t);
+            if (y <= N / 2) {
+                RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N;
+                for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
+            }
         }
-        fft_sync<L::WSYNC>();       // all reads of the result are done: the buffers may be restaged
+        fft_sync<L::WSYNC>();       // all reads of the line are done: the buffers may be restaged
     }
 }
 
