@@ -397,6 +397,17 @@ __device__ __forceinline__ void fft_forward_lastreg(cx<R>* a, cx<R>* b, const cx
     fft_rest_lastreg<R, N, REGTW, 0>(a, b, tw, t, vout);
 }
 
+// The same for a line whose elements are in registers (x[e] = line[t + e TPR], as for
+// fft_forward_regs).
+template <typename R, int N, bool REGTW>
+__device__ __forceinline__ void fft_forward_regs_lastreg(const cx<R>* x, cx<R>* a, cx<R>* b, const cx<R>* tw,
+                                                         int t, cx<R>* vout) {
+    static_assert(Plan<N>::NP >= 2, "needs a pass through LDS before the last one");
+    fft_pass<R, N, 0, REGTW, true>(x, a, tw, t);
+    fft_sync<LineCfg<N>::WSYNC>();
+    fft_rest_lastreg<R, N, REGTW, 1>(a, b, tw, t, vout);
+}
+
 // LDS buffers per slot: one when a slot is a single wavefront (in-place passes), else two
 template <int N>
 constexpr int fft_nbuf() { return LineCfg<N>::WSYNC ? 1 : 2; }

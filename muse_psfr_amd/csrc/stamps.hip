@@ -269,7 +269,7 @@ __device__ __forceinline__ void cf_split0(const cx<R>* res, int kx, cx<R>& a0,
 // and the stamp sum read half the bytes), double when they go straight into the caller's psf_out.
 // R: arithmetic type (float: mixed mode; double: f64 mode, 74 KB of LDS).
 template <typename R, typename TF>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 4 : 2)))
 k_conv_fft(int nl, const R* __restrict__ pre, const cx<R>* __restrict__ khat_tt,
            const cx<R>* __restrict__ khat_muse, TF* __restrict__ fin) {
     extern __shared__ __align__(16) unsigned char conv_smem[];
@@ -305,28 +305,39 @@ k_conv_fft(int nl, const R* __restrict__ pre, const cx<R>* __restrict__ khat_tt,
         __syncthreads();        // F is free: the inverse rows of the previous pass have read it
         if (slot < NS / 2) cf_rows_forward(x, F, buf, tw, slot, t);
         __syncthreads();
-        {   // columns: forward, multiply by the kernel spectrum, inverse (conjugation trick)
-            const cx<R>* res = cf_col_forward(F, NS, buf, tw, slot, t);
+        {   // columns: forward, multiply by the kernel spectrum, inverse (conjugation trick).  A thread
+            // consumes exactly the elements t + 8 e its last pass produces, so the results of the
+            // transforms stay in registers (fft_pass, TOREG) -- except in slot 0, whose packed DC /
+            // Nyquist column needs the mirrored elements of the forward transform.
             cx<R> y[8];
+            if (slot == 0) {
+                const cx<R>* res = cf_col_forward(F, NS, buf, tw, slot, t);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int kx = t + 8 * e;
-                cx<R> v;
-                if (slot == 0) {
+                for (int e = 0; e < 8; ++e) {
                     cx<R> a0, a32;
-                    cf_split0(res, kx, a0, a32);
+                    cf_split0(res, t + 8 * e, a0, a32);
                     const cx<R> b0 = cmul(a0, khv[e]), b32 = cmul(a32, khn[e]);
-                    v = {b0.x - b32.y, b0.y + b32.x};
-                } else {
-                    v = cmul(res[lds_out<CF, 8>(kx)], khv[e]);
+                    y[e] = conjf<R>(cx<R>{b0.x - b32.y, b0.y + b32.x});
                 }
-                y[e] = conjf<R>(v);
+                fft_sync<true>();           // the line buffer is rewritten by the inverse transform
+            } else {
+                cx<R> xin[8], v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = t + 8 * e;
+                    xin[e] = r < NS ? F[r][slot] : cx<R>{(R)0, (R)0};
+                }
+                fft_forward_regs_lastreg<R, CF, true>(xin, buf, buf, tw.w, t, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = conjf<R>(cmul(v[e], khv[e]));
+                fft_sync<true>();
             }
-            const cx<R>* r2 = fft_forward_regs<R, CF, true>(y, buf, buf, tw.w, t);
+            cx<R> r2[8];
+            fft_forward_regs_lastreg<R, CF, true>(y, buf, buf, tw.w, t, r2);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int r = t + 8 * e;
-                if (r >= KS / 2 && r < KS / 2 + NS) F[r][slot] = conjf<R>(r2[lds_out<CF, 8>(r)]);
+                if (r >= KS / 2 && r < KS / 2 + NS) F[r][slot] = conjf<R>(r2[e]);
             }
         }
         __syncthreads();
@@ -351,22 +362,23 @@ k_conv_fft(int nl, const R* __restrict__ pre, const cx<R>* __restrict__ khat_tt,
                 }
                 z[e] = {a.x - b.y, -(a.y + b.x)};      // conj(A + iB)
             }
-            const cx<R>* res = fft_forward_regs<R, CF, true>(z, buf, buf, tw.w, t);
             // y_a = Re conj(res) = res.x, y_b = Im conj(res) = -res.y at columns [20, 60)
+            if (pass == 1) {    // the final stamp: a thread writes the columns its last pass produced
+                cx<R> v[8];
+                fft_forward_regs_lastreg<R, CF, true>(z, buf, buf, tw.w, t, v);
+                TF* out = fin + ((size_t)task * nl + l) * NS * NS;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = t + 8 * e;
-                if (c >= KS / 2 && c < KS / 2 + NS) {
-                    const cx<R> v = res[lds_out<CF, 8>(c)];
-                    const int i = 2 * slot, j = c - KS / 2;
-                    if (pass == 1) {
-                        TF* out = fin + ((size_t)task * nl + l) * NS * NS;
-                        out[i * NS + j] = (TF)v.x;
-                        out[(i + 1) * NS + j] = (TF)(-v.y);
+                for (int e = 0; e < 8; ++e) {
+                    const int c = t + 8 * e;
+                    if (c >= KS / 2 && c < KS / 2 + NS) {
+                        const int i = 2 * slot, j = c - KS / 2;
+                        out[i * NS + j] = (TF)v[e].x;
+                        out[(i + 1) * NS + j] = (TF)(-v[e].y);
                     }
                 }
-            }
-            if (pass == 0) {    // rows 2 slot, 2 slot + 1 of the intermediate image, columns t + 8 e
+            } else {            // rows 2 slot, 2 slot + 1 of the intermediate image, columns t + 8 e
+                                // (shifted by 20: another thread's results, through LDS)
+                const cx<R>* res = fft_forward_regs<R, CF, true>(z, buf, buf, tw.w, t);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = t + 8 * e;
