@@ -315,18 +315,35 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpar
     const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR;
     const int td = blockIdx.y;
     const cx<double>* Ct = C + (size_t)td * (N / 2 + 1) * NR;
-    // A workgroup walks the column groups blockIdx.x, blockIdx.x + gridDim.x, ...: the twiddle
-    // table is staged once, and the NR values of the next column are in flight (registers) behind
-    // the transform of the current one -- one workgroup per column group spent 47 % of its wave
-    // cycles waiting for its loads of C.
-    cx<double> pre[NLD];
+    // A workgroup walks the column groups blockIdx.x, blockIdx.x + gridDim.x, ...: the values of the
+    // next column are in flight (registers) behind the transform of the current one -- one workgroup
+    // per column group spent 47 % of its wave cycles waiting for its loads of C.
+    // DIRECT (every grid but 1280): a thread loads the column in the layout of the FIRST PASS, element
+    // n = t + e TPR of the mirrored line straight from its compact row (su >= -40: row su; below: the
+    // row -1-su that stands for it), so the line is never staged in LDS: together with the last pass
+    // kept in registers, a 512-point column costs 32 LDS accesses per lane instead of 66.  (At 1280 the
+    // 20 elements per lane do not fit beside the radix-20 pass: the column is staged.)
+    // (and at 256, two lines per wave, the staged form measured 7 % faster)
+    constexpr bool DIRECT = N != 1280 && N != 256;
+    constexpr int EPT = N / TPR;
+    cx<double> pre[DIRECT ? EPT : NLD];
     auto fetch = [&](int yg) {
         const int y = yg * SLOTS + slot;
         const cx<double>* col = Ct + (size_t)(y <= N / 2 ? y : 0) * NR;
+        if constexpr (DIRECT) {
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int ci = t + k * TPR;
-            pre[k] = (ci < NR && y <= N / 2) ? col[ci] : cx<double>{0.0, 0.0};
+            for (int e = 0; e < EPT; ++e) {
+                const int n = t + e * TPR;
+                const int su = n < N / 2 ? n : n - N;
+                const int ci = (su >= -NAO / 2 ? su : -1 - su) + NAO / 2;
+                pre[e] = y <= N / 2 ? col[ci] : cx<double>{0.0, 0.0};
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int ci = t + k * TPR;
+                pre[k] = (ci < NR && y <= N / 2) ? col[ci] : cx<double>{0.0, 0.0};
+            }
         }
     };
     fetch(blockIdx.x);
@@ -347,32 +364,17 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpar
     for (int b = threadIdx.x & 63; b < nparts; b += 64) dc += dcpart[(size_t)td * nparts + b];
     dc = wave_sum(dc);
     for (int yg = blockIdx.x; yg < NYG; yg += gridDim.x) {
-        // column y: NR contiguous compact rows; rows su >= 40 also stand for row -1-su
-        cx<double>* dst = bufA + slot * NPAD;
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int ci = t + k * TPR;
-            if (ci < NR) {
-                const int su = ci - NAO / 2;
-                dst[lds_pad(su < 0 ? su + N : su)] = pre[k];
-                if (su >= NAO / 2) dst[lds_pad(N - 1 - su)] = pre[k];
-            }
-        }
-        // (a slot of at most one wave stages, transforms and reads its own line: no workgroup barrier,
-        // the waves of a workgroup run free of each other)
-        fft_sync<L::WSYNC>();
-        if (yg + (int)gridDim.x < NYG) fetch(yg + gridDim.x);
-        // The last pass leaves its results in registers: entry (b, q) is element t + b TPR + q N / RADIX
-        // of the transform, so for every (b, q) the lanes of the slot hold consecutive x and the stores
-        // of D are whole cache lines -- the last image never goes through LDS (a fifth of the
-        // kernel's LDS traffic).
-        // (Not at 1280: the radix-20 pass with its 20 results live beside the prefetched column does
-        // not fit the register file.)
         const int y = yg * SLOTS + slot;
-        if constexpr (N != 1280) {
+        if constexpr (DIRECT) {
+            // first pass from the registers, the next column requested behind it, the last pass into
+            // registers: entry (b, q) is element t + b TPR + q N / RADIX of the transform, so for every
+            // (b, q) the lanes of the slot hold consecutive x and the stores of D are whole cache lines
             constexpr int LR = fft_last_radix<N>(), LB = fft_last_nbt<N>();
             cx<double> vout[LB * LR];
-            fft_forward_lastreg<double, N, REGTW>(bufA + slot * NPAD, bufB + slot * NPAD, twp, t, vout);
+            fft_pass<double, N, 0, REGTW, true>(pre, bufA + slot * NPAD, twp, t);
+            fft_sync<L::WSYNC>();
+            if (yg + (int)gridDim.x < NYG) fetch(yg + gridDim.x);
+            fft_rest_lastreg<double, N, REGTW, 1>(bufA + slot * NPAD, bufB + slot * NPAD, twp, t, vout);
             if (y <= N / 2) {
                 RO* out = D0t + ((size_t)td * (N / 2 + 1) + y) * N + t;
 #pragma unroll
@@ -382,6 +384,19 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpar
                         out[b * TPR + q * (N / LR)] = (RO)(scale2 * (dc - vout[b * LR + q].x));
             }
         } else {
+            // column y: NR contiguous compact rows; rows su >= 40 also stand for row -1-su
+            cx<double>* dst = bufA + slot * NPAD;
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int ci = t + k * TPR;
+                if (ci < NR) {
+                    const int su = ci - NAO / 2;
+                    dst[lds_pad(su < 0 ? su + N : su)] = pre[k];
+                    if (su >= NAO / 2) dst[lds_pad(N - 1 - su)] = pre[k];
+                }
+            }
+            fft_sync<L::WSYNC>();
+            if (yg + (int)gridDim.x < NYG) fetch(yg + gridDim.x);
             const cx<double>* res =
                 fft_forward<double, N, REGTW>(bufA + slot * NPAD, bufB + slot * NPAD, twp, t);
             if (y <= N / 2) {
@@ -389,7 +404,9 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpar
                 for (int x = t; x < N; x += TPR) out[x] = (RO)(scale2 * (dc - res[lds_out<N, 16>(x)].x));
             }
         }
-        fft_sync<L::WSYNC>();       // all reads of the line are done: the buffers may be restaged
+        // (a slot of at most one wave transforms and reads its own line: no workgroup barrier, the
+        // waves of a workgroup run free of each other)
+        fft_sync<L::WSYNC>();       // all reads of the line are done: the buffer may be rewritten
     }
 }
 
