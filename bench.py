@@ -28,7 +28,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 DOMINANT = 'otf_rowfft'      # the kernel the roofline object describes (FFT form; 'otf_mfma' on the matrix cores)
-PRIME_STEPS = 320            # untimed, before the warm-up steps (~80 ms: the GPU reaches its sustained clocks only after ~40 ms of load)
+PRIME_STEPS = 1200           # untimed, before the warm-up steps (~0.3 s: the GPU reaches its sustained clocks only after tens of ms of load,
+                             # longer after the CPU-baseline leg has left it idle for half a minute)
 PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector / fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak (same guide)
 PEAK_HBM_GBPS = 8000.0
