@@ -1069,8 +1069,18 @@ __global__ void __launch_bounds__(256) k_stamp_sum(int ntask, int nl, const TF* 
     const size_t e = (size_t)blockIdx.x * 64 + lane;
     const size_t per = (size_t)nl * NS * NS;
     double s = 0.0;
-    if (e < per)
-        for (int t = wave; t < ntask; t += 4) s += (double)fin[(size_t)t * per + e];
+    if (e < per) {
+        // (the loads of eight tasks in flight together; the additions stay in task order)
+        int t = wave;
+        for (; t + 28 < ntask; t += 32) {
+            TF v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fin[(size_t)(t + 4 * k) * per + e];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += (double)v[k];
+        }
+        for (; t < ntask; t += 4) s += (double)fin[(size_t)t * per + e];
+    }
     part[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && e < per) {
