@@ -55,7 +55,7 @@ enum KernelId {
     K_STAMP_SUM,
     K_VKEEP,        // FFT path: K_DMIN + K_VKEEP
     K_OTF_MFMA,     // matrix-core per-wavelength stage (K_OTF_MFMA2 + K_MF_FINISH, or K_OTF_MFMA1)
-    K_MF_PREP,      // its preparation: K_DMIN + K_MF_MASKS + K_MF_SCHED (or K_DMIN + K_VKEEP + K_TASK_ORDER)
+    K_MF_PREP,      // its preparation: K_DMIN + K_MF_PREP (or K_DMIN + K_VKEEP + K_TASK_ORDER)
     K_COUNT
 };
 

@@ -1114,7 +1114,7 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
             HIPCHK(hipMemcpy(tb.data(), c->tlb.p, tb.size() * sizeof(float), hipMemcpyDeviceToHost));
         }
         double steps = 0.0, tiles = 0.0, steps_full = 0.0, steps_mid = 0.0;
-        if (c->last_mf2) {          // the masks the thin-wave kernel ran on (K_MF_MASKS)
+        if (c->last_mf2) {          // the masks the thin-wave kernel ran on (K_MF_PREP)
             std::vector<unsigned long long> own((size_t)tc * nl * nmt * 2);
             HIPCHK(hipMemcpy(own.data(), ln.mown.p, own.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             for (size_t i = 0; i < own.size(); i += 2) {

@@ -17,23 +17,27 @@
 //      - above, the full three products.
 //    All three are bit-for-bit what the full products would give.
 //  * The masks (which blocks a wavelength keeps, in which tier; which blocks a wavelength group
-//    stages) are computed once per (task, wavelength) by K_MF_MASKS instead of by every wave, and
+//    stages) are computed once per (task, wavelength) by K_MF_PREP instead of by every wave, and
 //    the group's staging mask is the exact union of its members (no assumption on the order of
 //    the wavelengths).
 //  * Thin waves: a workgroup still shares the D | log2 tel tiles of a k-step through LDS between
-//    the up to eight wavelengths of a group, but every wavelength has TWO waves, each owning four
-//    of the sweep's eight m-tiles (48 accumulator registers instead of 96).  12-16 waves per CU
+//    the up to seven wavelengths of a group, but every wavelength has TWO waves, each owning four
+//    of the sweep's eight m-tiles (48 accumulator registers instead of 96).  12-14 waves per CU
 //    instead of 7 hide each other's LDS latency, LDS-DMA issue and barrier waits; the E slab of a
 //    wavelength is fetched once for its two waves (double buffered, so no wave waits for its
 //    partner before the next slab is requested).  The two partial stamps meet in LDS.
 //  * Work items and a queue.  The unit of work is (task, wavelength group, SWEEP of eight m-tiles)
 //    instead of (task, group): the sharpest PSFs keep three sweeps and six times the blocks of the
 //    broadest, and with one workgroup per (task, group) the launch ended on them at twice the
-//    balanced time.  K_MF_MASKS files every non-empty item in one of 16 lists by the number of
+//    balanced time.  K_MF_PREP files every non-empty item in one of 16 lists by the number of
 //    blocks it stages; one persistent workgroup per CU takes the items from an atomic counter,
-//    heaviest class first (longest-processing-time-first, to the width of a class).  A (task, group) with one sweep is
-//    finished by its workgroup; with several, every sweep leaves its partial tiles in memory and
-//    K_MF_FINISH adds them in sweep order (fixed order: results do not depend on who ran what).
+//    heaviest class first (longest-processing-time-first, to the width of a class).  A (task,
+//    group) with one sweep is finished by its workgroup; with several, every sweep leaves its partial
+//    tiles in memory and K_MF_FINISH adds them in sweep order (fixed order: results do not depend on
+//    who ran what).  (Whole (task, group)s as items, their sweeps run in sequence by one workgroup,
+//    need no K_MF_FINISH and balance so much worse that the launch is 20 % longer: DESIGN.md.)
+//  * The queue runs a little ahead: the next item's number is drawn during the last k-step, its
+//    descriptor and masks are loaded behind the second pass and the epilogue.
 #include "mf_common.h"
 
 namespace mpsfr {
@@ -184,11 +188,11 @@ struct Mf2Args {
     const LamPar* lp;
     const h8* E;
     const h4* G;
-    const u64* own;          // K_MF_MASKS
+    const u64* own;          // K_MF_PREP
     const u64* uni;
     const u64* ksum;
     const u64* kuni;
-    int* sched;              // [0..15] items per work class (K_MF_MASKS), [16] queue head
+    int* sched;              // [0..15] items per work class (K_MF_PREP), [16] queue head
     const int4* items;       // [16][cap]
     int cap;
     f4* part;                // [ntask][nl][nsw][8][64]: partial tiles of (task, group)s with several sweeps
@@ -226,7 +230,7 @@ __device__ __forceinline__ void otf_pair2(float c, f2 d, f2 t, unsigned* hi, uns
 
 // ------------------------------------------------------------------------------------------
 // K_OTF_MFMA2 (one direction).  Persistent workgroups (one per CU) of 2 per waves take items (task,
-// wavelength group of `per` <= 8 wavelengths, sweep of eight m-tiles) from the list of K_MF_MASKS.
+// wavelength group of `per` <= 8 wavelengths, sweep of eight m-tiles) from the list of K_MF_PREP.
 // Wave w < per is the even half (m-tiles 0, 2, 4, 6 of the sweep) of wavelength slot w, wave
 // per + w the odd half.  Per k-step (32 columns) the workgroup stages, by LDS-DMA into the buffer
 // the previous k-step does not read: the D | log2 tel tiles the group's union mask keeps (16 units
@@ -277,7 +281,7 @@ k_otf_mfma2(const Mf2Args a) {
         const int ipos = item - __builtin_amdgcn_readlane(cfirst, cls);
         return a.items[(size_t)cls * a.cap + ipos];
     };
-    // The masks of a sweep (K_MF_MASKS) with ONE load instruction: lane 8 k + g holds, for m-tile
+    // The masks of a sweep (K_MF_PREP) with ONE load instruction: lane 8 k + g holds, for m-tile
     // g0 + g, the group's staging mask (k = 0), this wavelength's full blocks (1) and mid blocks
     // (2); lane 24 the k-steps in which the wavelength has work, lane 25 the group's k-steps.
     auto load_masks = [&](int task, int grp, int sw, float* c2) -> u64 {
@@ -334,7 +338,7 @@ k_otf_mfma2(const Mf2Args a) {
         const char* dtask = reinterpret_cast<const char*>(a.D0t + (size_t)task * H1 * N);
         const char* etab = reinterpret_cast<const char*>(a.E + (size_t)lc * nks * NCT * 2 * 64);
         const h4* Gl = a.G + (size_t)lc * nmt_all * NJT * 2 * 2 * 64 + lane;
-        const u64 kuni = lane_word(mw, 25);            // != 0: K_MF_MASKS lists no empty item
+        const u64 kuni = lane_word(mw, 25);            // != 0: K_MF_PREP lists no empty item
         const u64 sany = lane_word(mw, 24);
         u64 of[kTW], om[kTW];              // this wave's tiles 2 i + half: full / mid blocks
 #pragma unroll

@@ -35,7 +35,7 @@ print('|---|---|---|---|---|---|---|')
 util = {}
 for k in ('k_otf_mfma2', 'k_mf_finish', 'k_mf_prep', 'k_otf_mfma1', 'k_otf_mfma', 'k_otf_r16', 'k_otf_rowfft', 'k_fit', 'k_conv_fft', 'k_colpass_m',
           'k_psd_rowfft', 'k_colfft_dphi', 'k_dmin', 'k_vkeep', 'k_task_order', 'k_khat', 'k_stamp_sum',
-          'k_dc_sum'):
+          ):
     if k not in dur:
         continue
     t = dur[k]
