@@ -554,8 +554,8 @@ def _oracle_rows(api, lb, see, gl, l0, three, dim, ps, npl, rows, lam_idx):
 def test_config_1000_rows_512(api):
     """BASELINE.json configs[2] on one GPU (its shard layout is exercised by tests/test_dist.py
     and tests/test_gpu_dist.py): 1000 rows x 35 wavelengths x 512^2 = 35 000 PSFs through one
-    call -- nine chunks over two lanes -- with the oracle on sampled rows and size-independent
-    properties on everything."""
+    call -- two chunks of 500 on the two lanes, then nine chunks of at most 117 -- with the oracle on
+    sampled rows and size-independent properties on everything."""
     n = 1000
     see, gl, l0 = api.synthetic_rows(n)
     lb = np.linspace(465, 930, 35)
@@ -571,6 +571,10 @@ def test_config_1000_rows_512(api):
     # the first 100 rows are the bench workload: same bits as a 100-row call (chunking invariance)
     r100 = ctx.reconstruct(lb, see[:100], gl[:100], l0[:100], three[:100], H, want_psf=False)
     assert np.array_equal(r100['fit'], fit[:100])
+    ctx.set_option('chunk_tasks', 117)          # the chunking of rounds 1-2: 8 x 117 + 64 rows
+    r9 = ctx.reconstruct(lb, see, gl, l0, three, H, want_psf=False)
+    assert np.array_equal(r9['fit'], fit)
+    np.testing.assert_allclose(r9['psf_sum'], r['psf_sum'], rtol=1e-13)
     ctx.close()
     li = [0, 17, 34]
     for k, (ofit, ofin) in _oracle_rows(api, lb, see, gl, l0, three, 512, ps, 1, [5, 499, 999], li).items():
