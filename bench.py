@@ -118,6 +118,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=400)
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--prime', type=int, default=PRIME_STEPS,
+                    help='untimed priming steps before the warm-up steps (profiling runs use fewer)')
     ap.add_argument('--rows', type=int, default=0,
                     help='rows per GPU per step (weak scaling); default: 100 at N = 1 (configs[1]), a 1000-row '
                          'table sharded over the ranks at N > 1 (configs[2])')
@@ -350,7 +352,7 @@ def main():
     # untimed priming before the W warm-up steps: lets the HIP runtime grow its command/signal
     # pools to the depth the host runs ahead by, and the GPU leave its idle clocks after the CPU
     # baseline (the first ~50 calls of a process are 5-10 % slower)
-    for _ in range(PRIME_STEPS):
+    for _ in range(a.prime):
         R['step']()
     R['fence']()
     # Timed region: HIP events only around the dominant kernel (roofline.achieved); bracketing
@@ -662,7 +664,7 @@ def main():
                                        'bracketed by HIP events' % nprof,
             'fit_iterations': {'mean': round(float(fitg[:, :, 7].mean()), 2),
                                'max': int(fitg[:, :, 7].max())},
-            'prime_steps': PRIME_STEPS,
+            'prime_steps': a.prime,
             'contexts': max(1, a.inflight), 'lanes_per_context': a.streams or 2,
             'host_enqueue_ms_per_step': round(t_enq / a.steps * 1e3, 4),
             'host_enqueue_note': 'host_enqueue_ms_per_step: CPU time of the Python thread per step, '
