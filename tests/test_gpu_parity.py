@@ -796,3 +796,19 @@ def test_wavelengths_in_any_order(api, opts):
         else:                       # every stamp is computed on its own: bit for bit
             np.testing.assert_array_equal(psf, res[0][0])
             np.testing.assert_array_equal(fit, res[0][1])
+
+
+def test_automatic_chunking_keeps_a_call_in_one_pass(api):
+    """A call is one pipeline pass up to 512 tasks and balanced passes (a multiple of the two lanes)
+    beyond: 125 rows -- the 8-GPU shard of BASELINE.json configs[2] -- must not run as 118 + 7
+    (mpsfr_debug_fetch hands out the LAST pass, whose size is what is checked here)."""
+    lb = np.linspace(500.0, 900.0, 16)          # (with few wavelengths a pass may be larger: >= 4096 stamps)
+    ps = api.grid_pixscale(128)
+    ctx = api.Context(dim=128, pixscale=ps, precision='mixed')
+    for n, last in ((125, 125), (512, 512), (513, 256), (1100, 275)):      # 513 = 257 + 256
+        see, gl, l0 = api.synthetic_rows(n)
+        r = ctx.reconstruct(lb, see, gl, l0, np.zeros(n, np.uint8), H, want_psf=False)
+        assert np.isfinite(r['fit']).all()
+        pre = ctx.debug_fetch('pre', (last, 16, 40, 40))        # raises unless the last pass had `last` tasks
+        assert pre.shape[0] == last
+    ctx.close()
