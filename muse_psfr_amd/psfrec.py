@@ -14,6 +14,7 @@ no difference): ``dim=1280`` (:955), ``dimpsf=40`` (:658), ``pixscale=0.2`` (:65
 astropy is used for tables / FITS when it is importable (then the return types are astropy's, as
 in the reference); otherwise the small NumPy implementations in ``_minifits`` / ``Table`` below.
 """
+import functools
 import logging
 import os
 from collections import OrderedDict
@@ -32,13 +33,20 @@ _FIT_COLS = ('lbda', 'center', 'flux', 'fwhm', 'n', 'peak', 'err_center', 'err_f
              'err_n', 'err_peak')
 
 
+_ASTROPY = []
+
+
 def _astropy():
-    try:
-        from astropy.io import fits
-        from astropy.table import Table as ATable
-        return fits, ATable
-    except Exception:  # noqa: BLE001 - absent or broken astropy: use the NumPy implementations
-        return None, None
+    """(astropy.io.fits, astropy.table.Table), or (None, None) without a working astropy.  The
+    outcome is kept: a failed import costs 0.1 ms every time, a fifth of a one-row compute_psf."""
+    if not _ASTROPY:
+        try:
+            from astropy.io import fits
+            from astropy.table import Table as ATable
+            _ASTROPY.append((fits, ATable))
+        except Exception:  # noqa: BLE001 - absent or broken astropy: use the NumPy implementations
+            _ASTROPY.append((None, None))
+    return _ASTROPY[0]
 
 
 class Table:
@@ -78,6 +86,7 @@ class Table:
         return cls(OrderedDict((n, np.array(d[n])) for n in d.dtype.names), meta)
 
 
+@functools.lru_cache(maxsize=1)
 def host_cutoff_masks():
     """The cut-off masks of psfrec.py:257 (>=) and :435 (>) evaluated with this host's NumPy in
     exactly the reference's way: |f cos(arctan(fy/fx))| and |f sin(arctan(fy/fx))| against
