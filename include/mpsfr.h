@@ -86,6 +86,10 @@ const char* mpsfr_last_error(void);
  * "profile_only" (-1 = all kernels, else the kernel id of mpsfr_profile_name to time alone);
  * "prune_eps_f64" (f64 mode only, default 1e-13, at most 1e-6: the same bound for the line pruning
  * of the reference-precision mode; 0 = everything).
+ * "cold_stagger" (default 0 = off; 1 / 2: after the GPU has drained, the second lane's first chunk
+ * waits once for the first lane's column transforms / per-wavelength preparation, so that the two
+ * lanes do not start in step: +3 % in a sustained run of 100-row calls, -1 % on a burst of 20;
+ * results do not depend on it).
  * Experiment switches of the matrix-core stage (results do not depend on them beyond the last
  * bits of the fp16 representation floor): "mf_kernel" (2 = thin-wave kernel with precision tiers
  * for one direction, 1 = the blocked kernel that several directions always use), "mf_permax"

@@ -112,6 +112,12 @@ struct mpsfr_ctx {
     hipEvent_t lsum_done = nullptr;      // the per-lane partial stamp sums have been consumed
     bool lsum_busy = false;
     hipEvent_t wait_next = nullptr;      // caller's event the next call must wait for
+    // Stagger of the lanes at a cold start (see mpsfr_reconstruct)
+    int cold_stagger = 0;                // 0: off; 1: behind the column transforms; 2: behind the preparation of the
+                                         // per-wavelength stage
+    hipEvent_t stagger_ev = nullptr;     // behind the column transforms of the first chunk after a cold start
+    bool stagger_armed = false;
+    int stagger_lane = -1;
     DevBuf fit, sum, stage, lsum;      // lsum: [lanes][nl][40][40] per-lane partial stamp sums
     // Small per-call parameters: one pinned host blob -> one device blob, no stream sync.  A ring
     // of NSTAGE slots (pinned blob, device blob, tip-tilt kernel spectra): the host may queue
@@ -409,7 +415,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         (void)hipEventDestroy(p.b);
     }
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    hipEvent_t evs[] = {c->tables_ready, c->cache_ready, c->lsum_done};
+    hipEvent_t evs[] = {c->tables_ready, c->cache_ready, c->lsum_done, c->stagger_ev};
     for (auto e : evs)
         if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k) {
@@ -461,6 +467,8 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
     } else if (!strcmp(key, "mf_kernel")) {
         if (value != 1.0 && value != 2.0) return fail(MPSFR_E_INVALID, "mf_kernel must be 1 or 2");
         c->mf_kernel = (int)value;
+    } else if (!strcmp(key, "cold_stagger")) {
+        c->cold_stagger = (int)value;
     } else if (!strcmp(key, "mf_permax")) {
         if (value != (int)value || value < 1.0 || value > 7.0) return fail(MPSFR_E_INVALID, "mf_permax must be 1..7");
         c->mf_permax = (int)value;
@@ -646,6 +654,24 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         if (!ln.done) HIPCHK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
     }
     hipStream_t s0 = lane_of(0).stream;        // the call's tables are produced on its first lane
+    // Stagger of the lanes at a cold start.  Two lanes that start together -- the first two calls (or
+    // chunks) after the GPU has drained -- settle into one of two phase relations, which then persists
+    // for as long as the pipeline stays full; on the bench workload (100 rows x 35 wavelengths, 512^2)
+    // the one they mostly find from a standing start is the slower (14.1 M PSFs/s against 14.6 M).  So
+    // the first chunk after a cold start records an event behind its column transforms and the next
+    // chunk on another lane waits for it: a one-time offset of half a stage A, after which the lanes run
+    // free.  OFF by default ("cold_stagger" = 1 / 2 switches it on): which relation a one-time offset
+    // selects depends on the shape of the call (measured in the sustained run: 100 rows +3 %, 125 rows 0,
+    // 250 rows -3 %, 500 rows +2.5 %, 1024^2 -2 %, 1280^2 -1 %), and the offset itself costs a short burst
+    // of calls what it gains a long one (20 calls from a standing start: -1 %).
+    const int stagger = c->cold_stagger;
+    bool cold_first = false;
+    if (stagger && NLmax > 1) {
+        cold_first = true;
+        for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
+            if (c->lane[k].busy && hipEventQuery(c->lane[k].done) != hipSuccess) cold_first = false;
+        if (!c->stagger_ev) HIPCHK(hipEventCreateWithFlags(&c->stagger_ev, hipEventDisableTiming));
+    }
 
     // ---- uploads: one pinned blob [LamPar nl][TaskPar ntask][gam][alp][mask_rec][mask_res]
     auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -880,6 +906,11 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         const int j = ci % NL;
         mpsfr_ctx::Lane& ln = lane_of(j);
         hipStream_t ls = ln.stream;
+        const int lane_index = (int)(&ln - c->lane);
+        if (c->stagger_armed && lane_index != c->stagger_lane) {
+            HIPCHK(hipStreamWaitEvent(ls, c->stagger_ev, 0));
+            c->stagger_armed = false;
+        }
         {
             ProfScope ps(c, K_PSD_ROWFFT, ls);
             launch_psd_rowfft(ls, N, ntd, ndir, d_tp + t0, (const double*)c->aotab.p, cfit, ln.C.p,
@@ -890,6 +921,16 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             launch_colfft_dphi(ls, N, ntd, ln.C.p, (const double*)ln.s00.p, scale2, ln.D0t.p,
                                c->f64, c->tw64.p, mf2 ? (int*)ln.msched.p : nullptr);
         }
+        auto stagger_here = [&](int which) -> int {
+            if (cold_first && stagger == which) {           // (the first chunk of a call that found every lane idle)
+                if (hipEventRecord(c->stagger_ev, ls) != hipSuccess) return -1;
+                c->stagger_armed = true;
+                c->stagger_lane = lane_index;
+                cold_first = false;
+            }
+            return 0;
+        };
+        if (stagger_here(1)) return fail(MPSFR_E_HIP, "hipEventRecord failed");
         if (mf2) {
             // thin-wave kernel: block minima (one direction: they are the minima over the directions),
             // then masks and work lists (otf_mfma2.hip); no line bounds needed
@@ -907,6 +948,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             if (mf) launch_task_order(ls, tc, nl, (const int*)ln.vkeep.p, (int*)ln.order.p);
         }
         const int* d_vkeep = prune ? (const int*)ln.vkeep.p : nullptr;
+        if (stagger_here(2)) return fail(MPSFR_E_HIP, "hipEventRecord failed");
         if (mf2) {
             ProfScope ps(c, K_OTF_MFMA, ls);
             launch_otf_mfma2(ls, N, tc, nl, c->mf_permax, c->ncu, ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
