@@ -57,3 +57,35 @@ def test_create_without_gpu_fails_loudly():
     from muse_psfr_amd import Context, MpsfrError
     with pytest.raises(MpsfrError):
         Context(dim=128, pixscale=0.019)
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/mpsfr.h is the boundary a non-Python caller binds to: it must compile as C99 (no C++
+    in the signatures) and a C program must link against libmpsfr.so.  Without a GPU mpsfr_create
+    fails loudly (an error code and a message), which is all this program checks."""
+    import shutil
+    import subprocess
+    from muse_psfr_amd._build import build_library
+    lib = build_library(force=False, verbose=False)
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    src = tmp_path / 'abi_c.c'
+    src.write_text(
+        '#include "mpsfr.h"\n'
+        '#include <stdio.h>\n'
+        'int main(void) {\n'
+        '    mpsfr_ctx* c = 0;\n'
+        '    int rc = mpsfr_create(&c, 0, 512, 40, 0.0762, 0);\n'
+        '    if (rc == 0) { mpsfr_destroy(c); puts("created"); return 0; }\n'
+        '    printf("rc=%d msg=%s version=%d devices=%d\\n", rc, mpsfr_last_error(), mpsfr_version(),\n'
+        '           mpsfr_device_count());\n'
+        '    return mpsfr_last_error()[0] ? 0 : 1;\n'
+        '}\n')
+    exe = tmp_path / 'abi_c'
+    libdir = os.path.dirname(lib)
+    subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', os.path.join(ROOT, 'include'),
+                    str(src), '-L', libdir, '-lmpsfr', '-Wl,-rpath,' + libdir, '-o', str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert 'created' in r.stdout or 'rc=-' in r.stdout
