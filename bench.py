@@ -168,6 +168,9 @@ def main():
     ps = grid_pixscale(dim)
     lb = np.linspace(465.0, 930.0, nl) if dim != 1280 else np.linspace(490.0, 930.0, nl)
     # the table and this rank's contiguous shard of it
+    # MPSFR_BENCH_FORCE_EXCHANGE=1 (under a launcher, any N): the collectives of the N > 1 step also run
+    # with one rank -- the RCCL path of this script on a box with a single GPU (tests/test_gpu_dist.py)
+    xchg = world > 1 or (bool(os.environ.get('MPSFR_BENCH_FORCE_EXCHANGE')) and 'WORLD_SIZE' in os.environ)
     strong = world > 1 and a.rows <= 0
     if strong:
         total_rows = a.table_rows
@@ -225,7 +228,7 @@ def main():
     backend = os.environ.get('MPSFR_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    if xchg:
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
@@ -264,7 +267,7 @@ def main():
         psums = [torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev) for _ in range(nset)]
         # the exchange buffers are allocated once (one set per result-buffer set)
         xdev = dev if backend == 'nccl' else torch.device('cpu')
-        exch = [ShardExchange(total_rows, nl, NFIT, xdev) for _ in range(nset)] if world > 1 else None
+        exch = [ShardExchange(total_rows, nl, NFIT, xdev) for _ in range(nset)] if xchg else None
         state = {'i': 0, 'ev': [None] * nset}
         # torch orders its collectives against the library on the GPU (no host sync inside a
         # step): torch's stream waits for the context's stream (which is ordered after every call
@@ -281,7 +284,7 @@ def main():
                 ctxs[k].wait_event(state['ev'][b].cuda_event)
             ctxs[k].reconstruct_device(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin,
                                        None, None, psum_b.data_ptr(), fit_b.data_ptr())
-            if world > 1:      # FIT_ROWS gather + PSF_MEAN numerator reduce
+            if xchg:           # FIT_ROWS gather + PSF_MEAN numerator reduce
                 cur = torch.cuda.current_stream()
                 cur.wait_stream(lib_streams[k])
                 if backend == 'nccl':
@@ -298,7 +301,7 @@ def main():
             torch.cuda.synchronize()
             for c in ctxs:
                 c.sync()
-            if world > 1:
+            if xchg:
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -316,7 +319,7 @@ def main():
             fence()
             dt = time.perf_counter() - t0
             tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
-            if world > 1:
+            if xchg:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item()), t_enq
 
@@ -705,7 +708,7 @@ def main():
                     pm['tests']['wide_parameter_range_vs_oracle'], source='profiles/r03_parity_margins.json')
             out['speedup_vs_cpu_baseline'] = round(out['value'] / cpu['value'], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if xchg:
         dist.destroy_process_group()
 
 

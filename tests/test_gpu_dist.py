@@ -92,3 +92,73 @@ def test_bench_starts_its_own_ranks():
     assert out['scaling'] == 'strong' and out['config']['rows_total'] == 31
     assert 'row-sharded over 2 GPUs (16/15 rows per GPU)' in out['config']['workload']
     assert abs(out['value'] - 31 * 5 * 4 / (out['ms_per_step'] * 4e-3)) < 1e-3 * out['value']
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=%r, RANK='0', WORLD_SIZE='1',
+                  HSA_ENABLE_IPC_MODE_LEGACY='0')
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+dist.init_process_group('nccl', device_id=dev)
+import muse_psfr_amd as api
+from muse_psfr_amd import NFIT
+from muse_psfr_amd.distributed import ShardExchange
+n, nl = 24, 5
+see, gl, l0 = api.synthetic_rows(n)
+lb = np.linspace(465, 930, nl)
+ctx = api.Context(dim=128, pixscale=api.grid_pixscale(128), precision='mixed', device=0)
+fit = torch.zeros((n, nl, NFIT), dtype=torch.float64, device=dev)
+psum = torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev)
+ex = ShardExchange(n, nl, NFIT, dev)
+lib_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
+for it in range(3):       # the step of bench.py at N > 1: library call, stream hand-over, collectives, event back
+    ctx.reconstruct_device(lb, see, gl, l0, np.zeros(n, np.uint8), (100, 10000), 12.0, 1, None, None,
+                           psum.data_ptr(), fit.data_ptr())
+    cur = torch.cuda.current_stream()
+    cur.wait_stream(lib_stream)
+    fit_all = ex.gather(fit)
+    ex.reduce(psum, dst=0)
+    ev = torch.cuda.Event(); ev.record(cur)
+    ctx.wait_event(ev.cuda_event)
+dist.barrier()
+torch.cuda.synchronize()
+ref = ctx.reconstruct(lb, see, gl, l0, np.zeros(n, np.uint8), (100, 10000), want_psf=False)
+ok = bool(np.array_equal(fit_all.cpu().numpy(), ref['fit'])) and bool(np.allclose(psum.cpu().numpy(), ref['psf_sum'], rtol=1e-13))
+print(json.dumps({'ok': ok, 'backend': dist.get_backend()}))
+ctx.close()
+dist.destroy_process_group()
+"""
+
+
+def test_shard_exchange_on_rccl_with_one_rank():
+    """RCCL itself, as far as one GPU allows: a one-rank `nccl` process group on the device, the
+    step of bench.py at N > 1 (asynchronous library call, stream hand-over, all-gather of the fit
+    table and reduce of the stamp sum on device tensors, the event back into the library) and the
+    result against the plain call.  (Two ranks cannot share a device under RCCL: the N = 2...8 runs
+    are the driver's.)"""
+    code = _RCCL_ONE_RANK % (ROOT, str(_free_port()))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert r.returncode == 0 and line, r.stderr[-3000:]
+    out = json.loads(line[-1])
+    assert out['ok'] and out['backend'] == 'nccl'
+
+
+def test_bench_step_with_collectives_on_rccl_one_rank():
+    """bench.py under the driver's launcher form with ONE rank, backend nccl and the collectives of the
+    N > 1 step forced on: the exact code the scaling run executes per step (library call on device
+    buffers, all-gather + reduce on RCCL, barrier, max over ranks), on the one GPU there is."""
+    env = dict(os.environ, MPSFR_BENCH_FORCE_EXCHANGE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'),
+           '--gpus', '1', '--steps', '10', '--warmup', '2', '--prime', '20', '--rows', '40', '--dim', '128',
+           '--nl', '5', '--cpu-rows', '0', '--f64-steps', '0', '--unpruned-steps', '0', '--host-steps', '0',
+           '--native-steps', '0', '--profile-steps', '0']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert r.returncode == 0 and line, r.stderr[-3000:]
+    out = json.loads(line[-1])
+    assert out['n_gpus'] == 1 and out['value'] > 0 and out['steps'] == 10
