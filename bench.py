@@ -263,11 +263,22 @@ def main():
         # Two sets of result buffers per context: consecutive calls of one context overlap on its
         # internal lanes, and calls that share an output buffer would be serialised.
         nset = 2 * nctx
-        fits = [torch.zeros((rows, nl, NFIT), dtype=torch.float64, device=dev) for _ in range(nset)]
-        psums = [torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev) for _ in range(nset)]
         # the exchange buffers are allocated once (one set per result-buffer set)
         xdev = dev if backend == 'nccl' else torch.device('cpu')
         exch = [ShardExchange(total_rows, nl, NFIT, xdev) for _ in range(nset)] if xchg else None
+        packed = xchg and backend == 'nccl' and bool(os.environ.get('MPSFR_BENCH_PACKED_EXCHANGE'))
+        if packed:
+            # optional (MPSFR_BENCH_PACKED_EXCHANGE=1): the library writes the rank's fit table and stamp
+            # sum side by side into the send block of ONE all-gather per step and the stamp sums of the
+            # ranks are added locally.  Not the default: on one rank it is the slower of the two forms
+            # (125 rows: 13.44 against 13.85 M PSFs/s)
+            for e in exch:
+                e.packed(40 * 40)
+            fits = [e.fit_view for e in exch]
+            psums = [e.psum_view.view(nl, 40, 40) for e in exch]
+        else:
+            fits = [torch.zeros((rows, nl, NFIT), dtype=torch.float64, device=dev) for _ in range(nset)]
+            psums = [torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev) for _ in range(nset)]
         state = {'i': 0, 'ev': [None] * nset}
         # torch orders its collectives against the library on the GPU (no host sync inside a
         # step): torch's stream waits for the context's stream (which is ordered after every call
@@ -287,10 +298,12 @@ def main():
             if xchg:           # FIT_ROWS gather + PSF_MEAN numerator reduce
                 cur = torch.cuda.current_stream()
                 cur.wait_stream(lib_streams[k])
-                if backend == 'nccl':
+                if packed:
+                    state['fit_all'], state['psum'] = exch[b].exchange_packed()
+                elif backend == 'nccl':      # all-gather of the fit tables + reduce of the stamp sums
                     state['fit_all'] = exch[b].gather(fit_b)
                     exch[b].reduce(psum_b, dst=0)
-                else:          # CPU rehearsal of the same exchange
+                else:          # CPU rehearsal of the exchange in its two-collective form
                     state['fit_all'] = exch[b].gather(fit_b.cpu())
                     state['psum'] = exch[b].reduce(psum_b.cpu(), dst=0)
                 ev = torch.cuda.Event()

@@ -6,7 +6,9 @@ collective.  Two small exchanges reproduce the reference's outputs (SURVEY.md 8(
   * all-gather of the per-task fit tables  [ntask][nl][NFIT] float64  (FIT_ROWS), and
   * sum-reduce of the per-rank partial stamp sums [nl][40][40] float64, because PSF_MEAN / FIT_MEAN
     are computed from the mean stamp over *all* tasks (psfrec.py:1104-1105).
-Both are < 1 MB: latency-bound, one call each.
+Both are < 1 MB: latency-bound, one call each -- or ONE call for both (ShardExchange.packed: the fit
+table and the stamp sum side by side in one all-gather, the stamp sums added locally); bench.py
+uses the two-call form by default, the faster of the two where one GPU can measure them.
 """
 import numpy as np
 
@@ -58,6 +60,45 @@ class ShardExchange:
             if e > s:
                 self.out[s:e].copy_(self.buf[r * self.nmax:r * self.nmax + (e - s)])
         return self.out
+
+    # ---- one collective per step: the rank's fit table and stamp sum side by side in one send block
+    def packed(self, npix=1600):
+        """Allocate the packed form: `fit_view` [n_local, nl, nfit] and `psum_view` [nl, npix] are
+        views into ONE send block (the library writes its device outputs straight into them), and
+        exchange_packed() is a single all-gather -- the stamp sums of the ranks are added locally,
+        in rank order, by every rank (one collective, one strided copy and one small sum per step)."""
+        import torch
+        nl, nfit = self.buf.shape[1], self.buf.shape[2]
+        a, b = self.bounds[self.rank]
+        self._nfit_block = self.nmax * nl * nfit
+        self._npsum = nl * npix
+        self.send = torch.zeros(self._nfit_block + self._npsum, dtype=self.buf.dtype, device=self.buf.device)
+        self.recv_flat = torch.empty(self.world * (self._nfit_block + self._npsum), dtype=self.buf.dtype,
+                                     device=self.buf.device)
+        self.recv = self.recv_flat.view(self.world, -1)
+        self.table = torch.empty((self.ntask, nl, nfit), dtype=self.buf.dtype, device=self.buf.device)
+        self.psum_total = torch.empty(self._npsum, dtype=self.buf.dtype, device=self.buf.device)
+        self.fit_view = self.send[:(b - a) * nl * nfit].view(b - a, nl, nfit)
+        self.psum_view = self.send[self._nfit_block:].view(nl, npix)
+        return self
+
+    def exchange_packed(self):
+        """-> (fit_all [ntask, nl, nfit], psum_total [nl, npix]); views / buffers valid until the
+        next exchange on this object."""
+        import torch
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(self.recv_flat, self.send, group=self.group)
+        nl, nfit = self.buf.shape[1], self.buf.shape[2]
+        fits = self.recv[:, :self._nfit_block].view(self.world, self.nmax, nl, nfit)
+        if self.ragged:
+            for r, (s, e) in enumerate(self.bounds):
+                if e > s:
+                    self.table[s:e].copy_(fits[r, :e - s])
+        else:                 # one strided copy: the fit blocks of the ranks, without the stamp sums between them
+            self.table.view(self.world, self.nmax, nl, nfit).copy_(fits)
+        fits = self.table
+        torch.sum(self.recv[:, self._nfit_block:], dim=0, out=self.psum_total)      # rank order
+        return fits, self.psum_total.view(nl, -1)
 
     def reduce(self, psum_local, dst=None):
         """Sum the per-rank partial stamp sums in place.  dst=None: every rank gets the total."""

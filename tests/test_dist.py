@@ -105,6 +105,60 @@ def test_exchange_buffers_are_allocated_once():
         assert np.all(psum == 2 * (step + 1))
 
 
+def _worker_packed(rank, world, port, ntask, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from muse_psfr_amd.distributed import ShardExchange, shard_bounds
+    from muse_psfr_amd.synthetic import synthetic_rows
+    see = synthetic_rows(ntask)[0]
+    a, b = shard_bounds(ntask, world)[rank]
+    ex = ShardExchange(ntask, 3, 16, torch.device('cpu')).packed(1600)
+    ex2 = ShardExchange(ntask, 3, 16, torch.device('cpu'))
+    outs = []
+    for step in range(2):         # the producer writes straight into the views of the send block
+        fit, psum = _fake_local(see * (step + 1))(a, b)
+        ex.fit_view.copy_(fit)
+        ex.psum_view.copy_(psum.view(3, 1600))
+        f, p = ex.exchange_packed()
+        f2 = ex2.gather(fit)
+        p2 = ex2.reduce(psum.clone())
+        outs.append((f.numpy().copy(), p.numpy().copy(), f2.numpy().copy(), p2.numpy().reshape(3, 1600).copy()))
+    if rank == 0:
+        q.put(outs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('ntask', [6, 5, 1])
+def test_packed_exchange_is_the_two_collectives_in_one(ntask):
+    """ShardExchange.packed: one all-gather carries the fit table and the stamp sum; against the
+    all-gather + all-reduce form and against the single-process result, even and ragged shards
+    and an empty one."""
+    sys.path.insert(0, ROOT)
+    from muse_psfr_amd.synthetic import synthetic_rows
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_packed, args=(r, 2, port, ntask, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    see = synthetic_rows(ntask)[0]
+    for step, (f, p, f2, p2) in enumerate(outs):
+        fit1, psum1 = _fake_local(see * (step + 1))(0, ntask)
+        np.testing.assert_array_equal(f, fit1.numpy())
+        np.testing.assert_array_equal(f, f2)
+        np.testing.assert_allclose(p, psum1.numpy().reshape(3, 1600), rtol=1e-14)
+        np.testing.assert_allclose(p, p2, rtol=1e-15)
+
+
 def test_bench_self_launch_command(monkeypatch):
     """`python bench.py --gpus N` without a launcher environment starts N ranks through
     torch.distributed.run on 127.0.0.1 and passes its arguments on."""

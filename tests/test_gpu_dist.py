@@ -123,10 +123,20 @@ for it in range(3):       # the step of bench.py at N > 1: library call, stream 
     ex.reduce(psum, dst=0)
     ev = torch.cuda.Event(); ev.record(cur)
     ctx.wait_event(ev.cuda_event)
+pk = ShardExchange(n, nl, NFIT, dev).packed(1600)
+for it in range(3):       # the packed form bench.py uses: the library writes into the send block of ONE all-gather
+    ctx.reconstruct_device(lb, see, gl, l0, np.zeros(n, np.uint8), (100, 10000), 12.0, 1, None, None,
+                           pk.psum_view.data_ptr(), pk.fit_view.data_ptr())
+    cur = torch.cuda.current_stream()
+    cur.wait_stream(lib_stream)
+    fit_pk, psum_pk = pk.exchange_packed()
+    ev = torch.cuda.Event(); ev.record(cur)
+    ctx.wait_event(ev.cuda_event)
 dist.barrier()
 torch.cuda.synchronize()
 ref = ctx.reconstruct(lb, see, gl, l0, np.zeros(n, np.uint8), (100, 10000), want_psf=False)
 ok = bool(np.array_equal(fit_all.cpu().numpy(), ref['fit'])) and bool(np.allclose(psum.cpu().numpy(), ref['psf_sum'], rtol=1e-13))
+ok = ok and bool(np.array_equal(fit_pk.cpu().numpy(), ref['fit'])) and bool(np.allclose(psum_pk.cpu().numpy().reshape(nl, 40, 40), ref['psf_sum'], rtol=1e-13))
 print(json.dumps({'ok': ok, 'backend': dist.get_backend()}))
 ctx.close()
 dist.destroy_process_group()
