@@ -528,8 +528,11 @@ __device__ __forceinline__ T wave_total(T v) {
     v += dpp_term<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
     v += dpp_term<0x141, 0xf>(v);    // row_half_mirror
     v += dpp_term<0x140, 0xf>(v);    // row_mirror: every lane holds its row's sum
-    v += dpp_term<0x142, 0xa>(v);    // row_bcast15 into rows 1 and 3
-    v += dpp_term<0x143, 0xc>(v);    // row_bcast31 into rows 2 and 3: lane 63 holds the total
+    // rows 1..3 add lane 15 of the row before, then rows 2, 3 add lane 31: lane 63 = s2 + s3 + (s0 + s1).
+    // All rows enabled (the other lanes hold partial sums nobody reads): with a row mask the
+    // compiler cannot fuse the move into the addition and each step is three instructions, not one
+    v += dpp_term<0x142, 0xf>(v);    // row_bcast15
+    v += dpp_term<0x143, 0xf>(v);    // row_bcast31: lane 63 holds the total
     return lane63(v);
 }
 
@@ -557,11 +560,20 @@ __device__ __forceinline__ S fit_rsqrt(S x);
 template <>
 __device__ __forceinline__ float fit_rsqrt<float>(float x) { return __builtin_amdgcn_rsqf(x); }
 template <>
-__device__ __forceinline__ double fit_rsqrt<double>(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ double fit_rsqrt<double>(double x) {
+    // hardware seed (v_rsq_f64, ~2^-26) + two Newton steps: 9 instructions where sqrt and the
+    // division took ~40; the ten of a 5 x 5 factorisation were most of its cost
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    return y;
+}
 
 // Lean fp64 exp / log for the polish (arguments are tame: z <= 0 for the model, x >= 1 for the
 // logarithm), ~18 and ~27 instructions against ~55 and ~65 for the general library routines.
-//   exp: z = k ln2 + r, |r| <= ln2 / 2, degree-13 Taylor in r (remainder 4e-18), v_ldexp_f64.
+//   exp: z = k ln2 + r, |r| <= ln2 / 2, degree-10 Taylor in r (remainder r^11 / 11! < 2.2e-13 --
+//        the residuals it serves only have to beat the 1e-6 of the float model), v_ldexp_f64.
 //   log: l0 = hardware log2 in fp32 (error ~1e-7), then log x = l0 + log1p(d) with
 //        d = x exp(-l0) - 1 ~ 1e-7, three terms of the series (remainder d^4 / 4).
 __device__ __forceinline__ double lean_exp(double z) {
@@ -569,10 +581,7 @@ __device__ __forceinline__ double lean_exp(double z) {
     const double k = rint(z * 1.4426950408889634074);
     double r = fma(-k, 6.93147180369123816490e-01, z);
     r = fma(-k, 1.90821492927058770002e-10, r);
-    double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
+    double p = 1.0 / 3628800.0;
     p = fma(p, r, 1.0 / 362880.0);
     p = fma(p, r, 1.0 / 40320.0);
     p = fma(p, r, 1.0 / 5040.0);
@@ -607,15 +616,103 @@ __device__ __forceinline__ double fit_exp2m1<double>(double eta) {
     return lean_exp(0.69314718055994530942 * eta) - 1.0;
 }
 
+// log2 / exp2 of the model passes.  Float: the bare hardware instructions -- the argument of the
+// logarithm is >= 1 and the power is in (0, 1], so the denormal scaling and the extended-precision
+// ln of __logf (11 instructions per pixel of the 56 the pass had) buy nothing, and the float phase
+// only has to reach the basin of the fp64 polish.
+template <typename RE>
+__device__ __forceinline__ RE fit_log2(RE x);
+template <>
+__device__ __forceinline__ float fit_log2<float>(float x) { return __builtin_amdgcn_logf(x); }
+template <>
+__device__ __forceinline__ double fit_log2<double>(double x) { return log(x) * 1.4426950408889634074; }
+template <typename RE>
+__device__ __forceinline__ RE fit_exp2(RE x);
+template <>
+__device__ __forceinline__ float fit_exp2<float>(float x) { return __builtin_amdgcn_exp2f(x); }
+template <>
+__device__ __forceinline__ double fit_exp2<double>(double x) { return exp(x * 0.69314718055994530942); }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Accumulators of the normal equations over a lane's pixels.  Generic form: 15 + 5 + 1 multiply-adds
+// per pixel.  Float form: the same 21 sums as 9 packed multiply-adds (v_pk_fma_f32: two fp32 lanes
+// per instruction at the issue cost of one) + 3 plain ones -- with r as a sixth "column" the rows
+// of the upper triangle are  J_x * (J_x .. J_4, r), and the pairs (J0,J1) (J2,J3) (J4,r) sit in
+// aligned register pairs; the factor J_x is a half of one of those pairs, picked by op_sel.
+template <typename RE>
+struct NormAcc {
+    RE a[15], g[5], chi2;
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) a[k] = (RE)0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) g[k] = (RE)0;
+        chi2 = (RE)0;
+    }
+    __device__ __forceinline__ void add(const RE* J, RE r) {
+        chi2 += r * r;
+        int k = 0;
+#pragma unroll
+        for (int x = 0; x < 5; ++x) {
+            g[x] += J[x] * r;
+#pragma unroll
+            for (int y = x; y < 5; ++y) a[k++] += J[x] * J[y];
+        }
+    }
+    template <typename F>
+    __device__ __forceinline__ void totals(NormEqT<RE>& ne, F total) const {
+        ne.chi2 = total(chi2);
+#pragma unroll
+        for (int k = 0; k < 15; ++k) ne.a[k] = total(a[k]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) ne.g[k] = total(g[k]);
+    }
+};
+template <>
+struct NormAcc<float> {
+    f32x2 r0a, r0b, r0c;      // (a00,a01) (a02,a03) (a04,g0)
+    f32x2 r1b, r1c;           // (a12,a13) (a14,g1)
+    f32x2 r2b, r2c;           // (a22,a23) (a24,g2)
+    f32x2 r3c, r4c;           // (a34,g3)  (a44,g4)
+    float a11, a33, chi2;
+    __device__ __forceinline__ void zero() {
+        const f32x2 z = {0.f, 0.f};
+        r0a = r0b = r0c = r1b = r1c = r2b = r2c = r3c = r4c = z;
+        a11 = a33 = chi2 = 0.f;
+    }
+    __device__ __forceinline__ void add(const float* J, float r) {
+        const f32x2 p01 = {J[0], J[1]}, p23 = {J[2], J[3]}, p4r = {J[4], r};
+        const f32x2 s0 = {J[0], J[0]}, s1 = {J[1], J[1]}, s2 = {J[2], J[2]}, s3 = {J[3], J[3]},
+                    s4 = {J[4], J[4]};
+        r0a += s0 * p01; r0b += s0 * p23; r0c += s0 * p4r;
+        r1b += s1 * p23; r1c += s1 * p4r;
+        r2b += s2 * p23; r2c += s2 * p4r;
+        r3c += s3 * p4r;
+        r4c += s4 * p4r;
+        a11 += J[1] * J[1];
+        a33 += J[3] * J[3];
+        chi2 += r * r;
+    }
+    template <typename F>
+    __device__ __forceinline__ void totals(NormEqT<float>& ne, F total) const {
+        ne.chi2 = total(chi2);
+        const float a[15] = {r0a.x, r0a.y, r0b.x, r0b.y, r0c.x, a11, r1b.x, r1b.y, r1c.x,
+                             r2b.x, r2b.y, r2c.x, a33, r3c.x, r4c.x};
+        const float g[5] = {r0c.y, r1c.y, r2c.y, r3c.y, r4c.y};
+#pragma unroll
+        for (int k = 0; k < 15; ++k) ne.a[k] = total(a[k]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) ne.g[k] = total(g[k]);
+    }
+};
+
 template <typename RE>
 __device__ __forceinline__ void moffat_accumulate(const RE* pix, int lane, const RE* v,
                                                   NormEqT<RE>& ne) {
     constexpr int NPX = NS * NS / 64;
-    RE a[15], g[5], chi2 = (RE)0;
-#pragma unroll
-    for (int k = 0; k < 15; ++k) a[k] = (RE)0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) g[k] = (RE)0;
+    NormAcc<RE> acc;
+    acc.zero();
     // wave-uniform scalars in the evaluation type: in the mixed mode the whole LM phase is float
     // (fp64 here put ~40 double instructions and four double divisions on the serial path of
     // every iteration); the fp64 polish of k_fit removes what that costs in accuracy
@@ -625,7 +722,9 @@ __device__ __forceinline__ void moffat_accumulate(const RE* pix, int lane, const
     const RE K = (RE)4 * s_ * i3 * i3;
     // d(1/a^2)/d eta / (1/a^2) = s'/s with s' = 2^eta ln2
     const RE dKn = (s_ + (RE)1) * (RE)0.69314718055994530942 * fit_rcp<RE>(s_);
-    const RE I = v[0], p0 = v[1], q0 = v[2], nsq = n * n;
+    const RE I = v[0], p0 = v[1], q0 = v[2];
+    const RE nsq2 = n * n * (RE)0.69314718055994530942;      // n^2 ln2: the logarithm below is to base 2
+    const RE c12 = (RE)2 * n * K, c3 = c12 * i3, c4 = n * K * dKn;
     // Pixel map of the model passes: the lane is a cell (lr, lc) of an 8 x 8 block, and the 25 blocks
     // of the stamp are walked as 5 x 5 -- pixel (8 mo + lr, 8 mi + lc).  The coordinates are then one
     // addition per block row and one per pixel (the row-major map lane + 64 m cost a
@@ -642,33 +741,24 @@ __device__ __forceinline__ void moffat_accumulate(const RE* pix, int lane, const
         const RE dq = (RE)(8 * mi) + lcf;
         const RE u = dq * dq + dp2;
         const RE gg = (RE)1 + u * K;
-        const RE lg = fit_log<RE>(gg);
-        const RE e = fit_exp<RE>(-n * lg);
+        const RE lg2 = fit_log2<RE>(gg);
+        const RE e = fit_exp2<RE>(-n * lg2);
         const RE mo_ = I * e;
         const RE r = mo_ - pl[mo * 8 * NS + mi * 8];
-        chi2 += r * r;
-        const RE cm = mo_ * n * fit_rcp<RE>(gg);
-        const RE ck = cm * (RE)2 * K;
+        // with t = model / g:  d/dp0 = 2 n K t dp,  d/dq0 = 2 n K t dq,  d/dw = 2 n K t u / w,
+        // d/d eta = n^2 model ln g - n K (s'/s) t u   (the wave-uniform factors folded into c12, c3, c4)
+        const RE t = mo_ * fit_rcp<RE>(gg);
+        const RE tu = t * u, tc = t * c12;
         RE J[5];
         J[0] = e;
-        J[1] = ck * dp;
-        J[2] = ck * dq;
-        J[3] = ck * u * i3;
-        J[4] = nsq * mo_ * lg - cm * u * K * dKn;         // d model / d eta
-        int k = 0;
-#pragma unroll
-        for (int x = 0; x < 5; ++x) {
-            g[x] += J[x] * r;
-#pragma unroll
-            for (int y = x; y < 5; ++y) a[k++] += J[x] * J[y];
-        }
+        J[1] = tc * dp;
+        J[2] = tc * dq;
+        J[3] = tu * c3;
+        J[4] = mo_ * (nsq2 * lg2) - tu * c4;
+        acc.add(J, r);
         }
     }
-    ne.chi2 = wave_total(chi2);
-#pragma unroll
-    for (int k = 0; k < 15; ++k) ne.a[k] = wave_total(a[k]);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) ne.g[k] = wave_total(g[k]);
+    acc.totals(ne, [](RE x) { return wave_total(x); });
 }
 
 // chi2 alone at (I, p0, q0, a, n): the residual pass without the Jacobian (a third of the work)
@@ -883,25 +973,28 @@ k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit, doubl
     // all 3500 stamps of the bench step are resident at once instead of in two rounds)
     __shared__ RE spix[4][NS * NS];
     RE* sp = spix[threadIdx.x >> 6];
-    double best = -1.0e300;
+    // comparisons in the type the stamp is stored in (exact; in double they were a conversion and
+    // a two-register select per pixel for float stamps)
+    TS best = (TS)-3.0e38;
     int besto = 0;
 #pragma unroll
     for (int m = 0; m < NPX; ++m) {
         const int o = lane + m * 64;
-        const double d = (double)src[o];
+        const TS d = src[o];
         sp[o] = (RE)d;
         if (d > best) { best = d; besto = o; }
     }
     // argmax (first maximum in C order, as np.argmax) and the pixel count above half maximum
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_xor(best, o, 64);
+        const TS ob = __shfl_xor(best, o, 64);
         const int oo = __shfl_xor(besto, o, 64);
         if (ob > best || (ob == best && oo < besto)) { best = ob; besto = oo; }
     }
     int cnt = 0;
+    const TS half = (TS)0.5 * best;
 #pragma unroll
-    for (int m = 0; m < NPX; ++m) cnt += (double)sp[lane + m * 64] > 0.5 * best ? 1 : 0;
+    for (int m = 0; m < NPX; ++m) cnt += (TS)sp[lane + m * 64] > half ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     // start values: peak and its position, FWHM from the area above half maximum, n = 2.5.
@@ -917,7 +1010,10 @@ k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit, doubl
     // float evaluation only has to reach the basin of quadratic convergence: the fp64 polish
     // below finishes the job.  Every lane carries the same LM state (the totals of
     // moffat_accumulate are wave-uniform), so the control flow is uniform.
-    const S tol = sizeof(RE) == 4 ? (S)1.0e-3 : (S)1.0e-10;
+#ifndef MPSFR_FIT_TOL_F32
+#define MPSFR_FIT_TOL_F32 1.0e-3
+#endif
+    const S tol = sizeof(RE) == 4 ? (S)MPSFR_FIT_TOL_F32 : (S)1.0e-10;
     NormEqT<RE> ne;
     moffat_accumulate<RE>(sp, lane, v, ne);
     S mu = (S)1.0e-2, nu = (S)2;
@@ -1003,18 +1099,19 @@ k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit, doubl
             moffat_gradient(src, lane, vd, np.g, &np.chi2);
             double dx[5];
             if (!lm_solve<double, double>(np, 1.0e-10, dx)) break;
-            double rel = 0.0;
+            float rel = 0.f;               // a size, compared with 0.1 / 1e-3 / polish_tol: float
 #pragma unroll
             for (int k = 0; k < 5; ++k)
-                rel = fmax(rel, fabs(dx[k]) / (fabs(vd[k] + dx[k]) + 1.0e-300));
+                rel = fmaxf(rel, fabsf((float)dx[k]) *
+                                     __builtin_amdgcn_rcpf(fabsf((float)(vd[k] + dx[k])) + 1.0e-30f));
             const bool inside = vd[3] + dx[3] > 1.0e-3 && vd[4] + dx[4] > 1.0e-3 &&
-                                vd[4] + dx[4] < 1.0e2 && rel < 0.1;
+                                vd[4] + dx[4] < 1.0e2 && rel < 0.1f;
             if (!inside) break;
 #pragma unroll
             for (int k = 0; k < 5; ++k) vd[k] += dx[k];
             ++it;
-            polish_chi2 = rel < 1.0e-3 ? np.chi2 : -1.0;
-            if (rel < polish_tol) break;            // error after this step ~ 1e-2 rel
+            polish_chi2 = rel < 1.0e-3f ? np.chi2 : -1.0;
+            if (rel < (float)polish_tol) break;            // error after this step ~ 1e-2 rel
         }
     }
     // Outputs in (a, n).  The covariance comes from the normal matrix of the last LM iteration (in
