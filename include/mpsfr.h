@@ -69,7 +69,8 @@ void mpsfr_destroy(mpsfr_ctx* ctx);
 const char* mpsfr_last_error(void);
 
 /* Tunables: "chunk_tasks" (tasks per pipeline pass, 0 = automatic: one pass up to 512 tasks /
- * 65536 stamps / 4 GiB of workspace, balanced passes beyond); "fast_exp" (mixed mode only,
+ * 65536 stamps / 4 GiB of workspace, balanced passes beyond; a synchronous call -- host outputs --
+ * of 8192 stamps or more: one pass per lane); "fast_exp" (mixed mode only,
  * default 1: hardware exp2 for the OTF); "fft_conv" (mixed mode only, default 1: the two 41x41
  * convolutions through 64-point FFTs instead of the direct form); "streams" (0 = automatic = 2,
  * or 1..4 pipeline lanes: consecutive chunks -- of one call and of consecutive asynchronous

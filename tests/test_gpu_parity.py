@@ -799,16 +799,30 @@ def test_wavelengths_in_any_order(api, opts):
 
 
 def test_automatic_chunking_keeps_a_call_in_one_pass(api):
-    """A call is one pipeline pass up to 512 tasks and balanced passes (a multiple of the two lanes)
-    beyond: 125 rows -- the 8-GPU shard of BASELINE.json configs[2] -- must not run as 118 + 7
-    (mpsfr_debug_fetch hands out the LAST pass, whose size is what is checked here)."""
+    """An asynchronous call (device outputs; its neighbours run on the other lane) is one pipeline pass
+    up to 512 tasks and balanced passes (a multiple of the two lanes) beyond: 125 rows -- the 8-GPU
+    shard of BASELINE.json configs[2] -- must not run as 118 + 7.  A synchronous call (host outputs)
+    of 8192 stamps or more runs as one pass per lane.  (mpsfr_debug_fetch hands out the LAST pass, whose
+    size is what is checked here.)"""
+    import torch
     lb = np.linspace(500.0, 900.0, 16)          # (with few wavelengths a pass may be larger: >= 4096 stamps)
     ps = api.grid_pixscale(128)
     ctx = api.Context(dim=128, pixscale=ps, precision='mixed')
-    for n, last in ((125, 125), (512, 512), (513, 256), (1100, 275)):      # 513 = 257 + 256
+    dev = torch.device('cuda', 0)
+    for n, last_async, last_sync in ((125, 125, 125), (511, 511, 511), (512, 512, 256), (513, 256, 256),
+                                     (1100, 275, 275)):      # 512 rows x 16 = 8192 stamps; 513 = 257 + 256
         see, gl, l0 = api.synthetic_rows(n)
         r = ctx.reconstruct(lb, see, gl, l0, np.zeros(n, np.uint8), H, want_psf=False)
         assert np.isfinite(r['fit']).all()
-        pre = ctx.debug_fetch('pre', (last, 16, 40, 40))        # raises unless the last pass had `last` tasks
-        assert pre.shape[0] == last
+        pre = ctx.debug_fetch('pre', (last_sync, 16, 40, 40))   # raises unless the last pass had that many tasks
+        assert pre.shape[0] == last_sync
+        fit = torch.zeros((n, 16, api.NFIT), dtype=torch.float64, device=dev)
+        psum = torch.zeros((16, 40, 40), dtype=torch.float64, device=dev)
+        ctx.reconstruct_device(lb, see, gl, l0, np.zeros(n, np.uint8), H, 12.0, 1, None, None,
+                               psum.data_ptr(), fit.data_ptr())
+        ctx.sync()
+        pre = ctx.debug_fetch('pre', (last_async, 16, 40, 40))
+        assert pre.shape[0] == last_async
+        np.testing.assert_array_equal(fit.cpu().numpy(), r['fit'])          # the passes do not change a fit
+        np.testing.assert_allclose(psum.cpu().numpy(), r['psf_sum'], rtol=1e-13)
     ctx.close()
