@@ -269,7 +269,10 @@ __device__ __forceinline__ void cf_split0(const cx<R>* res, int kx, cx<R>& a0,
 // and the stamp sum read half the bytes), double when they go straight into the caller's psf_out.
 // R: arithmetic type (float: mixed mode; double: f64 mode, 74 KB of LDS).
 template <typename R, typename TF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 4 : 2)))
+#ifndef MPSFR_CONV_WAVES
+#define MPSFR_CONV_WAVES 4
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? MPSFR_CONV_WAVES : 2)))
 k_conv_fft(int nl, const R* __restrict__ pre, const cx<R>* __restrict__ khat_tt,
            const cx<R>* __restrict__ khat_muse, TF* __restrict__ fin) {
     extern __shared__ __align__(16) unsigned char conv_smem[];
@@ -950,11 +953,14 @@ __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][
 #define MPSFR_POLISH_TOL 1.0e-4
 #endif
 #ifndef MPSFR_FIT_WAVES
-#define MPSFR_FIT_WAVES 4
+#define MPSFR_FIT_WAVES 3
 #endif
-// amdgpu_waves_per_eu: the serial LM iterations are latency-bound, so occupancy matters more than
-// the scheduler's appetite for registers (208 VGPRs -> 2 waves/SIMD without the hint).  The fp64
-// mode needs the registers (2 waves).
+// amdgpu_waves_per_eu: at least three waves per SIMD for the float fit (without the hint the
+// scheduler's appetite for registers took 208 VGPRs -> 2 waves).  Four (128 registers: every stamp
+// of the bench step resident at once) was the better setting until the instruction diet of round 3;
+// the leaner kernel wants 156 registers, and squeezed into 128 it pays 100 B of scratch and ~30
+// moves per iteration: 66.9 us at four waves against 60.7 at three.  The fp64 mode needs the
+// registers (2 waves).
 template <typename RE>
 constexpr int fit_min_waves() { return sizeof(RE) == 4 ? MPSFR_FIT_WAVES : 2; }
 
