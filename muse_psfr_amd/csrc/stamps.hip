@@ -764,6 +764,95 @@ __device__ __forceinline__ void moffat_accumulate(const RE* pix, int lane, const
     acc.totals(ne, [](RE x) { return wave_total(x); });
 }
 
+#ifndef MPSFR_FIT_PAIRS
+#define MPSFR_FIT_PAIRS 1
+#endif
+// The float pass two pixels at a time: every quantity of the pass is a pair (pixel A, pixel B) in an
+// aligned register pair, so the arithmetic between the three transcendental instructions of a pixel --
+// coordinates, residual, Jacobian, and the 21 sums -- runs in packed instructions (v_pk_mul_f32 /
+// v_pk_fma_f32 / v_pk_add_f32: 42 per pair where the pixel-at-a-time form has 62).  The wave-uniform
+// factors are the low halves of pairs picked by op_sel.  Pairs: (mi = 0, 1) and (2, 3) of each of the
+// five block rows, then column mi = 4 by rows (0, 1), (2, 3), and its last pixel with an empty partner.
+// The accumulators hold one partial sum per half (42 registers instead of 21): the kernel's 156
+// registers at three waves per SIMD have the room (k_fit, MPSFR_FIT_WAVES).
+__device__ __forceinline__ void moffat_accumulate_pairs(const float* pix, int lane, const float* v,
+                                                        NormEqT<float>& ne) {
+    f32x2 A[15], G[5], C = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 15; ++k) A[k] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) G[k] = f32x2{0.f, 0.f};
+    const float n = fit_rcp<float>(v[4]);
+    const float s_ = fit_exp2m1<float>(v[4]);
+    const float i3 = fit_rcp<float>(v[3]);
+    const float K = 4.f * s_ * i3 * i3;
+    const float dKn = (s_ + 1.f) * 0.69314718f * fit_rcp<float>(s_);
+    const float I = v[0], p0 = v[1], q0 = v[2];
+    const float nsq2 = n * n * 0.69314718f;
+    const float c12 = 2.f * n * K, c3 = c12 * i3, c4 = n * K * dKn;
+    const f32x2 K2 = {K, K}, I2 = {I, I}, nn2 = {-n, -n}, nsq22 = {nsq2, nsq2}, c122 = {c12, c12},
+                c32 = {c3, c3}, c42 = {c4, c4}, one2 = {1.f, 1.f};
+    const float lrf = (float)(lane >> 3) - p0, lcf = (float)(lane & 7) - q0;      // pixel map: moffat_accumulate
+    const float* pl = pix + (lane >> 3) * NS + (lane & 7);
+    auto pair = [&](f32x2 u, f32x2 dpv, f32x2 dqv, f32x2 px, bool last) {
+        const f32x2 gg = u * K2 + one2;
+        const f32x2 lg2 = {fit_log2<float>(gg.x), fit_log2<float>(gg.y)};
+        const f32x2 arg = lg2 * nn2;
+        f32x2 e = {fit_exp2<float>(arg.x), fit_exp2<float>(arg.y)};
+        if (last) e.y = 0.f;                     // the empty partner: model, residual and Jacobian vanish
+        const f32x2 m = e * I2;
+        const f32x2 r = m - px;
+        const f32x2 rg = {fit_rcp<float>(gg.x), fit_rcp<float>(gg.y)};
+        const f32x2 t = m * rg;
+        const f32x2 tu = t * u, tc = t * c122;
+        f32x2 J[5];
+        J[0] = e;
+        J[1] = tc * dpv;
+        J[2] = tc * dqv;
+        J[3] = tu * c32;
+        J[4] = m * (lg2 * nsq22) - tu * c42;
+        C += r * r;
+        int k = 0;
+#pragma unroll
+        for (int x = 0; x < 5; ++x) {
+            G[x] += J[x] * r;
+#pragma unroll
+            for (int y = x; y < 5; ++y) A[k++] += J[x] * J[y];
+        }
+    };
+    const f32x2 dqa = {lcf, 8.f + lcf}, dqb = {16.f + lcf, 24.f + lcf};
+    const f32x2 dqa2 = dqa * dqa, dqb2 = dqb * dqb;
+    const float dq4 = 32.f + lcf, dq4s = dq4 * dq4;
+#pragma unroll 1
+    for (int mo = 0; mo < 5; ++mo) {
+        const float dp = (float)(8 * mo) + lrf, dp2 = dp * dp;
+        const f32x2 dpv = {dp, dp}, dp2v = {dp2, dp2};
+        const float* row = pl + mo * 8 * NS;
+        pair(dqa2 + dp2v, dpv, dqa, f32x2{row[0], row[8]}, false);
+        pair(dqb2 + dp2v, dpv, dqb, f32x2{row[16], row[24]}, false);
+    }
+    {
+        const f32x2 dq4v = {dq4, dq4}, dq4sv = {dq4s, dq4s};
+        const f32x2 dpa = {lrf, 8.f + lrf}, dpb = {16.f + lrf, 24.f + lrf};
+        const float dp4 = 32.f + lrf;
+        pair(dpa * dpa + dq4sv, dpa, dq4v, f32x2{pl[32], pl[8 * NS + 32]}, false);
+        pair(dpb * dpb + dq4sv, dpb, dq4v, f32x2{pl[16 * NS + 32], pl[24 * NS + 32]}, false);
+        pair(f32x2{dp4 * dp4 + dq4s, 0.f}, f32x2{dp4, 0.f}, dq4v, f32x2{pl[32 * NS + 32], 0.f}, true);
+    }
+    ne.chi2 = wave_total(C.x + C.y);
+#pragma unroll
+    for (int k = 0; k < 15; ++k) ne.a[k] = wave_total(A[k].x + A[k].y);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) ne.g[k] = wave_total(G[k].x + G[k].y);
+}
+
+// the float pass of the LM phase (pairs of pixels) / the generic pass
+template <typename RE>
+__device__ __forceinline__ void lm_accumulate(const RE* pix, int lane, const RE* v, NormEqT<RE>& ne) {
+    if constexpr (sizeof(RE) == 4 && MPSFR_FIT_PAIRS) moffat_accumulate_pairs(pix, lane, v, ne);
+    else moffat_accumulate<RE>(pix, lane, v, ne);
+}
+
 // chi2 alone at (I, p0, q0, a, n): the residual pass without the Jacobian (a third of the work)
 template <typename RE, typename DT>
 __device__ __forceinline__ RE moffat_chi2(const DT* pix, int lane, const double* va) {
@@ -1021,7 +1110,7 @@ k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit, doubl
 #endif
     const S tol = sizeof(RE) == 4 ? (S)MPSFR_FIT_TOL_F32 : (S)1.0e-10;
     NormEqT<RE> ne;
-    moffat_accumulate<RE>(sp, lane, v, ne);
+    lm_accumulate<RE>(sp, lane, v, ne);
     S mu = (S)1.0e-2, nu = (S)2;
     const S mu_max = sizeof(RE) == 4 ? (S)1.0e15f : (S)1.0e15;
     int it = 0, status = 1;
@@ -1062,7 +1151,7 @@ k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit, doubl
         NormEqT<RE> nn;
         S rho = (S)-1;
         if (inside) {
-            moffat_accumulate<RE>(sp, lane, vn, nn);
+            lm_accumulate<RE>(sp, lane, vn, nn);
             // predicted decrease of chi2: dx^T (mu D dx - g)
             S pred = (S)0;
             const int dg[5] = {0, 5, 9, 12, 14};
