@@ -22,7 +22,8 @@ struct TaskPar {
     double cn2_0;     // normalised Cn2 of the ground layer (psfrec.py:57-58)
     double cn2_1;
     int geom;         // 0 = 4 LGS, 1 = 3 LGS (psfrec.py:86-91)
-    int pad;
+    int basis;        // 0: a task.  k + 1: "basis task" k of the series form of stage A (stage_a2.hip):
+                      // PSD = r0m53 cfit (f^2 + inv_l0sq)^(-11/6 - k) [f >= fc], no corrected zone
 };
 
 // per-wavelength scalars
@@ -56,6 +57,8 @@ enum KernelId {
     K_VKEEP,        // FFT path: K_DMIN + K_VKEEP
     K_OTF_MFMA,     // matrix-core per-wavelength stage (K_OTF_MFMA2 + K_MF_FINISH, or K_OTF_MFMA1)
     K_MF_PREP,      // its preparation: K_DMIN + K_MF_PREP (or K_DMIN + K_VKEEP + K_TASK_ORDER)
+    K_PATCH,        // series form of stage A (stage_a2.hip): K_PATCH_GEN + K_PATCH_ROWS
+    K_DPHI_SERIES,  //   and K_DPHI_SERIES
     K_COUNT
 };
 
@@ -79,6 +82,20 @@ void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const do
 // (f64: D / the telescope OTF are double; the minima are rounded down, the maxima up)
 void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk,
                  bool f64 = false);
+// Series form of stage A (stage_a2.hip).  d_coef: [N/2+1][N][series_terms] structure functions of the
+// terms of the expansion of the fitting PSD in 1/L0^2 about series_eps0() (launch_series_coef from the
+// fp64 planes [terms][N/2+1][N] that launch_colfft_dphi produced for the basis tasks);
+// launch_patch: d_P [ntd][80][80], d_T [ntd][N/2+1][80] complex, d_sp [ntd];
+// launch_dphi_series: D0t as launch_colfft_dphi writes it.  Valid for 1/L0^2 <= series_eps_max().
+int series_terms(bool f64);
+double series_eps0();
+inline double series_eps_max() { return 1.0 / 49.0; }
+void launch_series_coef(hipStream_t s, int N, const double* d_planes, void* d_coef, bool f64);
+void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const double* d_aotab,
+                  double cfit, const void* d_tw64, double* d_P, void* d_T, double* d_sp, bool f64);
+void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const void* d_T,
+                        const double* d_sp, const void* d_coef, const void* d_tw64, double scale2,
+                        void* d_D0t, bool f64out, int* d_zero = nullptr);
 void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax, bool f64 = false);
 void launch_vkeep(hipStream_t s, int N, int ntask, int ndir, int nl, const LamPar* d_lp,
                   const float* d_dline, const float* d_dblk, const float* d_tlmax, float thr_sum,

@@ -46,7 +46,8 @@ int fail(int code, const char* fmt, ...) {
 
 const char* kKernelNames[K_COUNT] = {
     "ao_tables", "tel_otf", "psd_rowfft", "colfft_dphi", "gtable",
-    "moffat_kernels", "otf_rowfft", "colpass", "conv", "fit", "stamp_sum", "vkeep", "otf_mfma", "mf_prep"};
+    "moffat_kernels", "otf_rowfft", "colpass", "conv", "fit", "stamp_sum", "vkeep", "otf_mfma", "mf_prep",
+    "patch", "dphi_series"};
 
 struct DevBuf {
     void* p = nullptr;
@@ -80,9 +81,10 @@ struct mpsfr_ctx {
     int mf_permax = 6;           // wavelengths per workgroup of the thin-wave kernel (6: 12 waves, 7: 14 waves)
     double mf_mid_log2 = -18.01; // blocks below 2^this need no low half of the OTF (see otf_mfma2.hip)
     bool mf_clock = false;       // experiments: phase time stamps of the matrix-core kernel
+    int stage_a = 1;             // 1: series + patch form of stage A (stage_a2.hip); 0: full-size transforms
     DevBuf mfclk;
     // constant tables
-    DevBuf tw64, tel, rows, tlmax, tl2, tlb;
+    DevBuf tw64, tel, rows, tlmax, tl2, tlb, scoef;
     // per-call tables
     DevBuf aotab, samp_p, samp_a, G, kmuse, xtab, etab, gtab;
     // Pipeline lanes: each lane owns a HIP stream and a set of chunk workspaces.  Consecutive
@@ -94,6 +96,7 @@ struct mpsfr_ctx {
         hipEvent_t done = nullptr;       // after the lane's last chunk of the most recent call
         bool busy = false;               // `done` has been recorded
         DevBuf C, s00, D0t, Tq, pre, fin, dmin, dblk, vkeep, dminb, order, mown, muni, msched, mpart;
+        DevBuf pP, pT, psp;              // series form of stage A: patch, its row transforms, its sum
         // device outputs of its most recent calls: `done` is recorded behind every call of the lane,
         // so waiting for it covers all of them (a caller that rotates more buffer sets than lanes
         // must still get the calls that share a buffer in order)
@@ -300,6 +303,55 @@ int npix_crop(double lbda_nm, int dimpsf, double pixscale) {
     return (int)(std::nearbyint((x / lbda_nm) / 2.0) * 2.0);
 }
 
+double fit_constant() {
+    return (std::tgamma(11.0 / 6.0) * std::tgamma(11.0 / 6.0) / (2.0 * std::pow(M_PI, 11.0 / 3.0))) *
+           std::pow(24.0 * std::tgamma(6.0 / 5.0) / 5.0, 5.0 / 6.0);   // psfrec.py:622-623
+}
+
+double dphi_scale2() {
+    const double k500 = 0.5 * 1000 / (2 * M_PI);                      // psfrec.py:151
+    return 2.0 * (k500 * k500) / 256.0;       // 2 (.)/L^2, L = 16 m (psfrec.py:710, 718)
+}
+
+// Series form of stage A (stage_a2.hip): the structure functions of the terms
+// binom(-11/6, k) cfit (f^2 + eps0)^(-11/6 - k) [f >= fc] of the fitting PSD, computed once with the
+// full-size fp64 transforms of stage_a.hip ("basis tasks": r0m53 = the binomial coefficient,
+// inv_l0sq = eps0), then interleaved per pixel in the precision of the context.
+int build_series_tables(mpsfr_ctx* c) {
+    const int N = c->N, H1 = N / 2 + 1, K = series_terms(c->f64);
+    std::vector<TaskPar> tp(K);
+    double binom = 1.0;
+    for (int k = 0; k < K; ++k) {
+        if (k > 0) binom *= (-11.0 / 6.0 - (k - 1)) / k;
+        tp[k].r0m53 = binom;
+        tp[k].inv_l0sq = series_eps0();
+        tp[k].cn2_0 = 1.0;
+        tp[k].cn2_1 = 0.0;
+        tp[k].geom = 0;
+        tp[k].basis = k + 1;
+    }
+    DevBuf dtp, C, s00, planes;
+    int rc = MPSFR_OK;
+    auto done = [&](int code) {
+        release(dtp); release(C); release(s00); release(planes);
+        return code;
+    };
+    if ((rc = ensure(c, dtp, K * sizeof(TaskPar)))) return done(rc);
+    if ((rc = ensure(c, C, (size_t)K * (N / 2 + NAO / 2) * H1 * 2 * sizeof(double)))) return done(rc);
+    if ((rc = ensure(c, s00, (size_t)K * psd_rowfft_groups(N) * sizeof(double)))) return done(rc);
+    if ((rc = ensure(c, planes, (size_t)K * H1 * N * sizeof(double)))) return done(rc);
+    if ((rc = ensure(c, c->scoef, (size_t)K * H1 * N * rsize(c)))) return done(rc);
+    if (hipMemcpy(dtp.p, tp.data(), K * sizeof(TaskPar), hipMemcpyHostToDevice) != hipSuccess)
+        return done(fail(MPSFR_E_HIP, "hipMemcpy of the basis tasks failed"));
+    launch_psd_rowfft(c->stream, N, K, 1, (const TaskPar*)dtp.p, nullptr, fit_constant(), C.p, c->tw64.p,
+                      (double*)s00.p, true);
+    launch_colfft_dphi(c->stream, N, K, C.p, (const double*)s00.p, dphi_scale2(), planes.p, true, c->tw64.p);
+    launch_series_coef(c->stream, N, (const double*)planes.p, c->scoef.p, c->f64);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+        return done(fail(MPSFR_E_HIP, "building the series tables of stage A failed"));
+    return done(MPSFR_OK);
+}
+
 int build_constant_tables(mpsfr_ctx* c) {
     const int N = c->N;
     // twiddles exp(-2 pi i m / N)
@@ -344,7 +396,7 @@ int build_constant_tables(mpsfr_ctx* c) {
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
-    return MPSFR_OK;
+    return build_series_tables(c);
 }
 
 }  // namespace
@@ -422,7 +474,8 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         mpsfr_ctx::Lane& ln = c->lane[k];
         if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
         if (ln.done) (void)hipEventDestroy(ln.done);
-        DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.dmin, &ln.dblk, &ln.vkeep, &ln.dminb, &ln.order, &ln.mown, &ln.muni, &ln.msched, &ln.mpart};
+        DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.dmin, &ln.dblk, &ln.vkeep, &ln.dminb, &ln.order, &ln.mown, &ln.muni, &ln.msched, &ln.mpart,
+                         &ln.pP, &ln.pT, &ln.psp};
         for (auto b : lb) release(*b);
     }
     for (int k = 0; k < mpsfr_ctx::NSTAGE; ++k) {
@@ -433,7 +486,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         release(sl.params);
         release(sl.ktt);
     }
-    DevBuf* all[] = {&c->tw64, &c->tel, &c->rows, &c->tlmax, &c->tl2, &c->tlb, &c->aotab, &c->samp_p,
+    DevBuf* all[] = {&c->scoef, &c->tw64, &c->tel, &c->rows, &c->tlmax, &c->tl2, &c->tlb, &c->aotab, &c->samp_p,
                      &c->samp_a, &c->G, &c->xtab, &c->etab, &c->gtab, &c->kmuse, &c->fit, &c->sum,
                      &c->stage, &c->lsum, &c->mfclk};
     for (auto b : all) release(*b);
@@ -474,6 +527,9 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         c->mf_permax = (int)value;
     } else if (!strcmp(key, "mf_mid_log2")) {
         c->mf_mid_log2 = value;
+    } else if (!strcmp(key, "stage_a")) {
+        if (value != 0.0 && value != 1.0) return fail(MPSFR_E_INVALID, "stage_a must be 0 (full-size transforms) or 1 (series + patch)");
+        c->stage_a = (int)value;
     } else if (!strcmp(key, "mf_clock")) {
         c->mf_clock = value != 0.0;
         if (c->mf_clock) {
@@ -585,11 +641,16 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         tp[t].cn2_0 = c0;
         tp[t].cn2_1 = c1;
         tp[t].geom = (three_lgs && three_lgs[t]) ? 1 : 0;
-        tp[t].pad = 0;
+        tp[t].basis = 0;
         gam[t] = tiptilt_alpha(seeing[t], gl[t], l0[t], c->pixscale);
         alp[t] = 2.0;                                    // beta_tt, psfrec.py:879
     }
     for (int l = 0; l < nl; ++l) muse_kernel_params(lbda_nm[l], c->pixscale, &gam[ntask + l], &alp[ntask + l]);
+    // Stage A in its series form needs every 1/L0^2 inside the radius of its expansion (L0 >= 7 m;
+    // the SPARTA front end only lets 8 < L0 < 30 through, psfrec.py:1049-1051); a call with a shorter
+    // outer scale takes the full-size transforms.
+    bool series = c->stage_a == 1;
+    for (int t = 0; t < ntask; ++t) series = series && tp[t].inv_l0sq <= series_eps_max();
 
     // ---- geometry of the AO tables (psfrec.py:61, 66, 86-93, 99, 154-158, 536-537, 594)
     AoGeom g;
@@ -631,7 +692,10 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         const int soft = (4096 + nl - 1) / nl < 8 ? 8 : (4096 + nl - 1) / nl;
         if (big > 512) big = 512;
         if (big < soft) big = soft;
-        const double per_task = (double)ndir * (N / 2 + NAO / 2) * H1 * 16.0;
+        // (the largest workspace per task: the row transforms C of the full-size form; D and the patch
+        // transforms of the series form)
+        const double per_task = series ? (double)ndir * H1 * (N * (double)rsize(c) + NAO * 16.0)
+                                       : (double)ndir * (N / 2 + NAO / 2) * H1 * 16.0;
         const int cap = (int)(4.0 * 1024 * 1024 * 1024 / per_task);
         if (big > cap) big = cap < 1 ? 1 : cap;
         int nch = (ntask + big - 1) / big;
@@ -852,9 +916,15 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     if (prune && mf && c->mf_floor && thr_blk < kMfFloorLog2) thr_blk = kMfFloorLog2;
     for (int j = 0; j < NL; ++j) {
         mpsfr_ctx::Lane& ln = lane_of(j);
-        // row FFTs of the PSD: only the N/2 + 40 distinct rows are stored (K_PSD_ROWFFT)
-        if ((rc = ensure(c, ln.C, (size_t)TC * ndir * (N / 2 + NAO / 2) * H1 * 2 * sizeof(double)))) return rc;
-        if ((rc = ensure(c, ln.s00, (size_t)TC * ndir * psd_rowfft_groups(N) * sizeof(double)))) return rc;
+        if (series) {
+            if ((rc = ensure(c, ln.pP, (size_t)TC * ndir * NAO * NAO * sizeof(double)))) return rc;
+            if ((rc = ensure(c, ln.pT, (size_t)TC * ndir * H1 * NAO * 2 * sizeof(double)))) return rc;
+            if ((rc = ensure(c, ln.psp, (size_t)TC * ndir * sizeof(double)))) return rc;
+        } else {
+            // row FFTs of the PSD: only the N/2 + 40 distinct rows are stored (K_PSD_ROWFFT)
+            if ((rc = ensure(c, ln.C, (size_t)TC * ndir * (N / 2 + NAO / 2) * H1 * 2 * sizeof(double)))) return rc;
+            if ((rc = ensure(c, ln.s00, (size_t)TC * ndir * psd_rowfft_groups(N) * sizeof(double)))) return rc;
+        }
         {   // 16 lines of padding behind D: the last m-tile of the matrix-core kernel reads past line
             // N/2 (where its telescope table is -inf); fresh memory is zeroed so that what it reads
             // there is always a finite number
@@ -890,11 +960,8 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         if ((rc = ensure(c, c->fit, (size_t)ntask * nl * NFIT * sizeof(double)))) return rc;
         d_fit_all = (double*)c->fit.p;
     }
-    const double cfit = (std::tgamma(11.0 / 6.0) * std::tgamma(11.0 / 6.0) /
-                         (2.0 * std::pow(M_PI, 11.0 / 3.0))) *
-                        std::pow(24.0 * std::tgamma(6.0 / 5.0) / 5.0, 5.0 / 6.0);   // psfrec.py:622-623
-    const double k500 = 0.5 * 1000 / (2 * M_PI);                                    // psfrec.py:151
-    const double scale2 = 2.0 * (k500 * k500) / 256.0;       // 2 (.)/L^2, L = 16 m (psfrec.py:710, 718)
+    const double cfit = fit_constant();
+    const double scale2 = dphi_scale2();
     double* d_sum = (dev_out && psf_sum_out) ? psf_sum_out : (double*)c->sum.p;
 
     // the call's tables are produced on its first lane; the other lanes wait for them
@@ -916,12 +983,21 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             HIPCHK(hipStreamWaitEvent(ls, c->stagger_ev, 0));
             c->stagger_armed = false;
         }
-        {
-            ProfScope ps(c, K_PSD_ROWFFT, ls);
-            launch_psd_rowfft(ls, N, ntd, ndir, d_tp + t0, (const double*)c->aotab.p, cfit, ln.C.p,
-                              c->tw64.p, (double*)ln.s00.p, c->f64);
-        }
-        {
+        if (series) {
+            {
+                ProfScope ps(c, K_PATCH, ls);
+                launch_patch(ls, N, ntd, ndir, d_tp + t0, (const double*)c->aotab.p, cfit, c->tw64.p,
+                             (double*)ln.pP.p, ln.pT.p, (double*)ln.psp.p, c->f64);
+            }
+            ProfScope ps(c, K_DPHI_SERIES, ls);
+            launch_dphi_series(ls, N, ntd, ndir, d_tp + t0, ln.pT.p, (const double*)ln.psp.p, c->scoef.p,
+                               c->tw64.p, scale2, ln.D0t.p, c->f64, mf2 ? (int*)ln.msched.p : nullptr);
+        } else {
+            {
+                ProfScope ps(c, K_PSD_ROWFFT, ls);
+                launch_psd_rowfft(ls, N, ntd, ndir, d_tp + t0, (const double*)c->aotab.p, cfit, ln.C.p,
+                                  c->tw64.p, (double*)ln.s00.p, c->f64);
+            }
             ProfScope ps(c, K_COLFFT_DPHI, ls);
             launch_colfft_dphi(ls, N, ntd, ln.C.p, (const double*)ln.s00.p, scale2, ln.D0t.p,
                                c->f64, c->tw64.p, mf2 ? (int*)ln.msched.p : nullptr);

@@ -4,6 +4,7 @@
 //
 // Stage A, once per (task, direction): AO tables, telescope OTF, PSD -> structure function.
 #include "device_common.h"
+#include "psd_model.h"
 
 namespace mpsfr {
 
@@ -148,48 +149,6 @@ constexpr size_t a_smem() {
     return (size_t)((a_regtw<N>() ? 0 : 1) + fft_nbuf<N>() * a_slots<N, COL>()) * LineCfg<N>::NPAD * sizeof(cx<double>);
 }
 
-// x^(-11/6) = (x^(-1/6))^11 for x > 0 in the float range.  y = x^(-1/6) from a hardware
-// log2/exp2 seed (relative error e0 ~ 1e-6) and Newton steps on y^-6 = x,
-//   y <- y (7 - x y^6) / 6,   e' = -3.5 e^2   (1e-6 -> 1e-11 -> 1e-21),
-// then five multiplies: ~25 fp64 instructions against ~70 for cbrt(sqrt(x)) / x^2 (this function
-// is what K_PSD_ROWFFT spends its VALU time on: every element of every distinct PSD row).
-// (NEWTON = 1: relative error ~4e-12, mixed mode -- D is stored as fp32; 2: f64 mode)
-template <int NEWTON>
-__device__ __forceinline__ double pow_m11_6(double x) {
-    double y = (double)__builtin_amdgcn_exp2f(-0.16666667f * __builtin_amdgcn_logf((float)x));
-#pragma unroll
-    for (int it = 0; it < NEWTON; ++it) {
-        const double y2 = y * y, y3 = y2 * y;
-        y = y * fma(-(1.0 / 6.0) * x, y3 * y3, 7.0 / 6.0);
-    }
-    const double y2 = y * y, y4 = y2 * y2;
-    return (y4 * y4) * (y2 * y);
-}
-
-// fitting term (psd_fit psfrec.py:616-626) at row su, column sv of the half-pixel grid
-template <int NEWTON>
-__device__ __forceinline__ double psd_fit_value(int su, int sv, const TaskPar& p, double cfit) {
-    const double fx = sv + 0.5, fy = su + 0.5;
-    const double f2 = (fx * fx + fy * fy) * (1.0 / 256.0);          // L = 16 m, psfrec.py:618
-    return f2 >= 2.25 ? cfit * p.r0m53 * pow_m11_6<NEWTON>(f2 + p.inv_l0sq) : 0.0;   // f >= fc = 1.5, :624
-}
-
-// max(fit, AO) inside the 80 x 80 corrected zone (psfrec.py:148-149), fit elsewhere
-template <int NEWTON>
-__device__ __forceinline__ double psd_with_ao(double fit, int su, int sv, const TaskPar& p,
-                                              const double* __restrict__ tb) {
-    if (su >= -NAO / 2 && su < NAO / 2 && sv >= -NAO / 2 && sv < NAO / 2) {
-        const int ia = su < 0 ? su + NAO : su, ib = sv < 0 ? sv + NAO : sv;
-        const double g2 = (double)(su * su + sv * sv) * (1.0 / 256.0);
-        const double vk = 0.0229 * p.r0m53 * pow_m11_6<NEWTON>(g2 + p.inv_l0sq);   // :569-571
-        const int o = ia * NAO + ib;
-        const double ao = vk * (p.cn2_0 * tb[o] + p.cn2_1 * tb[NAO * NAO + o]) +
-                          tb[2 * NAO * NAO + o];
-        fit = fmax(fit, ao);                                        // :149
-    }
-    return fit;
-}
-
 // F64: the f64 mode (two Newton steps in x^(-11/6)).  dcpart[td][workgroup]: the workgroup's share of
 // S00 = sum of the PSD = Re sum_r C[td][r][0] (bg[0,0], psfrec.py:721; compact rows with su >= 40
 // stand for two rows) -- K_COLFFT_DPHI adds the shares in a fixed order.
@@ -248,7 +207,7 @@ k_psd_rowfft(int ndir, const TaskPar* __restrict__ tp, const double* __restrict_
             x[e] = {psd_fit_value<NEWTON>(sua, sv, p, cfit), psd_fit_value<NEWTON>(sub, sv, p, cfit)};
         }
     }
-    if (sua < NAO / 2) {                                        // (wave-uniform when TPR >= 64)
+    if (sua < NAO / 2 && p.basis == 0) {                        // (wave-uniform when TPR >= 64)
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int c = t + e * TPR;

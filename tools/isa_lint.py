@@ -26,6 +26,10 @@ instruction of every kernel (it cannot tell compiler instructions from asm ones,
       s_waitcnt vmcnt(0) with no LDS-DMA load in between (a barrier does not drain the DMA, and the
       waves behind it read what the DMA wrote).
 
+  R6  a VGPR written by a vector instruction is not read through DPP (the first source of a *_dpp
+      instruction: the row_newbcast operands of stage_a2.hip) within 2 wait states, and EXEC written
+      by a vector instruction is not followed by a DPP instruction within 5.
+
 Wait states are counted conservatively: every instruction is one, s_nop N is N + 1; a distance is
 taken over every path that reaches the instruction (fall-through and branches).
 
@@ -241,6 +245,24 @@ def lint_kernel(name, code):
                         code[i], sorted(pj.dst_regs() & vsrc), pj)))
                 return True
             walk_back(code, preds, i, 1, v4)
+        if ins.is_valu() and ins.op.endswith('_dpp') and len(ins.ops) > 1:
+            dsrc = {r for r in regs_of(ins.ops[1]) if r[0] == 'v'}
+            def v6(j, between, dsrc=dsrc, i=i):
+                pj = code[j]
+                if pj.is_valu() and (pj.dst_regs() & dsrc):
+                    out.append(('R6', name, '%r reads %s through DPP, written by %r %d wait state(s) earlier (need 2)' % (
+                        code[i], sorted(pj.dst_regs() & dsrc), pj, between)))
+                    return True
+                return False
+            walk_back(code, preds, i, 2, v6)
+            def v6x(j, between, i=i):
+                pj = code[j]
+                if pj.is_valu() and ('exec',) in pj.dst_regs():
+                    out.append(('R6', name, '%r: EXEC written by %r %d wait state(s) before a DPP instruction (need 5)' % (
+                        code[i], pj, between)))
+                    return True
+                return False
+            walk_back(code, preds, i, 5, v6x)
         if has_dma and ins.op == 's_barrier':
             # every path backwards must meet an s_waitcnt vmcnt(0) before it meets an LDS-DMA load
             stack, seen, bad = list(preds[i]), set(), None
