@@ -28,7 +28,7 @@ def test_library_builds_and_exports_the_header():
     assert lib.mpsfr_version() == 102
     from muse_psfr_amd._build import source_hash
     assert lib.mpsfr_build_id().decode() == source_hash()
-    assert lib.mpsfr_profile_count() == 14
+    assert lib.mpsfr_profile_count() == 16
     assert lib.mpsfr_profile_name(6) == b'otf_rowfft' and lib.mpsfr_profile_name(12) == b'otf_mfma'
 
 
