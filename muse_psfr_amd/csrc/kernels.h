@@ -87,15 +87,22 @@ void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dlin
 // fp64 planes [terms][N/2+1][N] that launch_colfft_dphi produced for the basis tasks);
 // launch_patch: d_P [ntd][80][80], d_T [ntd][N/2+1][80] complex, d_sp [ntd];
 // launch_dphi_series: D0t as launch_colfft_dphi writes it.  Valid for 1/L0^2 <= series_eps_max().
+// d_twk: the per-lane twiddle table of launch_series_twiddles (series_twiddle_bytes), which takes the
+// place of d_tw64 in launch_patch / launch_dphi_series
+size_t series_twiddle_bytes(int N);
+void launch_series_twiddles(hipStream_t s, int N, const void* d_tw64, void* d_twk);
 int series_terms(bool f64);
 double series_eps0();
 inline double series_eps_max() { return 1.0 / 49.0; }
 void launch_series_coef(hipStream_t s, int N, const double* d_planes, void* d_coef, bool f64);
 void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const double* d_aotab,
-                  double cfit, const void* d_tw64, double* d_P, void* d_T, double* d_sp, bool f64);
+                  double cfit, const void* d_twk, double* d_P, void* d_T, double* d_sp, bool f64);
 void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const void* d_T,
-                        const double* d_sp, const void* d_coef, const void* d_tw64, double scale2,
-                        void* d_D0t, bool f64out, int* d_zero = nullptr);
+                        const double* d_sp, const void* d_coef, const void* d_twk, double scale2,
+                        void* d_D0t, float* d_dlin, bool f64out, int* d_zero, int ncu);
+// d_dlin: [ntd][N/2+1][N/32] minima of max(D, 0) per line and block of 32 columns, written by
+// launch_dphi_series when not nullptr; launch_dmin16 turns them into what launch_dmin computes from D
+void launch_dmin16(hipStream_t s, int N, int ntd, const float* d_dlin, float* d_dline, float* d_dblk);
 void launch_tel_linemax(hipStream_t s, int N, const void* d_tel, float* d_tlmax, bool f64 = false);
 void launch_vkeep(hipStream_t s, int N, int ntask, int ndir, int nl, const LamPar* d_lp,
                   const float* d_dline, const float* d_dblk, const float* d_tlmax, float thr_sum,

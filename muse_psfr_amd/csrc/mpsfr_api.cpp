@@ -84,7 +84,7 @@ struct mpsfr_ctx {
     int stage_a = 1;             // 1: series + patch form of stage A (stage_a2.hip); 0: full-size transforms
     DevBuf mfclk;
     // constant tables
-    DevBuf tw64, tel, rows, tlmax, tl2, tlb, scoef;
+    DevBuf tw64, tel, rows, tlmax, tl2, tlb, scoef, stwk;
     // per-call tables
     DevBuf aotab, samp_p, samp_a, G, kmuse, xtab, etab, gtab;
     // Pipeline lanes: each lane owns a HIP stream and a set of chunk workspaces.  Consecutive
@@ -96,7 +96,7 @@ struct mpsfr_ctx {
         hipEvent_t done = nullptr;       // after the lane's last chunk of the most recent call
         bool busy = false;               // `done` has been recorded
         DevBuf C, s00, D0t, Tq, pre, fin, dmin, dblk, vkeep, dminb, order, mown, muni, msched, mpart;
-        DevBuf pP, pT, psp;              // series form of stage A: patch, its row transforms, its sum
+        DevBuf pP, pT, psp, dlin;        // series form of stage A: patch, its row transforms, its sum; line minima
         // device outputs of its most recent calls: `done` is recorded behind every call of the lane,
         // so waiting for it covers all of them (a caller that rotates more buffer sets than lanes
         // must still get the calls that share a buffer in order)
@@ -347,6 +347,8 @@ int build_series_tables(mpsfr_ctx* c) {
                       (double*)s00.p, true);
     launch_colfft_dphi(c->stream, N, K, C.p, (const double*)s00.p, dphi_scale2(), planes.p, true, c->tw64.p);
     launch_series_coef(c->stream, N, (const double*)planes.p, c->scoef.p, c->f64);
+    if ((rc = ensure(c, c->stwk, series_twiddle_bytes(N)))) return done(rc);
+    launch_series_twiddles(c->stream, N, c->tw64.p, c->stwk.p);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
         return done(fail(MPSFR_E_HIP, "building the series tables of stage A failed"));
     return done(MPSFR_OK);
@@ -475,7 +477,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
         if (ln.done) (void)hipEventDestroy(ln.done);
         DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.dmin, &ln.dblk, &ln.vkeep, &ln.dminb, &ln.order, &ln.mown, &ln.muni, &ln.msched, &ln.mpart,
-                         &ln.pP, &ln.pT, &ln.psp};
+                         &ln.pP, &ln.pT, &ln.psp, &ln.dlin};
         for (auto b : lb) release(*b);
     }
     for (int k = 0; k < mpsfr_ctx::NSTAGE; ++k) {
@@ -486,7 +488,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         release(sl.params);
         release(sl.ktt);
     }
-    DevBuf* all[] = {&c->scoef, &c->tw64, &c->tel, &c->rows, &c->tlmax, &c->tl2, &c->tlb, &c->aotab, &c->samp_p,
+    DevBuf* all[] = {&c->scoef, &c->stwk, &c->tw64, &c->tel, &c->rows, &c->tlmax, &c->tl2, &c->tlb, &c->aotab, &c->samp_p,
                      &c->samp_a, &c->G, &c->xtab, &c->etab, &c->gtab, &c->kmuse, &c->fit, &c->sum,
                      &c->stage, &c->lsum, &c->mfclk};
     for (auto b : all) release(*b);
@@ -920,6 +922,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             if ((rc = ensure(c, ln.pP, (size_t)TC * ndir * NAO * NAO * sizeof(double)))) return rc;
             if ((rc = ensure(c, ln.pT, (size_t)TC * ndir * H1 * NAO * 2 * sizeof(double)))) return rc;
             if ((rc = ensure(c, ln.psp, (size_t)TC * ndir * sizeof(double)))) return rc;
+            if (prune && (rc = ensure(c, ln.dlin, (size_t)TC * ndir * H1 * (N / 32) * sizeof(float)))) return rc;
         } else {
             // row FFTs of the PSD: only the N/2 + 40 distinct rows are stored (K_PSD_ROWFFT)
             if ((rc = ensure(c, ln.C, (size_t)TC * ndir * (N / 2 + NAO / 2) * H1 * 2 * sizeof(double)))) return rc;
@@ -986,12 +989,13 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         if (series) {
             {
                 ProfScope ps(c, K_PATCH, ls);
-                launch_patch(ls, N, ntd, ndir, d_tp + t0, (const double*)c->aotab.p, cfit, c->tw64.p,
+                launch_patch(ls, N, ntd, ndir, d_tp + t0, (const double*)c->aotab.p, cfit, c->stwk.p,
                              (double*)ln.pP.p, ln.pT.p, (double*)ln.psp.p, c->f64);
             }
             ProfScope ps(c, K_DPHI_SERIES, ls);
             launch_dphi_series(ls, N, ntd, ndir, d_tp + t0, ln.pT.p, (const double*)ln.psp.p, c->scoef.p,
-                               c->tw64.p, scale2, ln.D0t.p, c->f64, mf2 ? (int*)ln.msched.p : nullptr);
+                               c->stwk.p, scale2, ln.D0t.p, prune ? (float*)ln.dlin.p : nullptr, c->f64,
+                               mf2 ? (int*)ln.msched.p : nullptr, c->ncu);
         } else {
             {
                 ProfScope ps(c, K_PSD_ROWFFT, ls);
@@ -1016,13 +1020,15 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             // thin-wave kernel: block minima (one direction: they are the minima over the directions),
             // then masks and work lists (otf_mfma2.hip); no line bounds needed
             ProfScope ps(c, K_MF_PREP, ls);
-            if (prune) launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p);
+            if (prune && series) launch_dmin16(ls, N, ntd, (const float*)ln.dlin.p, (float*)ln.dmin.p, (float*)ln.dblk.p);
+            else if (prune) launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p);
             launch_mf_prep(ls, N, tc, nl, c->mf_permax, d_lp, prune ? (const float*)ln.dblk.p : nullptr, (const float*)c->tlb.p,
                            thr_blk, (prune && c->mf_floor) ? (float)c->mf_mid_log2 : -1.0e30f, ln.mown.p,
                            ln.muni.p, ln.msched.p);
         } else if (prune) {
             ProfScope ps(c, mf ? K_MF_PREP : K_VKEEP, ls);
-            launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p, c->f64);
+            if (series) launch_dmin16(ls, N, ntd, (const float*)ln.dlin.p, (float*)ln.dmin.p, (float*)ln.dblk.p);
+            else launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p, c->f64);
             launch_vkeep(ls, N, tc, ndir, nl, d_lp, (const float*)ln.dmin.p, (const float*)ln.dblk.p,
                          (const float*)c->tlmax.p, thr_sum, (int*)ln.vkeep.p, c->prune_fixed,
                          mf ? (float*)ln.dminb.p : nullptr);

@@ -208,6 +208,31 @@ __device__ __forceinline__ double mov_bc(double x) {                            
 
 constexpr int kNX = NAO / 16;        // register pairs per component of a fold's 80 inputs
 
+// Minima over the lanes 0-31 and 32-63 of four values at a time: five v_min_f32_dpp steps each (quad
+// swaps, half-row and row mirrors: every lane holds the minimum of its row of 16; row_bcast:15: rows 1
+// and 3 hold the minima of lanes 0-31 and 32-63 -- row 0 gets min(v, 0) and row 2 the minimum of rows
+// 1 | 2, which nobody reads).  One statement: a DPP operand must not have been written in the two wait
+// states before, which the three other values' instructions provide between the steps of one value
+// (and the opening s_nop for whatever computed the inputs); hipcc does not form v_min_f32_dpp from
+// __builtin_amdgcn_update_dpp + fminf with an identity of +inf (mov, mov_dpp, two wait states, min:
+// the fused minima took a third of the kernel that way).
+#define MPSFR_MIN4(ctrl)                                                        \
+    "v_min_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_min_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_min_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_min_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void min32_x4(float& a, float& b, float& c, float& d) {
+    asm("s_nop 1\n\t"
+        MPSFR_MIN4("quad_perm:[1,0,3,2]")
+        MPSFR_MIN4("quad_perm:[2,3,0,1]")
+        MPSFR_MIN4("row_half_mirror")
+        MPSFR_MIN4("row_mirror")
+        MPSFR_MIN4("row_bcast:15")
+        "s_nop 0"       /* (the next instruction may read d: written by a DPP instruction one state before) */
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+#undef MPSFR_MIN4
+
 // The sums of a group of CNT residues r_i = R0 + RS i:  acc[i] = sum_j in[r_i + Q j] W_64^(j k2)
 // (the factor W_N^(r k2) is the caller's).  xr / xi: the inputs as broadcast operands (index
 // su + 40; xi unused for a real input), wj[j - JMIN] = W_64^(j k2).  Term by term over j, all
@@ -296,6 +321,22 @@ __device__ __forceinline__ void fold_sums(cx<double>* v, const double* xr, const
 }
 
 // ------------------------------------------------------------------------------------------
+// The twiddles of a lane, laid out per lane: twk[j - JMIN][k2] = W_64^(j k2) for the NJ fold terms,
+// then twk[NJ + r][k2] = W_N^(r k2) for r < Q.  Built once per context: a wave reads a row of the
+// table as 1 KB of consecutive bytes, where twg[(r k2) mod N] straight from the table of N-th roots
+// is a gather of 64 cache lines per instruction -- the 16 such gathers at the head of every wave of
+// K_PATCH_ROWS kept its vector-memory pipe full and the waves at 40 cycles per instruction.
+// ------------------------------------------------------------------------------------------
+template <int N>
+__global__ void __launch_bounds__(64) k_series_twiddles(const cx<double>* __restrict__ twg,
+                                                        cx<double>* __restrict__ twk) {
+    constexpr int Q = N / 64, NJ = fold_nj<Q>(), JMIN = fold_jmin<Q>();
+    const int row = blockIdx.x, k2 = threadIdx.x;
+    if (row < NJ) twk[row * 64 + k2] = twg[(((Q * (row + JMIN) * k2) % N) + N) % N];
+    else twk[row * 64 + k2] = twg[((row - NJ) * k2) % N];
+}
+
+// ------------------------------------------------------------------------------------------
 // K_PATCH_GEN: P[td][su + 40][sv + 40] = max(F, AO) - F on the corrected zone (psfrec.py:148-149;
 // F and AO exactly as K_PSD_ROWFFT evaluates them).
 // ------------------------------------------------------------------------------------------
@@ -315,26 +356,39 @@ __global__ void __launch_bounds__(256) k_patch_gen(int ndir, const TaskPar* __re
 }
 
 // ------------------------------------------------------------------------------------------
-// K_PATCH_ROWS: T[td][su + 40][y] = sum_sv P[su][sv] exp(-2 pi i sv y / N), y in [0, N/2], and
-// sp[td] = sum P.  A wave takes a row su: lane k2 folds the row's 80 values (broadcast operands)
-// into Q sums with its own twiddles, transforms them in registers and owns y = k2, 64 + k2, ...
+// K_PATCH_ROWS: T[td][y][su + 40] = sum_sv P[su][sv] exp(-2 pi i sv y / N), y in [0, N/2], and
+// sp[td] = sum P.  A wave takes two or four adjacent rows su: lane k2 folds a row's 80 values (broadcast
+// operands) into Q sums with its own twiddles, transforms them in registers and owns y = k2, 64 + k2, ...
+// K_DPHI_SERIES reads the 80 values of one (td, y) as 1280 contiguous bytes (with T[td][su][y] every
+// line of it gathered 80 cache lines: 12 of its 50 us at 512^2), so a lane stores its rows' values
+// of one y as one 32- or 64-byte piece; the waves are independent (a transposition of 8 rows through LDS
+// for 128-byte pieces cost two barriers per workgroup and, at 1280^2, all of a CU's LDS: 31 -> 46 us).
 // ------------------------------------------------------------------------------------------
-constexpr int kRowsPerWg = 16;
+template <int N>
+constexpr int rows_per_wave() { return N / 64 <= 8 ? 4 : 2; }      // (a row's results are N/128 + 1 complex registers)
+
 template <int N>
 __global__ void __launch_bounds__(256) k_patch_rows(const double* __restrict__ P,
-                                                    const cx<double>* __restrict__ twg,
+                                                    const cx<double>* __restrict__ twk,
                                                     cx<double>* __restrict__ T, double* __restrict__ sp) {
     constexpr int Q = N / 64, H1 = N / 2 + 1, NJ = fold_nj<Q>(), JMIN = fold_jmin<Q>();
     constexpr bool WJREG = NJ <= 10;
+    constexpr int NY = Q / 2 + 1;                        // values y = 64 k1 + k2 <= N/2 of a lane
+    constexpr int RW = rows_per_wave<N>();
     __shared__ cx<double> swj[WJREG ? 1 : NJ][64];
     __shared__ double sred[256];
     const int td = blockIdx.y;
     const double* Pg = P + (size_t)td * (NAO * NAO);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = RW * (blockIdx.x * 4 + wave);                        // rows su + 40 = n0 ... n0 + RW - 1
+    double xr[RW][kNX];
+#pragma unroll
+    for (int h = 0; h < RW; ++h)
+#pragma unroll
+        for (int a = 0; a < kNX; ++a) xr[h][a] = Pg[(n0 + h) * NAO + 16 * a + (lane & 15)];
     if constexpr (!WJREG) {
-        for (int i = threadIdx.x; i < NJ * 64; i += 256)
-            swj[i >> 6][i & 63] = twg[(((Q * ((i >> 6) + JMIN) * (i & 63)) % N) + N) % N];
+        for (int i = threadIdx.x; i < NJ * 64; i += 256) swj[i >> 6][i & 63] = twk[i];
         __syncthreads();
     }
     if (blockIdx.x == 0) {      // sum of the patch, in an order fixed by the launch geometry
@@ -351,15 +405,13 @@ __global__ void __launch_bounds__(256) k_patch_rows(const double* __restrict__ P
     cx<double> wjr[WJREG ? NJ : 1], wr[Q];
     if constexpr (WJREG) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) wjr[j] = twg[(((Q * (j + JMIN) * lane) % N) + N) % N];
+        for (int j = 0; j < NJ; ++j) wjr[j] = twk[j * 64 + lane];
     }
 #pragma unroll
-    for (int r = 1; r < Q; ++r) wr[r] = twg[(r * lane) % N];
-    for (int i = 0; i < kRowsPerWg / 4; ++i) {
-        const int n = blockIdx.x * kRowsPerWg + wave + 4 * i;          // row su + 40
-        double xr[kNX];
+    for (int r = 1; r < Q; ++r) wr[r] = twk[(NJ + r) * 64 + lane];
+    cx<double> res[RW][NY];
 #pragma unroll
-        for (int a = 0; a < kNX; ++a) xr[a] = Pg[n * NAO + 16 * a + (lane & 15)];
+    for (int h = 0; h < RW; ++h) {
         cx<double> S[Q];
         {
             constexpr int GC = Q % 5 == 0 ? 5 : (Q < 4 ? Q : 4);
@@ -371,42 +423,261 @@ __global__ void __launch_bounds__(256) k_patch_rows(const double* __restrict__ P
             const cx<double>* wjp = WJREG ? wjr : wl;
             static_for<0, Q / GC>([&](auto gc) {
                 constexpr int R0 = decltype(gc)::value * GC;
-                fold_sums<Q, false, R0, 1, GC>(S + R0, xr, xr, wjp, [&](int r) { return wr[r]; });
+                fold_sums<Q, false, R0, 1, GC>(S + R0, xr[h], xr[h], wjp, [&](int r) { return wr[r]; });
             });
         }
         dftq<Q>(S);
-        cx<double>* Tt = T + ((size_t)td * NAO + n) * H1 + lane;
 #pragma unroll
-        for (int k1 = 0; k1 <= Q / 2; ++k1)
-            if (64 * k1 + lane <= N / 2) Tt[64 * k1] = S[k1];
+        for (int k1 = 0; k1 < NY; ++k1) res[h][k1] = S[k1];
     }
+    cx<double>* Tt = T + ((size_t)td * H1 + lane) * NAO + n0;
+#pragma unroll
+    for (int k1 = 0; k1 < NY; ++k1)
+        if (64 * k1 + lane <= N / 2) {
+#pragma unroll
+            for (int h = 0; h < RW; ++h) Tt[(size_t)64 * k1 * NAO + h] = res[h][k1];
+        }
 }
 
 // ------------------------------------------------------------------------------------------
 // K_DPHI_SERIES: D0t[td][y][x] = r0^(-5/3) sum_k delta^k Hd_k[y][x] + scale2 (sp - Re X[x]) with
-// X[x] = sum_su T[td][su][y] exp(-2 pi i su x / N).  Workgroup = (line y, group of tasks): the
-// coefficients of the line and the twiddles W_N^(r k2) go to LDS once; every wave then walks its
-// tasks alone (no barrier).  The 80 complex inputs of a line are broadcast operands (above).
-//   coef: [y][x][K] (K fp32 / fp64 terms of pixel (y, x) side by side).
+// X[x] = sum_su T[td][y][su] exp(-2 pi i su x / N).  A wave takes one (td, y) at a time ("a line"):
+// the 80 complex inputs are broadcast operands (above), lane k2 owns x = k2, 64 + k2, ...
+//   coef: [y][x][K] (K fp32 / fp64 terms of pixel (y, x) side by side), staged in LDS per line y.
 // ------------------------------------------------------------------------------------------
 template <typename RO> struct SeriesCfg;
-template <> struct SeriesCfg<float> { static constexpr int K = 4, THREADS = 256; };
-template <> struct SeriesCfg<double> { static constexpr int K = 8, THREADS = 256; };
+template <> struct SeriesCfg<float> { static constexpr int K = 4; };
+template <> struct SeriesCfg<double> { static constexpr int K = 8; };
 
+// one line: xv = its inputs (lane l holds input 16 a + l % 16 in xv[a]), wjp[j - JMIN] = W_64^(j k2) of
+// the lane, swr[r * 64 + k2] = W_N^(r k2) (LDS), scoef = the coefficients of line y (LDS, [x][K])
+template <int N, typename RO>
+__device__ __forceinline__ void series_line(const cx<double>* xv, const cx<double>* wjp,
+                                            const cx<double>* swr, const RO* scoef, double r0m53,
+                                            double delta, double spv, double scale2, RO* dst, float* dlin,
+                                            int lane, int dbg) {
+    constexpr int Q = N / 64, K = SeriesCfg<RO>::K;
+    double xr[kNX], xi[kNX];
+#pragma unroll
+    for (int a = 0; a < kNX; ++a) {
+        xr[a] = xv[a].x;
+        xi[a] = xv[a].y;
+    }
+    double out[Q];
+    if (dbg & 2) {
+#pragma unroll
+        for (int k1 = 0; k1 < Q; ++k1) out[k1] = xr[k1 % kNX] + k1;
+    } else {
+        auto wrf = [&](int r) { return swr[r * 64 + lane]; };
+        if constexpr (Q == 2) {
+            cx<double> S[2];
+            fold_sums<Q, true, 0, 1, 2>(S, xr, xi, wjp, wrf);
+            out[0] = S[0].x + S[1].x;
+            out[1] = S[0].x - S[1].x;
+        } else if constexpr (Q >= 16) {
+            // the Q / 4 residues of one r1 at a time: 4 or 5 independent accumulator pairs
+            dftq_real_out<Q>(
+                [&](auto r1c, cx<double>* v) {
+                    fold_sums<Q, true, decltype(r1c)::value, 4, Q / 4>(v, xr, xi, wjp, wrf);
+                },
+                out);
+        } else {
+            // Q = 4, 8: all sums first, four residues to a group
+            cx<double> S[Q];
+            static_for<0, Q / 4>([&](auto gc) {
+                constexpr int R0 = decltype(gc)::value * 4;
+                fold_sums<Q, true, R0, 1, 4>(S + R0, xr, xi, wjp, wrf);
+            });
+            dftq_real_out<Q>(
+                [&](auto r1c, cx<double>* v) {
+#pragma unroll
+                    for (int r2 = 0; r2 < Q / 4; ++r2) v[r2] = S[4 * r2 + decltype(r1c)::value];
+                },
+                out);
+        }
+    }
+    if (dbg & 4) {
+        if (out[0] == 1.2345) dst[0] = 0;
+        return;
+    }
+    // Block minima for the pruning of the per-wavelength stage, while the values are in registers
+    // (K_DMIN read all of D back for them: 12 us at 512^2, 69 us at 1280^2): the minimum of max(D, 0)
+    // over the 32 columns [32 kb, 32 kb + 32) of this line, kb = 2 k1 + (lane >= 32), goes to
+    // dlin[kb]; K_DMIN16 takes the minima over 16 lines.  min32_x4 leaves them in lanes 16-31 and 48-63;
+    // lane 16 + k1 % 16 (48 + k1 % 16) keeps the result of k1.
+    float keep[(Q + 15) / 16], dq[Q < 4 ? 4 : Q];
+#pragma unroll
+    for (int i = 0; i < (Q + 15) / 16; ++i) keep[i] = 0.f;
+    if constexpr (sizeof(RO) == 4) {
+        const float df = (float)delta, rf = (float)r0m53;
+#pragma unroll
+        for (int k1 = 0; k1 < Q; ++k1) {
+            const float4 h = *reinterpret_cast<const float4*>(scoef + (size_t)(64 * k1 + lane) * K);
+            const float dF = rf * fmaf(fmaf(fmaf(h.w, df, h.z), df, h.y), df, h.x);
+            const float d = (float)(fma(scale2, spv - out[k1], (double)dF));
+            dst[64 * k1] = d;
+            dq[k1] = fmaxf(d, 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int k1 = 0; k1 < Q; ++k1) {
+            const double* h = scoef + (size_t)(64 * k1 + lane) * K;
+            double a = h[K - 1];
+#pragma unroll
+            for (int k = K - 2; k >= 0; --k) a = fma(a, delta, h[k]);
+            const double d = fma(scale2, spv - out[k1], r0m53 * a);
+            dst[64 * k1] = d;
+            dq[k1] = fmaxf(__double2float_rd(d), 0.f);      // (rounded down: the bound stays a bound)
+        }
+    }
+    if (dlin != nullptr) {
+        if constexpr (Q < 4) {
+            dq[2] = dq[0];
+            dq[3] = dq[1];
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < (Q < 4 ? 4 : Q); k1 += 4) {
+            min32_x4(dq[k1], dq[k1 + 1], dq[k1 + 2], dq[k1 + 3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (k1 + i < Q && (lane & 15) == ((k1 + i) & 15)) keep[(k1 + i) >> 4] = dq[k1 + i];
+        }
+    }
+    if (dlin != nullptr && (lane & 16)) {
+#pragma unroll
+        for (int i = 0; i < (Q + 15) / 16; ++i) {
+            const int k1 = 16 * i + (lane & 15);
+            if (k1 < Q) dlin[2 * k1 + (lane >> 5)] = keep[i];
+        }
+    }
+}
+
+// Persistent form: one workgroup per CU, the C = (N/2+1) ntd lines in y-major order cut into equal
+// contiguous shares; the waves of a workgroup take the lines of its share in turn (wave w: lines
+// c0 + w, c0 + w + NW, ...), so every wave of the launch does the same number of lines +- 1 and the
+// set-up (twiddles, first coefficients) is paid once.  At any time the waves of a workgroup are within
+// NW lines of each other, i.e. in at most two consecutive y: the coefficients of y_lo and y_lo + 1 sit
+// in two LDS slots, and when wave 0 moves on to a new y_lo the workgroup meets at a barrier and loads
+// the next line's into the slot that fell free (a share is 1 - 3 lines y long: a handful of barriers
+// per launch).  [first form: one workgroup per (y, group of tasks) -- 2056 workgroups at 512^2, whose
+// set-up and +-1 task imbalance cost 20 of its 50 us]
+template <int N, typename RO>
+constexpr int series_threads() { return (N == 512 && sizeof(RO) == 4) ? 768 : (N <= 128 ? 256 : 512); }
 template <int N, typename RO>
 constexpr size_t series_smem() {
+    return 2 * (size_t)N * SeriesCfg<RO>::K * sizeof(RO) + (size_t)(N / 64) * 64 * sizeof(cx<double>);
+}
+template <int N, typename RO>
+constexpr bool series_fits() { return series_smem<N, RO>() <= 160 * 1024; }
+
+template <int N, typename RO>
+__global__ void __launch_bounds__((series_threads<N, RO>()))
+k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
+              const TaskPar* __restrict__ tp, int ndir, int ntd, const RO* __restrict__ coef,
+              const cx<double>* __restrict__ twk, double scale2, RO* __restrict__ D0t,
+              float* __restrict__ dlin, int* __restrict__ zero17, int dbg) {
+    constexpr int Q = N / 64, H1 = N / 2 + 1, K = SeriesCfg<RO>::K, THREADS = series_threads<N, RO>();
+    constexpr int NW = THREADS / 64, NJ = fold_nj<Q>(), JMIN = fold_jmin<Q>();
+    constexpr bool WJREG = NJ <= 10;         // the twiddles W_64^(j k2) of a lane in registers
+    constexpr int LINE = N * K;              // coefficients of a line
+    extern __shared__ __align__(16) unsigned char smem[];
+    RO* scoef = reinterpret_cast<RO*>(smem);                                       // [2][N][K]
+    cx<double>* swr = reinterpret_cast<cx<double>*>(smem + 2 * (size_t)LINE * sizeof(RO));   // [Q][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long C = (long)H1 * ntd;
+    const int c0 = (int)(C * blockIdx.x / gridDim.x), c1 = (int)(C * (blockIdx.x + 1) / gridDim.x);
+    if (zero17 != nullptr && blockIdx.x == 0 && threadIdx.x < 17) zero17[threadIdx.x] = 0;
+    if (c0 >= c1) return;
+    cx<double> xva[kNX], xvb[kNX];
+    auto fetch = [&](int c, cx<double>* xv) {
+        const int y = c / ntd, td = c - y * ntd;
+        const cx<double>* src = T + ((size_t)td * H1 + y) * NAO + (lane & 15);
+#pragma unroll
+        for (int a = 0; a < kNX; ++a) xv[a] = src[16 * a];
+    };
+    int c = c0 + wave;
+    if (c < c1 && wave < min(NW, ntd)) fetch(c, xva);
+    using V4 = typename std::conditional<sizeof(RO) == 4, float4, double2>::type;
+    constexpr int NV = (int)((size_t)LINE * sizeof(RO) / 16);
+    auto load_line = [&](int y) {          // (all threads) coefficients of line y -> slot y & 1
+        if (y > N / 2 || (dbg & 8)) return;
+        const V4* src = reinterpret_cast<const V4*>(coef + (size_t)y * LINE);
+        V4* dst = reinterpret_cast<V4*>(scoef + (size_t)(y & 1) * LINE);
+        for (int i = threadIdx.x; i < NV; i += THREADS) dst[i] = src[i];
+    };
+    int ylo = c0 / ntd;
+    load_line(ylo);
+    load_line(ylo + 1);
+    for (int i = threadIdx.x; i < Q * 64; i += THREADS) swr[i] = twk[NJ * 64 + i];
+    cx<double> wjr[WJREG ? NJ : 1];
+    if constexpr (WJREG) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wjr[j] = twk[j * 64 + lane];
+    }
+    __syncthreads();
+    auto line = [&](int c, const cx<double>* xv) {
+        const int y = c / ntd, td = c - y * ntd;
+        const int task = td / ndir;
+        const double r0m53 = tp[task].r0m53, delta = tp[task].inv_l0sq - kEps0;
+        const double spv = sp[td];
+        cx<double> wl[WJREG ? 1 : NJ];
+        if constexpr (!WJREG) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) wl[j] = twk[j * 64 + lane];
+        }
+        series_line<N, RO>(xv, WJREG ? wjr : wl, swr, scoef + (size_t)(y & 1) * LINE, r0m53, delta, spv, scale2,
+                           D0t + ((size_t)td * H1 + y) * N + lane,
+                           dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, lane, dbg);
+    };
+    // every wave runs the same number of rounds (the barriers below are met by all of them); a round
+    // is one line per active wave: c = cb + wave.  (With fewer tasks than waves a round would span more
+    // than two y: only ntd waves work then.)
+    const int nwe = min(NW, ntd);
+    auto new_y = [&](int cb) {
+        const int yb = cb / ntd;                 // the y of wave 0's line: uniform over the workgroup
+        if (yb != ylo) {                         // (yb = ylo + 1: a round is at most ntd lines long)
+            __syncthreads();                     // nobody reads line ylo any more
+            for (int yy = ylo + 2; yy <= yb + 1; ++yy) load_line(yy);
+            ylo = yb;
+            __syncthreads();
+        }
+    };
+    const bool active = wave < nwe;
+    c = c0 + wave;
+    for (int cb = c0; cb < c1; cb += 2 * nwe) {
+        new_y(cb);
+        {
+            const int c = cb + wave;
+            if (active && c + nwe < c1 && !(dbg & 1)) fetch(c + nwe, xvb);
+            if (active && c < c1) line(c, xva);
+        }
+        if (cb + nwe < c1) {
+            new_y(cb + nwe);
+            const int c = cb + nwe + wave;
+            if (active && c + nwe < c1 && !(dbg & 1)) fetch(c + nwe, xva);
+            if (active && c < c1) line(c, xvb);
+        }
+    }
+}
+
+// The first form, kept for what does not fit two coefficient slots in LDS (f64 mode at 1280^2):
+// workgroup = (line y, group of tasks), the coefficients of the line in LDS once, every wave then walks
+// its tasks alone.
+template <int N, typename RO>
+constexpr size_t series1_smem() {
     return (size_t)N * SeriesCfg<RO>::K * sizeof(RO) + (size_t)(N / 64) * 64 * sizeof(cx<double>);
 }
 
 template <int N, typename RO>
-__global__ void __launch_bounds__((SeriesCfg<RO>::THREADS), (sizeof(RO) == 4 ? 2 : 1))
-k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
-              const TaskPar* __restrict__ tp, int ndir, int ntd, int tg, const RO* __restrict__ coef,
-              const cx<double>* __restrict__ twg, double scale2, RO* __restrict__ D0t,
-              int* __restrict__ zero17, int dbg) {
-    constexpr int Q = N / 64, H1 = N / 2 + 1, K = SeriesCfg<RO>::K, THREADS = SeriesCfg<RO>::THREADS;
+__global__ void __launch_bounds__(256)
+k_dphi_series1(const cx<double>* __restrict__ T, const double* __restrict__ sp,
+               const TaskPar* __restrict__ tp, int ndir, int ntd, int tg, const RO* __restrict__ coef,
+               const cx<double>* __restrict__ twk, double scale2, RO* __restrict__ D0t,
+               float* __restrict__ dlin, int* __restrict__ zero17, int dbg) {
+    constexpr int Q = N / 64, H1 = N / 2 + 1, K = SeriesCfg<RO>::K, THREADS = 256;
     constexpr int NJ = fold_nj<Q>(), JMIN = fold_jmin<Q>();
-    constexpr bool WJREG = NJ <= 10;         // the twiddles W_64^(j k2) of a lane in registers
+    constexpr bool WJREG = NJ <= 10;
     extern __shared__ __align__(16) unsigned char smem[];
     RO* scoef = reinterpret_cast<RO*>(smem);                                   // [N][K]
     cx<double>* swr = reinterpret_cast<cx<double>*>(smem + (size_t)N * K * sizeof(RO));   // [Q][64]
@@ -415,112 +686,48 @@ k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int td_end = min(ntd, (g + 1) * tg);
     int td = g * tg + wave;
-    // the inputs of the wave's first line are requested before anything else
-    // (two register sets: the inputs of a line are requested a whole line ahead -- T comes from the
-    // Infinity Cache or from memory, and the polynomial phase alone did not cover that: 1280^2 172 -> us)
     cx<double> xva[kNX], xvb[kNX];
     auto fetch = [&](int t, cx<double>* xv) {
-        const cx<double>* src = T + ((size_t)t * NAO + (lane & 15)) * H1 + y;
+        const cx<double>* src = T + ((size_t)t * H1 + y) * NAO + (lane & 15);
 #pragma unroll
-        for (int a = 0; a < kNX; ++a) xv[a] = src[(size_t)16 * a * H1];
+        for (int a = 0; a < kNX; ++a) xv[a] = src[16 * a];
     };
     if (td < td_end) fetch(td, xva);
-    if (!(dbg & 8)) {
-        // the line's coefficients: one contiguous block of N K values
+    {
         using V4 = typename std::conditional<sizeof(RO) == 4, float4, double2>::type;
         constexpr int NV = (int)((size_t)N * K * sizeof(RO) / 16);
         const V4* src = reinterpret_cast<const V4*>(coef + (size_t)y * N * K);
         V4* dst = reinterpret_cast<V4*>(scoef);
         for (int i = threadIdx.x; i < NV; i += THREADS) dst[i] = src[i];
-        for (int i = threadIdx.x; i < Q * 64; i += THREADS) swr[i] = twg[((i >> 6) * (i & 63)) % N];
+        for (int i = threadIdx.x; i < Q * 64; i += THREADS) swr[i] = twk[NJ * 64 + i];
     }
     if (zero17 != nullptr && y == 0 && g == 0 && threadIdx.x < 17) zero17[threadIdx.x] = 0;
     cx<double> wjr[WJREG ? NJ : 1];
     if constexpr (WJREG) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) wjr[j] = twg[(((Q * (j + JMIN) * lane) % N) + N) % N];
+        for (int j = 0; j < NJ; ++j) wjr[j] = twk[j * 64 + lane];
     }
     __syncthreads();
     auto line = [&](int td, const cx<double>* xv) {
         const int task = td / ndir;
         const double r0m53 = tp[task].r0m53, delta = tp[task].inv_l0sq - kEps0;
         const double spv = sp[td];
-        double xr[kNX], xi[kNX];
+        cx<double> wl[WJREG ? 1 : NJ];
+        if constexpr (!WJREG) {
 #pragma unroll
-        for (int a = 0; a < kNX; ++a) {
-            xr[a] = xv[a].x;
-            xi[a] = xv[a].y;
+            for (int j = 0; j < NJ; ++j) wl[j] = twk[j * 64 + lane];
         }
-        double out[Q];
-        if (dbg & 2) {
-#pragma unroll
-            for (int k1 = 0; k1 < Q; ++k1) out[k1] = xr[k1 % kNX] + k1;
-        } else {
-            cx<double> wl[WJREG ? 1 : NJ];
-            if constexpr (!WJREG) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) wl[j] = twg[(((Q * (j + JMIN) * lane) % N) + N) % N];
-            }
-            const cx<double>* wjp = WJREG ? wjr : wl;
-            auto wrf = [&](int r) { return swr[r * 64 + lane]; };
-            if constexpr (Q == 2) {
-                cx<double> S[2];
-                fold_sums<Q, true, 0, 1, 2>(S, xr, xi, wjp, wrf);
-                out[0] = S[0].x + S[1].x;
-                out[1] = S[0].x - S[1].x;
-            } else if constexpr (Q >= 16) {
-                // the Q / 4 residues of one r1 at a time: 4 or 5 independent accumulator pairs
-                dftq_real_out<Q>(
-                    [&](auto r1c, cx<double>* v) {
-                        fold_sums<Q, true, decltype(r1c)::value, 4, Q / 4>(v, xr, xi, wjp, wrf);
-                    },
-                    out);
-            } else {
-                // Q = 4, 8: all sums first, four residues to a group
-                cx<double> S[Q];
-                static_for<0, Q / 4>([&](auto gc) {
-                    constexpr int R0 = decltype(gc)::value * 4;
-                    fold_sums<Q, true, R0, 1, 4>(S + R0, xr, xi, wjp, wrf);
-                });
-                dftq_real_out<Q>(
-                    [&](auto r1c, cx<double>* v) {
-#pragma unroll
-                        for (int r2 = 0; r2 < Q / 4; ++r2) v[r2] = S[4 * r2 + decltype(r1c)::value];
-                    },
-                    out);
-            }
-        }
-        if (dbg & 4) {
-            if (out[0] == 1.2345) D0t[td] = 0;
-            return;
-        }
-        RO* dst = D0t + ((size_t)td * H1 + y) * N + lane;
-        if constexpr (sizeof(RO) == 4) {
-            const float df = (float)delta, rf = (float)r0m53;
-#pragma unroll
-            for (int k1 = 0; k1 < Q; ++k1) {
-                const float4 h = *reinterpret_cast<const float4*>(scoef + (size_t)(64 * k1 + lane) * K);
-                const float dF = rf * fmaf(fmaf(fmaf(h.w, df, h.z), df, h.y), df, h.x);
-                dst[64 * k1] = (float)(fma(scale2, spv - out[k1], (double)dF));
-            }
-        } else {
-#pragma unroll
-            for (int k1 = 0; k1 < Q; ++k1) {
-                const double* h = scoef + (size_t)(64 * k1 + lane) * K;
-                double a = h[K - 1];
-#pragma unroll
-                for (int k = K - 2; k >= 0; --k) a = fma(a, delta, h[k]);
-                dst[64 * k1] = fma(scale2, spv - out[k1], r0m53 * a);
-            }
-        }
+        series_line<N, RO>(xv, WJREG ? wjr : wl, swr, scoef, r0m53, delta, spv, scale2,
+                           D0t + ((size_t)td * H1 + y) * N + lane,
+                           dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, lane, dbg);
     };
     constexpr int STEP = THREADS / 64;
     while (td < td_end) {
-        if (td + STEP < td_end && !(dbg & 1)) fetch(td + STEP, xvb);
+        if (td + STEP < td_end) fetch(td + STEP, xvb);
         line(td, xva);
         td += STEP;
         if (td >= td_end) break;
-        if (td + STEP < td_end && !(dbg & 1)) fetch(td + STEP, xva);
+        if (td + STEP < td_end) fetch(td + STEP, xva);
         line(td, xvb);
         td += STEP;
     }
@@ -535,7 +742,45 @@ __global__ void __launch_bounds__(256) k_series_coef(int n, int K, const double*
     for (int k = 0; k < K; ++k) coef[(size_t)i * K + k] = (RO)planes[(size_t)k * n + i];
 }
 
+// K_DMIN16: dlin[td][y][kb] (the per-line block minima of K_DPHI_SERIES) -> dblk[td][y / 16][kb], the
+// minima over the blocks of 16 lines x 32 columns, and dline[td][y], the minima per line (what K_DMIN
+// computes from D itself).
+__global__ void __launch_bounds__(128) k_dmin16(int H1, int nks, const float* __restrict__ dlin,
+                                                float* __restrict__ dline, float* __restrict__ dblk) {
+    const int mt = blockIdx.x, td = blockIdx.y, nmt = gridDim.x;
+    const int nline = min(16, H1 - 16 * mt);
+    const float* src = dlin + ((size_t)td * H1 + 16 * mt) * nks;
+    if ((int)threadIdx.x < nks) {
+        float m = __builtin_inff();
+        for (int i = 0; i < nline; ++i) m = fminf(m, src[i * nks + threadIdx.x]);
+        dblk[((size_t)td * nmt + mt) * nks + threadIdx.x] = m;
+    } else if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + nline) {
+        const int i = threadIdx.x - 64;
+        float m = __builtin_inff();
+        for (int kb = 0; kb < nks; ++kb) m = fminf(m, src[i * nks + kb]);
+        dline[(size_t)td * H1 + 16 * mt + i] = m;
+    }
+}
+
 }  // namespace
+
+void launch_dmin16(hipStream_t s, int N, int ntd, const float* d_dlin, float* d_dline, float* d_dblk) {
+    const int H1 = N / 2 + 1;
+    hipLaunchKernelGGL(k_dmin16, dim3((H1 + 15) / 16, ntd), dim3(128), 0, s, H1, N / 32, d_dlin, d_dline, d_dblk);
+}
+
+size_t series_twiddle_bytes(int N) {
+    size_t n = 0;
+    DISPATCH_N(N, { n = (size_t)(fold_nj<NN / 64>() + NN / 64) * 64 * sizeof(cx<double>); })
+    return n;
+}
+
+void launch_series_twiddles(hipStream_t s, int N, const void* d_tw64, void* d_twk) {
+    DISPATCH_N(N, {
+        hipLaunchKernelGGL((k_series_twiddles<NN>), dim3(fold_nj<NN / 64>() + NN / 64), dim3(64), 0, s,
+                           (const cx<double>*)d_tw64, (cx<double>*)d_twk);
+    })
+}
 
 int series_terms(bool f64) { return f64 ? SeriesCfg<double>::K : SeriesCfg<float>::K; }
 double series_eps0() { return kEps0; }
@@ -551,48 +796,58 @@ void launch_series_coef(hipStream_t s, int N, const double* d_planes, void* d_co
 }
 
 void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const double* d_aotab,
-                  double cfit, const void* d_tw64, double* d_P, void* d_T, double* d_sp, bool f64) {
+                  double cfit, const void* d_twk, double* d_P, void* d_T, double* d_sp, bool f64) {
     const dim3 ggrid((NAO * NAO + 255) / 256, ntd);
     if (f64)
         hipLaunchKernelGGL(k_patch_gen<true>, ggrid, dim3(256), 0, s, ndir, d_tp, d_aotab, cfit, d_P);
     else
         hipLaunchKernelGGL(k_patch_gen<false>, ggrid, dim3(256), 0, s, ndir, d_tp, d_aotab, cfit, d_P);
     DISPATCH_N(N, {
-        hipLaunchKernelGGL((k_patch_rows<NN>), dim3(NAO / kRowsPerWg, ntd), dim3(256), 0, s, (const double*)d_P,
-                           (const cx<double>*)d_tw64, (cx<double>*)d_T, d_sp);
+        hipLaunchKernelGGL((k_patch_rows<NN>), dim3(NAO / (4 * rows_per_wave<NN>()), ntd), dim3(256), 0, s, (const double*)d_P,
+                           (const cx<double>*)d_twk, (cx<double>*)d_T, d_sp);
     })
 }
 
 void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const void* d_T,
-                        const double* d_sp, const void* d_coef, const void* d_tw64, double scale2,
-                        void* d_D0t, bool f64out, int* d_zero) {
+                        const double* d_sp, const void* d_coef, const void* d_twk, double scale2,
+                        void* d_D0t, float* d_dlin, bool f64out, int* d_zero, int ncu) {
     const int H1 = N / 2 + 1;
-    // task groups: enough workgroups to fill the GPU several times over, but every workgroup's table
-    // load (the line's coefficients) shared by as many tasks as that allows
-    const int waves = (f64out ? SeriesCfg<double>::THREADS : SeriesCfg<float>::THREADS) / 64;
-    int ngr = (2048 + H1 - 1) / H1;
-    if (ngr * waves > ntd) ngr = (ntd + waves - 1) / waves;
-    if (ngr < 1) ngr = 1;
-    int tg = (ntd + ngr - 1) / ngr;
-    tg = (tg + waves - 1) / waves * waves;      // every wave of a workgroup the same number of lines
-    static const int env_tg = getenv("MPSFR_SERIES_TG") ? atoi(getenv("MPSFR_SERIES_TG")) : 0;   // experiments
-    if (env_tg > 0) tg = env_tg;
     static const int env_dbg = getenv("MPSFR_SERIES_DBG") ? atoi(getenv("MPSFR_SERIES_DBG")) : 0;    // experiments
-    ngr = (ntd + tg - 1) / tg;
-    const dim3 grid(H1, ngr);
+    static const int env_wg = getenv("MPSFR_SERIES_WG") ? atoi(getenv("MPSFR_SERIES_WG")) : 0;
+    auto first_form = [&](auto kernel, size_t sm) {
+        // task groups: enough workgroups to fill the GPU several times over, every workgroup's table load
+        // shared by as many tasks as that allows, every wave of a workgroup the same number of lines
+        const int waves = 4;
+        int ngr = (2048 + H1 - 1) / H1;
+        if (ngr * waves > ntd) ngr = (ntd + waves - 1) / waves;
+        if (ngr < 1) ngr = 1;
+        int tg = (ntd + ngr - 1) / ngr;
+        tg = (tg + waves - 1) / waves * waves;
+        ngr = (ntd + tg - 1) / tg;
+        return std::make_pair(dim3(H1, ngr), tg);
+    };
     DISPATCH_N(N, {
         if (f64out) {
-            constexpr size_t sm = series_smem<NN, double>();
-            allow_smem((k_dphi_series<NN, double>), sm);
-            hipLaunchKernelGGL((k_dphi_series<NN, double>), grid, dim3(SeriesCfg<double>::THREADS), sm, s,
-                               (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, tg, (const double*)d_coef,
-                               (const cx<double>*)d_tw64, scale2, (double*)d_D0t, d_zero, env_dbg);
+            if constexpr (series_fits<NN, double>()) {
+                constexpr size_t sm = series_smem<NN, double>();
+                allow_smem((k_dphi_series<NN, double>), sm);
+                hipLaunchKernelGGL((k_dphi_series<NN, double>), dim3(env_wg > 0 ? env_wg : ncu), dim3(series_threads<NN, double>()), sm, s,
+                                   (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, (const double*)d_coef,
+                                   (const cx<double>*)d_twk, scale2, (double*)d_D0t, d_dlin, d_zero, env_dbg);
+            } else {
+                constexpr size_t sm = series1_smem<NN, double>();
+                allow_smem((k_dphi_series1<NN, double>), sm);
+                const auto gt = first_form(0, sm);
+                hipLaunchKernelGGL((k_dphi_series1<NN, double>), gt.first, dim3(256), sm, s,
+                                   (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, gt.second, (const double*)d_coef,
+                                   (const cx<double>*)d_twk, scale2, (double*)d_D0t, d_dlin, d_zero, env_dbg);
+            }
         } else {
             constexpr size_t sm = series_smem<NN, float>();
             allow_smem((k_dphi_series<NN, float>), sm);
-            hipLaunchKernelGGL((k_dphi_series<NN, float>), grid, dim3(SeriesCfg<float>::THREADS), sm, s,
-                               (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, tg, (const float*)d_coef,
-                               (const cx<double>*)d_tw64, scale2, (float*)d_D0t, d_zero, env_dbg);
+            hipLaunchKernelGGL((k_dphi_series<NN, float>), dim3(env_wg > 0 ? env_wg : ncu), dim3(series_threads<NN, float>()), sm, s,
+                               (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, (const float*)d_coef,
+                               (const cx<double>*)d_twk, scale2, (float*)d_D0t, d_dlin, d_zero, env_dbg);
         }
     })
 }
