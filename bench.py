@@ -458,8 +458,10 @@ def main():
         if a.prune_eps >= 0 and precision == 'mixed':
             c.set_option('prune_eps', a.prune_eps)
 
-    # ---- what a caller of compute_psf_from_sparta gets: one synchronous call per step, the fit
-    # table and the stamp sum copied to (pageable) host memory -- PCIe inclusive, never `value`
+    # ---- what a caller of compute_psf_from_sparta gets: the fit table and the stamp sum in (pageable)
+    # host memory -- PCIe inclusive, never `value`.  Asynchronous host-output calls (on_device = 2), two
+    # in flight: the results of call k are collected while call k + 1 runs, like the passes of a table
+    # larger than one call; `sync` beside it is the blocking call, one at a time.
     host_leg = None
     nhost = (min(a.steps, 50) if a.host_steps < 0 else a.host_steps) if world == 1 else 0
     if nhost > 0:
@@ -469,14 +471,33 @@ def main():
             c.reconstruct(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, want_psf=False)
         t0 = time.perf_counter()
         for _ in range(nhost):
-            rh = c.reconstruct(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, want_psf=False)
+            rs = c.reconstruct(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, want_psf=False)
+        dts = time.perf_counter() - t0
+        nh2 = 4 * nhost
+        pend = []
+        for _ in range(8):
+            pend.append(c.reconstruct_async(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, want_psf=False))
+            if len(pend) > 2:
+                pend.pop(0).wait()
+        while pend:
+            pend.pop(0).wait()
+        t0 = time.perf_counter()
+        for _ in range(nh2):
+            pend.append(c.reconstruct_async(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, want_psf=False))
+            if len(pend) > 2:
+                rh = pend.pop(0).wait()
+        while pend:
+            rh = pend.pop(0).wait()
         dth = time.perf_counter() - t0
         c.close()
-        host_leg = {'value': round(rows * nl * nhost / dth, 1), 'unit': 'PSFs/sec', 'steps': nhost,
-                    'ms_per_call': round(dth / nhost * 1e3, 4),
+        host_leg = {'value': round(rows * nl * nh2 / dth, 1), 'unit': 'PSFs/sec', 'steps': nh2,
+                    'ms_per_call': round(dth / nh2 * 1e3, 4), 'calls_in_flight': 2,
                     'outputs': 'fit table [rows][nl][16] + stamp sum [nl][40][40] (float64) in host memory, '
-                               'call synchronous: what compute_psf_from_sparta hands back (psfrec.py:978, '
-                               '1104-1113)'}
+                               'asynchronous host-output calls (on_device = 2), results collected one call behind: '
+                               'what compute_psf_from_sparta hands back (psfrec.py:978, 1104-1113)',
+                    'sync': {'value': round(rows * nl * nhost / dts, 1), 'ms_per_call': round(dts / nhost * 1e3, 4),
+                             'steps': nhost, 'note': 'blocking calls (on_device = 0), one at a time'},
+                    'async_equals_sync': bool(np.array_equal(rh['fit'], rs['fit']) and np.array_equal(rh['psf_sum'], rs['psf_sum']))}
         if cpu_fits is not None:
             n = cpu_fits.shape[0]
             host_leg['parity'] = {'rows_checked': n,

@@ -120,9 +120,15 @@ int mpsfr_set_option(mpsfr_ctx* ctx, const char* key, double value);
  * psf_sum_out    : [nl][dimpsf][dimpsf] sum over the ntask stamps (the caller divides by the
  *                  global task count to get PSF_MEAN, psfrec.py:1104), or NULL
  * fit_out        : [ntask][nl][MPSFR_NFIT] Moffat fit of every stamp, or NULL
- * on_device      : 0 = the three outputs are host pointers; 1 = device pointers on this
- *                  context's device (results complete after mpsfr_sync)
- * All outputs are float64.  The call is asynchronous when on_device = 1. */
+ * on_device      : 0 = the three outputs are host pointers, the call returns with the results;
+ *                  1 = device pointers on this context's device (results complete after mpsfr_sync);
+ *                  2 = host pointers, asynchronous: the call returns once its work is queued (like
+ *                  on_device = 1 it takes its turn on the pipeline lanes, so consecutive calls
+ *                  overlap), the results travel to a pinned staging set of the library and reach the
+ *                  caller's arrays in mpsfr_wait(ctx, mpsfr_last_ticket(ctx)) -- or in mpsfr_sync, or
+ *                  when the fourth asynchronous call after this one is made (the ring of staging
+ *                  sets has four); the arrays must stay allocated until then
+ * All outputs are float64.  The call is asynchronous when on_device != 0. */
 int mpsfr_reconstruct(mpsfr_ctx* ctx, int ntask, const double* seeing, const double* gl,
                       const double* l0, const uint8_t* three_lgs, const double h[2],
                       double wind_speed, int npsflin, int nl, const double* lbda_nm,
@@ -148,8 +154,18 @@ int mpsfr_reconstruct_multi(mpsfr_ctx* const* ctxs, int nctx, int ntask, const d
 int mpsfr_fit_stamps(mpsfr_ctx* ctx, int nstamp, const double* stamps, double* fit_out,
                      int on_device);
 
-/* Block until every call made so far has finished. */
+/* Block until every call made so far has finished (and hand over the results of every
+ * asynchronous host-output call). */
 int mpsfr_sync(mpsfr_ctx* ctx);
+
+/* Asynchronous host outputs (on_device = 2).  mpsfr_last_ticket: the ticket (0, 1, 2, ...) of the most
+ * recent such call of the context, -1 before the first.  mpsfr_wait: block until the call with that
+ * ticket has finished and copy its results (and those of every earlier ticket not yet handed over)
+ * into the arrays it was given.  This is how the rows of a table larger than one call are kept in
+ * flight (the reference: Parallel(...)(delayed(compute_psf) ...), psfrec.py:1082-1083, results
+ * collected at :1086-1113). */
+long mpsfr_last_ticket(mpsfr_ctx* ctx);
+int mpsfr_wait(mpsfr_ctx* ctx, long ticket);
 
 /* The context's hipStream_t (as void*): it is ordered after every asynchronous (on_device = 1)
  * call made so far, so a caller can queue its own GPU work behind the results without a host
@@ -175,8 +191,9 @@ int mpsfr_host_time(mpsfr_ctx* ctx, double* seconds, long* calls);
  *   "pre"        [chunk tasks][nl][dimpsf][dimpsf] stamps before the convolutions (psfrec.py:685)
  *   "vkeep"      [chunk tasks][(nl+1)/2] lines of the half plane transformed per wavelength pair
  *                (option "prune_eps")
- *   "mf_work"    [3] matrix-core stage, last chunk: tile steps executed, m-tiles with a second
- *                pass, tile steps without pruning
+ *   "mf_work"    [5] (the first 3 if capacity < 5) matrix-core stage, last chunk: tile steps executed,
+ *                m-tiles with a second pass, tile steps without pruning, tile steps with all three
+ *                products, tile steps without the low half of the OTF
  * Returns the number of doubles written (<= capacity) or a negative error. */
 long mpsfr_debug_fetch(mpsfr_ctx* ctx, const char* what, double* out, size_t capacity);
 

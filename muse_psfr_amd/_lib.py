@@ -71,6 +71,10 @@ def load():
     lib.mpsfr_fit_stamps.restype = C.c_int
     lib.mpsfr_sync.argtypes = [p]
     lib.mpsfr_sync.restype = C.c_int
+    lib.mpsfr_last_ticket.argtypes = [p]
+    lib.mpsfr_last_ticket.restype = C.c_long
+    lib.mpsfr_wait.argtypes = [p, C.c_long]
+    lib.mpsfr_wait.restype = C.c_int
     lib.mpsfr_stream.argtypes = [p]
     lib.mpsfr_stream.restype = C.c_void_p
     lib.mpsfr_wait_event.argtypes = [p, C.c_void_p]
@@ -98,7 +102,8 @@ def load():
 
 
 EXPORTS = ['mpsfr_create', 'mpsfr_destroy', 'mpsfr_last_error', 'mpsfr_set_option',
-           'mpsfr_reconstruct', 'mpsfr_reconstruct_multi', 'mpsfr_fit_stamps', 'mpsfr_sync', 'mpsfr_stream', 'mpsfr_wait_event',
+           'mpsfr_reconstruct', 'mpsfr_reconstruct_multi', 'mpsfr_fit_stamps', 'mpsfr_sync', 'mpsfr_last_ticket', 'mpsfr_wait',
+           'mpsfr_stream', 'mpsfr_wait_event',
            'mpsfr_host_time', 'mpsfr_debug_fetch',
            'mpsfr_profile_count', 'mpsfr_profile_name', 'mpsfr_profile_get',
            'mpsfr_profile_reset', 'mpsfr_version', 'mpsfr_build_id', 'mpsfr_device_count']
@@ -164,8 +169,14 @@ class Context:
         """hipStream_t of the context as an integer (for torch.cuda.ExternalStream)."""
         return int(self.lib.mpsfr_stream(self._h) or 0)
 
+    def reconstruct_async(self, *args, **kwargs):
+        """`reconstruct` without waiting for the GPU (on_device = 2): returns a PendingResult whose
+        .wait() blocks until the call has finished and returns the same dict.  Up to four such calls
+        are in flight per context, overlapping on the pipeline lanes; they complete in order."""
+        return self.reconstruct(*args, _async=True, **kwargs)
+
     def reconstruct(self, lbda, seeing, gl, l0, three_lgs=None, h=(100, 10000), wind_speed=None,
-                    npsflin=1, masks=None, want_psf=True, want_sum=True, want_fit=True):
+                    npsflin=1, masks=None, want_psf=True, want_sum=True, want_fit=True, _async=False):
         """Host-buffer call.  Returns dict(psf, psf_sum, fit) of float64 arrays (or None)."""
         seeing = np.ascontiguousarray(np.atleast_1d(seeing), dtype=np.float64)
         gl = np.ascontiguousarray(np.atleast_1d(gl), dtype=np.float64)
@@ -192,7 +203,9 @@ class Context:
         _check(self.lib.mpsfr_reconstruct(
             self._h, nt, _dptr(seeing), _dptr(gl), _dptr(l0), _u8ptr(three), _dptr(hh),
             float(wind_speed), int(npsflin), nl, _dptr(lbda), _u8ptr(mrec), _u8ptr(mres),
-            vp(psf), vp(psum), vp(fit), 0))
+            vp(psf), vp(psum), vp(fit), 2 if _async else 0))
+        if _async:
+            return PendingResult(self, int(self.lib.mpsfr_last_ticket(self._h)), dict(psf=psf, psf_sum=psum, fit=fit))
         return dict(psf=psf, psf_sum=psum, fit=fit)
 
     @staticmethod
@@ -280,6 +293,20 @@ class Context:
 
     def profile_reset(self):
         _check(self.lib.mpsfr_profile_reset(self._h))
+
+
+class PendingResult:
+    """An asynchronous host-output call (Context.reconstruct_async): the arrays of `wait()` are filled
+    by the library when the ticket is waited for."""
+
+    def __init__(self, ctx, ticket, arrays):
+        self.ctx, self.ticket, self._arrays, self._done = ctx, ticket, arrays, False
+
+    def wait(self):
+        if not self._done:
+            _check(self.ctx.lib.mpsfr_wait(self.ctx._h, self.ticket))
+            self._done = True
+        return self._arrays
 
 
 class ContextPool:

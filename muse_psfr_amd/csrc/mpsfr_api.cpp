@@ -137,6 +137,23 @@ struct mpsfr_ctx {
     };
     Slot slot[NSTAGE];
     unsigned stage_next = 0;
+    // Asynchronous host outputs (on_device = 2): a ring of result sets -- device buffers the call
+    // writes, a pinned host mirror the join stream copies them to -- and the caller's arrays, filled
+    // when the ticket is waited for.  The host queues up to NTICKET such calls ahead of the GPU and the
+    // calls rotate over the lanes like device-output calls do.
+    struct Ticket {
+        long id = -1;
+        bool pending = false;
+        hipEvent_t done = nullptr;
+        DevBuf dpsf, dsum, dfit;
+        void* host = nullptr;
+        size_t host_cap = 0;
+        double *u_psf = nullptr, *u_sum = nullptr, *u_fit = nullptr;
+        size_t n_psf = 0, n_sum = 0, n_fit = 0;
+    };
+    static constexpr int NTICKET = 4;
+    Ticket ticket[NTICKET];
+    long ticket_next = 0;                // id of the next asynchronous host-output call
     double host_seconds = 0.0;           // wall time spent inside mpsfr_reconstruct
     long host_calls = 0;
     // caches of the per-call tables that only depend on (lbda) / (geometry, masks)
@@ -188,6 +205,18 @@ void release(DevBuf& b) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
+}
+
+// wait for an asynchronous host-output call and hand its results to the caller's arrays
+int complete_ticket(mpsfr_ctx* c, mpsfr_ctx::Ticket& tk) {
+    if (!tk.pending) return MPSFR_OK;
+    HIPCHK(hipEventSynchronize(tk.done));
+    const double* h = (const double*)tk.host;
+    if (tk.u_psf) memcpy(tk.u_psf, h, tk.n_psf * sizeof(double));
+    if (tk.u_sum) memcpy(tk.u_sum, h + tk.n_psf, tk.n_sum * sizeof(double));
+    if (tk.u_fit) memcpy(tk.u_fit, h + tk.n_psf + tk.n_sum, tk.n_fit * sizeof(double));
+    tk.pending = false;
+    return MPSFR_OK;
 }
 
 hipEvent_t get_event(mpsfr_ctx* c) {
@@ -488,6 +517,14 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         release(sl.params);
         release(sl.ktt);
     }
+    for (int k = 0; k < mpsfr_ctx::NTICKET; ++k) {
+        mpsfr_ctx::Ticket& tk = c->ticket[k];
+        if (tk.done) (void)hipEventDestroy(tk.done);
+        if (tk.host) (void)hipHostFree(tk.host);
+        release(tk.dpsf);
+        release(tk.dsum);
+        release(tk.dfit);
+    }
     DevBuf* all[] = {&c->scoef, &c->stwk, &c->tw64, &c->tel, &c->rows, &c->tlmax, &c->tl2, &c->tlb, &c->aotab, &c->samp_p,
                      &c->samp_a, &c->G, &c->xtab, &c->etab, &c->gtab, &c->kmuse, &c->fit, &c->sum,
                      &c->stage, &c->lsum, &c->mfclk};
@@ -561,6 +598,30 @@ int mpsfr_sync(mpsfr_ctx* c) {
     for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
         if (c->lane[k].stream) HIPCHK(hipStreamSynchronize(c->lane[k].stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (long t = c->ticket_next - mpsfr_ctx::NTICKET; t < c->ticket_next; ++t)
+        if (t >= 0) {
+            mpsfr_ctx::Ticket& tk = c->ticket[t % mpsfr_ctx::NTICKET];
+            const int rc = tk.id == t ? complete_ticket(c, tk) : MPSFR_OK;
+            if (rc) return rc;
+        }
+    return MPSFR_OK;
+}
+
+long mpsfr_last_ticket(mpsfr_ctx* c) { return c ? c->ticket_next - 1 : -1; }
+
+int mpsfr_wait(mpsfr_ctx* c, long ticket) {
+    if (!c) return fail(MPSFR_E_INVALID, "ctx is NULL");
+    if (ticket < 0 || ticket >= c->ticket_next) return fail(MPSFR_E_INVALID, "ticket %ld was never issued", ticket);
+    HIPCHK(hipSetDevice(c->device));
+    // tickets complete in order (a later call's results never reach the caller before an earlier one's)
+    long first = ticket - mpsfr_ctx::NTICKET + 1;
+    if (first < 0) first = 0;
+    for (long t = first; t <= ticket; ++t) {
+        mpsfr_ctx::Ticket& tk = c->ticket[t % mpsfr_ctx::NTICKET];
+        if (tk.id != t) continue;            // already completed and its slot reused
+        const int rc = complete_ticket(c, tk);
+        if (rc) return rc;
+    }
     return MPSFR_OK;
 }
 
@@ -589,6 +650,11 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
     const int rc = reconstruct_impl(c, ntask, seeing, gl, l0, three_lgs, h, wind_speed, npsflin, nl, lbda_nm,
                                     mask_rec, mask_res, psf_out, psf_sum_out, fit_out, on_device);
     if (rc != MPSFR_OK) {
+        // whatever the failed call has queued (it may have cleared a slot's guard and started chunks
+        // on other lanes) must have drained before the next call reuses the slot and the workspaces
+        for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
+            if (c->lane[k].stream) (void)hipStreamSynchronize(c->lane[k].stream);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
         c->lane_rr = lane_rr0;
         c->stage_next = stage0;
         c->wait_next = nullptr;
@@ -676,6 +742,36 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     for (int d = 0; d < ndir; ++d) {
         g.dir[0][d] = (double)(d / npsflin - npsflin / 2) * 60 / 2 / 60;
         g.dir[1][d] = (double)(d % npsflin - npsflin / 2) * 60 / 2 / 60;
+    }
+
+    // ---- asynchronous host outputs: the call writes a result set of the ring and is, from here on, a
+    // device-output call; the join stream then copies the set to its pinned mirror
+    mpsfr_ctx::Ticket* tk = nullptr;
+    if (on_device == 2) {
+        tk = &c->ticket[c->ticket_next % mpsfr_ctx::NTICKET];
+        if ((rc = complete_ticket(c, *tk))) return rc;         // NTICKET calls ago: hand it over first
+        tk->u_psf = psf_out;
+        tk->u_sum = psf_sum_out;
+        tk->u_fit = fit_out;
+        tk->n_psf = psf_out ? (size_t)ntask * nl * NS * NS : 0;
+        tk->n_sum = psf_sum_out ? (size_t)nl * NS * NS : 0;
+        tk->n_fit = fit_out ? (size_t)ntask * nl * NFIT : 0;
+        const size_t hb = (tk->n_psf + tk->n_sum + tk->n_fit) * sizeof(double);
+        if (hb > tk->host_cap) {
+            if (tk->host) HIPCHK(hipHostFree(tk->host));
+            tk->host = nullptr;
+            tk->host_cap = 0;
+            HIPCHK(hipHostMalloc(&tk->host, hb + hb / 8, hipHostMallocDefault));
+            tk->host_cap = hb + hb / 8;
+        }
+        if (tk->n_psf && (rc = ensure(c, tk->dpsf, tk->n_psf * sizeof(double)))) return rc;
+        if (tk->n_sum && (rc = ensure(c, tk->dsum, tk->n_sum * sizeof(double)))) return rc;
+        if (tk->n_fit && (rc = ensure(c, tk->dfit, tk->n_fit * sizeof(double)))) return rc;
+        if (!tk->done) HIPCHK(hipEventCreateWithFlags(&tk->done, hipEventDisableTiming));
+        psf_out = tk->n_psf ? (double*)tk->dpsf.p : nullptr;
+        psf_sum_out = tk->n_sum ? (double*)tk->dsum.p : nullptr;
+        fit_out = tk->n_fit ? (double*)tk->dfit.p : nullptr;
+        on_device = 1;
     }
 
     // ---- chunking and lanes
@@ -1120,6 +1216,16 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     c->last_thr_blk = thr_blk;
     c->last_lpc.resize(nl);
     for (int l = 0; l < nl; ++l) c->last_lpc[l] = lp[l].c;
+    if (tk) {
+        double* h = (double*)tk->host;
+        if (tk->n_psf) HIPCHK(hipMemcpyAsync(h, tk->dpsf.p, tk->n_psf * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (tk->n_sum) HIPCHK(hipMemcpyAsync(h + tk->n_psf, tk->dsum.p, tk->n_sum * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (tk->n_fit)
+            HIPCHK(hipMemcpyAsync(h + tk->n_psf + tk->n_sum, tk->dfit.p, tk->n_fit * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(tk->done, s));
+        tk->id = c->ticket_next++;
+        tk->pending = true;
+    }
     if (!dev_out) {
         if (fit_out)
             HIPCHK(hipMemcpyAsync(fit_out, d_fit_all, (size_t)ntask * nl * NFIT * sizeof(double),

@@ -267,3 +267,42 @@ def test_reconstruct_multi_in_the_library(api):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_asynchronous_host_outputs_equal_the_blocking_call(api):
+    """on_device = 2 (Context.reconstruct_async): several calls in flight -- more than the ring of four
+    staging sets holds, so that the library hands the oldest over by itself -- give, bit for bit, what
+    the blocking call gives; tickets complete in order; mpsfr_sync hands everything over; a ticket that
+    was never issued is an error; a failing call leaves the ring as it found it."""
+    from muse_psfr_amd._lib import Context, MpsfrError
+    lb = np.linspace(480, 920, 7)
+    ps = api.grid_pixscale(256)
+    sets = [api.synthetic_rows(9 + 3 * k, seed=100 + k) for k in range(7)]
+    ctx = Context(dim=256, pixscale=ps, precision='mixed', device=0)
+    try:
+        want = [ctx.reconstruct(lb, s, g, l, None, (100, 10000)) for (s, g, l) in sets]
+        pend = [ctx.reconstruct_async(lb, s, g, l, None, (100, 10000)) for (s, g, l) in sets]
+        assert [p.ticket for p in pend] == list(range(7))
+        got_last = pend[-1].wait()              # completes every earlier ticket too
+        for p, w in zip(pend, want):
+            r = p.wait()
+            for k in ('psf', 'psf_sum', 'fit'):
+                np.testing.assert_array_equal(r[k], w[k])
+        np.testing.assert_array_equal(got_last['fit'], want[-1]['fit'])
+        # mpsfr_sync hands the pending results over
+        p1 = ctx.reconstruct_async(lb, *sets[0], None, (100, 10000), want_psf=False)
+        p2 = ctx.reconstruct_async(lb, *sets[1], None, (100, 10000), want_psf=False)
+        ctx.sync()
+        np.testing.assert_array_equal(p1._arrays['fit'], want[0]['fit'])
+        np.testing.assert_array_equal(p2._arrays['psf_sum'], want[1]['psf_sum'])
+        assert p2._arrays['psf'] is None
+        from muse_psfr_amd._lib import _check
+        with pytest.raises(MpsfrError):
+            _check(ctx.lib.mpsfr_wait(ctx._h, 99))
+        with pytest.raises(MpsfrError):          # grid too small for 100 nm: the call fails ...
+            ctx.reconstruct_async(np.array([100.0]), *sets[0], None, (100, 10000))
+        p3 = ctx.reconstruct_async(lb, *sets[2], None, (100, 10000))     # ... and the next ticket is the next number
+        assert p3.ticket == p2.ticket + 1
+        np.testing.assert_array_equal(p3.wait()['fit'], want[2]['fit'])
+    finally:
+        ctx.close()
