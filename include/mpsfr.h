@@ -91,8 +91,8 @@ const char* mpsfr_last_error(void);
  * waits once for the first lane's column transforms / per-wavelength preparation, so that the two
  * lanes do not start in step: +3 % in a sustained run of 100-row calls, -1 % on a burst of 20;
  * results do not depend on it).
- * Experiment switches of the matrix-core stage (results do not depend on them beyond the last
- * bits of the fp16 representation floor): "mf_kernel" (2 = thin-wave kernel with precision tiers
+ * Experiment switches of the matrix-core stage (results depend on them below 3e-7 of a stamp's
+ * peak: the precision tiers are approximations of the size of the block pruning): "mf_kernel" (2 = thin-wave kernel with precision tiers
  * for one direction, 1 = the blocked kernel that several directions always use), "mf_permax"
  * (1..7 wavelengths per workgroup, default 6), "mf_floor" (default 1: blocks below the fp16
  * representation floor are skipped), "mf_mid_log2" (default -18.01: blocks below 2^this of the

@@ -70,7 +70,8 @@ def main(args=None):
     add('--verbose', '-v', action='store_true', help='verbose flag')
     add('--no-color', action='store_true', help='no color in output')
     add('--plot', action='store_true', help='plot reconstructed psf')
-    add('--device', default=0, type=int, help='GPU index')
+    add('--device', default=None, type=int, help='GPU index (default: device 0 for a single PSF; a SPARTA\n'
+        'table fans out over the visible GPUs)')
     add('--version', action='version', version='%(prog)s ' + __version__)
     opt = parser.parse_args(args)
 

@@ -1256,8 +1256,10 @@ int mpsfr_reconstruct_multi(mpsfr_ctx* const* ctxs, int nctx, int ntask, const d
                                  lbda_nm, mask_rec, mask_res, psf_out, psf_sum_out, fit_out, 0);
     const size_t per_stamp = (size_t)ctxs[0]->dimpsf * ctxs[0]->dimpsf;
     for (int k = 1; k < nctx; ++k)
-        if (ctxs[k]->dimpsf != ctxs[0]->dimpsf || ctxs[k]->N != ctxs[0]->N)
-            return fail(MPSFR_E_INVALID, "the contexts must share dim and dimpsf");
+        if (ctxs[k]->dimpsf != ctxs[0]->dimpsf || ctxs[k]->N != ctxs[0]->N || ctxs[k]->prec != ctxs[0]->prec ||
+            ctxs[k]->pixscale != ctxs[0]->pixscale)
+            return fail(MPSFR_E_INVALID, "the contexts must share dim, dimpsf, pixscale and precision "
+                                         "(context %d differs from context 0)", k);
     // contiguous, balanced shards: the first ntask % nctx contexts get one row more
     std::vector<int> start(nctx + 1, 0);
     for (int k = 0; k < nctx; ++k) start[k + 1] = start[k] + ntask / nctx + (k < ntask % nctx ? 1 : 0);

@@ -9,13 +9,18 @@
 //  * Precision tiers per block of 16 lines x 32 columns, decided from the same bound as the block
 //    pruning (every element of the block is below 2^(c' dmin + log2 telmax)):
 //      - below 2^-29 of OTF[0][0] both fp16 halves of every element are subnormal (the OTF is
-//        generated times 2^15) and the matrix cores flush them: the block contributes exactly
-//        nothing and is dropped;
-//      - below 2^-18 the LOW half of every element is subnormal: its product with the table is
-//        exactly zero, so the block needs two of the three products and no low half ("mid" blocks:
-//        6 MFMA and 16 vector instructions per tile step instead of 9 and 28);
+//        generated times 2^15): the block is dropped;
+//      - below 2^-18 the LOW half of every element is subnormal: the block runs two of the three
+//        products and no low half ("mid" blocks: 6 MFMA and 16 vector instructions per tile step
+//        instead of 9 and 28);
 //      - above, the full three products.
-//    All three are bit-for-bit what the full products would give.
+//    Round 3 took the first two for bit-neutral ("the matrix cores flush fp16 subnormals").  They are
+//    not: the gfx950 matrix cores multiply subnormal fp16 inputs like any other, so the tiers are
+//    approximations of the same kind as the block pruning, and as small -- what a tier leaves out is
+//    below 2^-29 (2^-18 x 2^-11) of the largest OTF element per element: measured against a run
+//    without the tier, no stamp pixel moves by more than 2e-7 of its peak and beta by 1.2e-6
+//    (tests/test_gpu_parity.py::test_precision_tiers_of_the_matrix_core_stage holds them to 3e-7 of
+//    the peak, the bound of the block pruning).
 //  * The masks (which blocks a wavelength keeps, in which tier; which blocks a wavelength group
 //    stages) are computed once per (task, wavelength) by K_MF_PREP instead of by every wave, and
 //    the group's staging mask is the exact union of its members (no assumption on the order of

@@ -136,24 +136,30 @@ FANOUT_MIN_TASKS_PER_DEVICE = 32
 
 
 def _fanout_devices(devices, device, ntask, n_jobs):
-    """The devices a batch of `ntask` tasks runs on.  devices=None: every visible GPU when the
-    batch is large enough and the caller did not ask for one job (n_jobs = 1; n_jobs > 1 caps the
-    number of devices, like it caps the reference's worker processes, psfrec.py:1082); an explicit
-    list is taken as given (repeats allowed: several contexts on one GPU)."""
+    """The devices a batch of `ntask` tasks runs on.  An explicit list `devices` is taken as given
+    (repeats allowed: several contexts on one GPU).  An explicit `device` is that device and nothing
+    else.  Both left at None: every visible GPU when the batch is large enough and the caller did not
+    ask for one job (n_jobs = 1; n_jobs > 1 caps the number of devices, like it caps the reference's
+    worker processes, psfrec.py:1082) -- unless the process is one rank of a one-rank-per-GPU launch
+    (WORLD_SIZE / LOCAL_RANK set, distributed.py): a rank stays on its own device, LOCAL_RANK."""
     if devices is not None:
         devs = [int(d) for d in devices]
         if not devs:
             raise ValueError('devices must not be empty')
         return devs
-    if n_jobs == 1:
+    if device is not None:
         return [int(device)]
+    if 'WORLD_SIZE' in os.environ or 'LOCAL_RANK' in os.environ:
+        return [int(os.environ.get('LOCAL_RANK', 0))]
+    if n_jobs == 1:
+        return [0]
     from ._lib import device_count
     n = device_count()
     if n_jobs is not None and n_jobs > 1:
         n = min(n, int(n_jobs))
     n = min(n, ntask // FANOUT_MIN_TASKS_PER_DEVICE)
     if n <= 1:
-        return [int(device)]
+        return [0]
     return list(range(n))
 
 
@@ -177,14 +183,18 @@ def _reconstruct(lbda, tasks, npsflin, h, dim, dimpsf, pixscale, precision, cuto
                                masks=masks, want_psf=want_psf)
     try:
         if len(devs) == 1:
-            return run(devs[0], 0, 0, see.size)
+            res = run(devs[0], 0, 0, see.size)
+            res['devices'] = devs
+            return res
         # Row shards over the devices, one context per device and one host thread each inside the
         # library (mpsfr_reconstruct_multi): the reference's joblib fan-out (psfrec.py:1082-1083).
         # Per-task results do not depend on the sharding; the stamp sums are added in device order.
         replica = [devs[:i].count(d) for i, d in enumerate(devs)]
         ctxs = [get_context(dim, pixscale, dimpsf, precision, d, r) for d, r in zip(devs, replica)]
-        return Context.reconstruct_multi(ctxs, lbda, see, gl, l0, three, h, npsflin=npsflin, masks=masks,
-                                         want_psf=want_psf)
+        res = Context.reconstruct_multi(ctxs, lbda, see, gl, l0, three, h, npsflin=npsflin, masks=masks,
+                                        want_psf=want_psf)
+        res['devices'] = devs
+        return res
     except MpsfrError as e:
         if e.code == E_GRID:
             # the reference fails here with a ValueError from scipy's interpn (psfrec.py:663-683)
@@ -271,16 +281,18 @@ def _table_hdu(cols, meta, name):
 def compute_psf_from_sparta(filename, extname='SPARTA_ATM_DATA', npsflin=1, lmin=490, lmax=930,
                             nl=35, lbda=None, h=(100, 10000), n_jobs=-1, plot=False,
                             mean_of_lgs=True, verbose=True, *, dim=1280, dimpsf=40, pixscale=0.2,
-                            precision='mixed', cutoff_masks='host', device=0, devices=None):
+                            precision='mixed', cutoff_masks='host', device=None, devices=None):
     """Reconstruct a PSF from SPARTA data (psfrec.py:981-1120).
 
     ``filename`` is a FITS path or an already opened HDUList.  Returns an HDUList with
     PRIMARY, a copy of the SPARTA extension, FIT_ROWS, FIT_MEAN and PSF_MEAN -- or ``None``
     (with a 'No valid values' warning) when no row has a valid laser.  The rows are processed as one
     GPU batch -- or, like the reference's ``n_jobs`` worker processes (psfrec.py:1082-1083), as one
-    batch per GPU: ``devices=None`` takes every visible GPU when the table has at least
-    FANOUT_MIN_TASKS_PER_DEVICE tasks per device (``n_jobs`` = 1 keeps one device, ``n_jobs`` > 1 caps
-    their number); ``devices=[...]`` names them.  The per-row results do not depend on the split."""
+    batch per GPU: with ``device`` and ``devices`` both None every visible GPU is taken when the table
+    has at least FANOUT_MIN_TASKS_PER_DEVICE tasks per device (``n_jobs`` = 1 keeps one device,
+    ``n_jobs`` > 1 caps their number; a rank of a one-process-per-GPU launch keeps its own);
+    ``device=k`` names the one device to use, ``devices=[...]`` several.  The per-row results do not
+    depend on the split."""
     fits, _ = _astropy()
     io_mod = fits if fits is not None else _minifits
     opened = False
@@ -363,7 +375,7 @@ def compute_psf_from_sparta(filename, extname='SPARTA_ATM_DATA', npsflin=1, lmin
 
     # mean PSF over the tasks and its fit (psfrec.py:1104-1113)
     psftot = r['psf_sum'] / ntask
-    ctx = get_context(dim, pixscale, dimpsf, precision, device)
+    ctx = get_context(dim, pixscale, dimpsf, precision, r.get('devices', [device or 0])[0])
     mcols = _fit_columns(lbda, ctx.fit_stamps(psftot), pixscale)
     seeing, GL, L0 = np.median(stats, axis=0)
     out.append(_table_hdu(mcols, {'SEEING': float(seeing), 'GL': float(GL), 'L0': float(L0)},

@@ -238,8 +238,8 @@ def test_fan_out_over_devices_matches_one_context(api, ref_masks):
     np.testing.assert_allclose(np.asarray(two['FIT_MEAN'].data['n']), np.asarray(one['FIT_MEAN'].data['n']), rtol=1e-9)
     assert len(three['FIT_ROWS'].data) == (37 * 4 - 1) * 4
     # the automatic choice: one visible GPU, or n_jobs = 1, keeps one device
-    assert psfrec._fanout_devices(None, 0, 1000, 1) == [0]
-    assert psfrec._fanout_devices(None, 0, 10, -1) == [0]
+    assert psfrec._fanout_devices(None, None, 1000, 1) == [0]
+    assert psfrec._fanout_devices(None, None, 10, -1) == [0]
     assert psfrec._fanout_devices([1, 1], 0, 3, -1) == [1, 1]
 
 
@@ -264,6 +264,16 @@ def test_reconstruct_multi_in_the_library(api):
         with pytest.raises(MpsfrError) as e:       # 100 nm needs a crop far beyond the grid
             Context.reconstruct_multi(ctxs, np.array([100.0, 700.0]), see, gl, l0, three, (100, 10000))
         assert 'context' in str(e.value) and 'crop' in str(e.value)
+        # contexts that would give an inconsistent table are refused: another precision, another pixel scale
+        odd = [Context(dim=256, pixscale=ps, precision='f64', device=0), Context(dim=256, pixscale=1.1 * ps, device=0)]
+        try:
+            for o in odd:
+                with pytest.raises(MpsfrError) as e:
+                    Context.reconstruct_multi([ctxs[0], o], lb, see, gl, l0, three, (100, 10000))
+                assert 'share' in str(e.value)
+        finally:
+            for o in odd:
+                o.close()
     finally:
         for c in ctxs:
             c.close()

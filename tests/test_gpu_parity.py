@@ -701,6 +701,42 @@ def test_line_pruning_changes_nothing_above_its_bound(api, dim, npl):
     assert vk[1, 0] < 0.25 * nv                          # and most of its half plane is dropped
 
 
+def test_precision_tiers_of_the_matrix_core_stage(api):
+    """The matrix-core stage skips blocks below 2^-29 of OTF[0][0] ("mf_floor") and runs blocks below
+    2^-18 without the low half of the OTF ("mf_mid_log2"), where the fp16 halves it leaves out are
+    subnormal (otf_mfma2.hip).  Round 3 documented that as bit-neutral ("the
+    matrix cores flush fp16 subnormals"); this test showed it is not -- the gfx950 matrix cores keep
+    subnormal fp16 inputs -- so the tiers are approximations like the pruning, and what is asserted is
+    their size: no stamp pixel moves by more than 3e-7 of its stamp's peak (the bound the block pruning
+    is held to), the fits far inside the parity tolerance."""
+    see, gl, l0 = api.synthetic_rows(10)
+    see[0], gl[0], l0[0] = 0.4, 0.95, 29.0
+    see[1], gl[1], l0[1] = 1.6, 0.30, 9.0
+    lb = np.linspace(465, 930, 9)
+    ps = api.grid_pixscale(512)
+    out = {}
+    for key, opts in (('default', {}), ('no_floor', {'mf_floor': 0}), ('no_mid', {'mf_mid_log2': -1e30})):
+        ctx = api.Context(dim=512, pixscale=ps, precision='mixed')
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        out[key] = ctx.reconstruct(lb, see, gl, l0, None, H)
+        out[key + '_work'] = ctx.debug_fetch('mf_work', (5,))
+        ctx.close()
+    # the tiers are in use on this workload (else the test says nothing)
+    assert out['default_work'][4] > 0 and out['no_mid_work'][4] == 0
+    assert out['no_floor_work'][0] > out['default_work'][0]
+    a = out['default']
+    peak = a['psf'].max(axis=(2, 3), keepdims=True)
+    well = a['fit'][:, :, 4] < 10
+    for key in ('no_mid', 'no_floor'):
+        b = out[key]
+        dst = float((np.abs(b['psf'] - a['psf']) / peak).max())
+        dfw = float(np.abs(b['fit'][:, :, 5] - a['fit'][:, :, 5])[well].max(initial=0) * ps)
+        dbe = float(np.abs(b['fit'][:, :, 4] - a['fit'][:, :, 4])[well].max(initial=0))
+        record_margin('precision_tiers_' + key, stamp=dst, fwhm_arcsec=dfw, beta=dbe)
+        assert dst < 3e-7 and dfw < 2e-6 and dbe < 2e-5, (key, dst, dfw, dbe)
+
+
 @pytest.mark.parametrize('dim,npl', [(512, 1), (128, 1), (256, 2), (256, 5), (512, 3), (1280, 1)])
 def test_matrix_core_stage_against_the_fft_stage(api, dim, npl):
     """Mixed mode has two implementations of the per-wavelength stage: split-fp16 contractions on

@@ -236,3 +236,34 @@ def test_plot_psf_on_a_result_list(tmp_path):
     fig2 = plot_psf(out)
     fig2.savefig(str(tmp_path / 'fig2.png'))
     assert os.path.getsize(str(tmp_path / 'fig2.png')) > 0
+
+
+def test_fanout_devices(monkeypatch):
+    """The devices a table runs on (psfrec._fanout_devices): an explicit device is that device and no
+    other; the automatic choice fans out over the visible GPUs for large tables only, is capped by
+    n_jobs, and never leaves its own GPU inside a one-rank-per-GPU launch."""
+    import muse_psfr_amd._lib as L
+    from muse_psfr_amd import psfrec
+    monkeypatch.setattr(L, 'device_count', lambda: 8)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.delenv('LOCAL_RANK', raising=False)
+    f = psfrec._fanout_devices
+    assert f(None, 3, 1000, -1) == [3]                 # explicit device: nothing else, whatever n_jobs
+    assert f(None, 3, 1000, 1) == [3]
+    assert f(None, 0, 100000, 4) == [0]
+    assert f(None, None, 1000, -1) == list(range(8))   # automatic: every visible GPU
+    assert f(None, None, 1000, 2) == [0, 1]            # capped by n_jobs
+    assert f(None, None, 1000, 1) == [0]
+    assert f(None, None, 100, -1) == [0, 1, 2]         # 32 tasks per device at least
+    assert f(None, None, 40, -1) == [0]
+    assert f([2, 2, 5], None, 3, 1) == [2, 2, 5]       # an explicit list is taken as given
+    with pytest.raises(ValueError):
+        f([], None, 10, -1)
+    monkeypatch.setenv('WORLD_SIZE', '8')              # a rank of torch.distributed.run stays at home
+    monkeypatch.setenv('LOCAL_RANK', '5')
+    assert f(None, None, 100000, -1) == [5]
+    assert f(None, 2, 100000, -1) == [2]
+    monkeypatch.setattr(L, 'device_count', lambda: 1)
+    monkeypatch.delenv('WORLD_SIZE')
+    monkeypatch.delenv('LOCAL_RANK')
+    assert f(None, None, 100000, -1) == [0]
