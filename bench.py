@@ -108,6 +108,67 @@ def hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac=1.0, has_tq=True):
     return b
 
 
+def rank_times_block(rank_dt, steps):
+    """Every rank's own time for the timed region (`ms_per_step` is the maximum): an imbalance between
+    the shards is visible in the scaling record."""
+    ms = [d / steps * 1e3 for d in rank_dt]
+    return {'min': round(min(ms), 4), 'max': round(max(ms), 4), 'all': [round(m, 4) for m in ms]}
+
+
+def rehearse(a, rank, world, bounds, total_rows, strong):
+    """MPSFR_BENCH_REHEARSAL=1: the N > 1 path of this script WITHOUT a GPU -- launcher environment, row
+    shards, the exchange of muse_psfr_amd/distributed.py (all-gather of the fit tables, sum-reduce of the
+    stamp sums) on gloo with CPU tensors, barrier + maximum over the ranks, the JSON line -- around a
+    deterministic stand-in for the rank's rows.  What an 8-GPU node will run for the first time is then
+    only the library call and RCCL itself (tests/test_dist.py runs this with 8 ranks)."""
+    import torch
+    import torch.distributed as dist
+    from muse_psfr_amd import synthetic_rows
+    from muse_psfr_amd.distributed import ShardExchange
+    nl, nfit = a.nl, 16
+    dist.init_process_group('gloo')
+    see = synthetic_rows(total_rows)[0]
+    lo, hi = bounds[rank]
+    lam = torch.arange(1, nl + 1, dtype=torch.float64)
+    ex = ShardExchange(total_rows, nl, nfit, torch.device('cpu'))
+
+    def step():
+        sr = torch.tensor(see[lo:hi], dtype=torch.float64)
+        fit = (sr[:, None, None] * lam[None, :, None]) * torch.arange(1, nfit + 1, dtype=torch.float64)[None, None, :]
+        psum = (sr.sum() * lam)[:, None, None] * torch.ones((nl, 40, 40), dtype=torch.float64)
+        return ex.gather(fit), ex.reduce(psum, dst=0)
+    for _ in range(a.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        fit_all, psum = step()
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    allt = [torch.zeros_like(tt) for _ in range(world)]
+    dist.all_gather(allt, tt)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    ok = True
+    if rank == 0:
+        sa = torch.tensor(see, dtype=torch.float64)
+        want = (sa[:, None, None] * lam[None, :, None]) * torch.arange(1, nfit + 1, dtype=torch.float64)[None, None, :]
+        ok = bool(torch.equal(fit_all, want)) and bool(torch.allclose(psum[:, 0, 0], sa.sum() * lam, rtol=1e-13))
+        print(json.dumps({
+            'metric': 'PSFs/sec (row x lambda) on %d^2 grid, %d lambda' % (a.dim, nl), 'rehearsal': True,
+            'value': round(total_rows * nl * a.steps / dt, 1), 'unit': 'PSFs/sec', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 4), 'higher_is_better': True,
+            'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'stand-in', 'data': 'synthetic',
+            'config': {'workload': '%d-row synthetic SPARTA table row-sharded over %d ranks (%s rows per rank), '
+                                   'stand-in compute on the CPU' % (total_rows, world, '/'.join(str(b - a_) for a_, b in bounds)),
+                       'rows_total': total_rows, 'parallelism': 'rows sharded x%d' % world},
+            'rank_ms_per_step': rank_times_block([float(t.item()) for t in allt], a.steps),
+            'exchange_matches_single_process': ok}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def load_json(name):
     f = os.path.join(ROOT, 'profiles', name)
     return json.load(open(f)) if os.path.exists(f) else None
@@ -182,6 +243,8 @@ def main():
     see, gl, l0 = synthetic_rows(total_rows)
     sl = slice(*bounds[rank])
     rows = bounds[rank][1] - bounds[rank][0]
+    if os.environ.get('MPSFR_BENCH_REHEARSAL'):
+        sys.exit(rehearse(a, rank, world, bounds, total_rows, strong))
     default_workload = (world == 1 and (rows, nl, dim, a.npsflin, a.precision) == (100, 35, 512, 1, 'mixed'))
     mixed = a.precision == 'mixed'
 
@@ -333,6 +396,10 @@ def main():
             dt = time.perf_counter() - t0
             tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
             if xchg:
+                # every rank's own time travels too (an imbalance between the shards shows in SCALE_r*.json)
+                allt = [torch.zeros_like(tt) for _ in range(world)]
+                dist.all_gather(allt, tt)
+                state['rank_dt'] = [float(t.item()) for t in allt]
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item()), t_enq
 
@@ -347,11 +414,14 @@ def main():
         def close():
             for c in ctxs:
                 c.close()
+
+        def rank_times():
+            return state.get('rank_dt')
         def host_lib():
             tot = [c.host_time() for c in ctxs]
             return sum(t[0] for t in tot) / max(1, sum(t[1] for t in tot))
         return dict(ctxs=ctxs, step=step, fence=fence, timed=timed, profile_sum=profile_sum,
-                    fits=fits, close=close, host_lib=host_lib)
+                    fits=fits, close=close, host_lib=host_lib, rank_times=rank_times)
 
     def parity_block(fitg, n):
         return {'rows_checked': n,
@@ -390,6 +460,7 @@ def main():
     for _ in range(a.warmup):
         R['step']()
     dt, t_enq = R['timed'](a.steps)
+    rank_dt = R['rank_times']()
     prof = R['profile_sum']()
     host_lib_s = R['host_lib']()
     # A region of a few milliseconds is thin evidence: repeat it (same K steps, same brackets) until
@@ -711,6 +782,8 @@ def main():
             'host_library_ms_per_call': round(host_lib_s * 1e3, 4),
             'build_id': load_lib().mpsfr_build_id().decode(),
         }
+        if rank_dt:
+            out['rank_ms_per_step'] = rank_times_block(rank_dt, a.steps)
         if len(rep_dt) > 1:
             vals = [npsf / d for d in rep_dt]
             out['timed_region_repeats'] = {'count': len(rep_dt), 'seconds_each': round(dt, 4),

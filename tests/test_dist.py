@@ -185,3 +185,62 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
     assert cmd[-4:] == ['--gpus', '4', '--steps', '7'] and cmd[-5].endswith('bench.py')
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def _spawn(target, world, args):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize('ntask', [1000, 1001, 5])
+def test_eight_rank_sharding_matches_single_process(ntask):
+    """The split of BASELINE configs[2] (1000 rows over 8 ranks: 125 each), a ragged one (1001: one rank
+    takes 126) and one with empty shards (5 rows over 8 ranks), on eight gloo ranks."""
+    sys.path.insert(0, ROOT)
+    from muse_psfr_amd.distributed import shard_bounds
+    from muse_psfr_amd.synthetic import synthetic_rows
+    b = shard_bounds(ntask, 8)
+    assert b[0][0] == 0 and b[-1][1] == ntask and all(b[i][1] == b[i + 1][0] for i in range(7))
+    sizes = [hi - lo for lo, hi in b]
+    assert max(sizes) - min(sizes) <= 1 and (ntask != 1000 or sizes == [125] * 8)
+    fit_all, mean = _spawn(_worker, 8, (ntask,))
+    see = synthetic_rows(ntask)[0]
+    fit1, psum1 = _fake_local(see)(0, ntask)
+    np.testing.assert_array_equal(fit_all, fit1.numpy())
+    np.testing.assert_allclose(mean, psum1.numpy() / ntask, rtol=1e-13)
+
+
+def test_bench_eight_rank_rehearsal():
+    """`python bench.py --gpus 8` end to end on the CPU (MPSFR_BENCH_REHEARSAL=1): the script launches
+    its own eight ranks, shards configs[2], runs the exchange on gloo and prints one JSON line with the
+    whole-job value, the maximum over the ranks and every rank's own time."""
+    import json
+    import subprocess
+    env = dict(os.environ, MPSFR_BENCH_REHEARSAL='1', MPSFR_BENCH_BACKEND='gloo', OMP_NUM_THREADS='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1',
+                        '--nl', '5'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 8 and out['scaling'] == 'strong' and out['rehearsal'] is True
+    assert out['exchange_matches_single_process'] is True
+    assert '125/125/125/125/125/125/125/125' in out['config']['workload']
+    rk = out['rank_ms_per_step']
+    assert len(rk['all']) == 8 and rk['max'] >= rk['min'] > 0
+    assert abs(out['ms_per_step'] - rk['max']) < 1e-3 + 0.05 * rk['max']
+    assert abs(out['value'] - 1000 * 5 / (out['ms_per_step'] * 1e-3)) / out['value'] < 1e-2

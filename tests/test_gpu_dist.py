@@ -172,3 +172,50 @@ def test_bench_step_with_collectives_on_rccl_one_rank():
     assert r.returncode == 0 and line, r.stderr[-3000:]
     out = json.loads(line[-1])
     assert out['n_gpus'] == 1 and out['value'] > 0 and out['steps'] == 10
+
+
+def test_multi_context_call_selects_every_device(tmp_path):
+    """mpsfr_reconstruct_multi on a node with several GPUs: one worker thread per context, each selecting
+    ITS device.  A one-GPU box cannot show that directly, so an LD_PRELOAD shim (tests/helpers) makes the
+    HIP runtime report four devices -- all of them the real device 0 -- and logs every hipSetDevice per
+    host thread: four contexts on "devices" 0..3 must be driven by four distinct threads, each asking
+    for its own id, and the table must equal the single-context one."""
+    import shutil
+    import subprocess
+    import textwrap
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    shim = str(tmp_path / 'shim.so')
+    subprocess.check_call(['gcc', '-shared', '-fPIC', '-O1', '-o', shim,
+                           os.path.join(ROOT, 'tests', 'helpers', 'hip_device_shim.c'), '-ldl', '-lpthread'])
+    log = str(tmp_path / 'setdevice.log')
+    script = textwrap.dedent('''
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from muse_psfr_amd import synthetic_rows, grid_pixscale
+        from muse_psfr_amd._lib import Context, device_count
+        assert device_count() == 4
+        see, gl, l0 = synthetic_rows(40)
+        lb = np.linspace(500, 900, 4)
+        ps = grid_pixscale(256)
+        ctxs = [Context(dim=256, pixscale=ps, device=d) for d in range(4)]
+        open(%r, 'w').close()                    # only the calls below are of interest
+        multi = Context.reconstruct_multi(ctxs, lb, see, gl, l0, None, (100, 10000))
+        one = ctxs[0].reconstruct(lb, see, gl, l0, None, (100, 10000))
+        assert np.array_equal(multi['fit'], one['fit']) and np.array_equal(multi['psf'], one['psf'])
+        np.testing.assert_allclose(multi['psf_sum'], one['psf_sum'], rtol=1e-13)
+        for c in ctxs:
+            c.close()
+        print('OK')
+    ''') % (ROOT, log)
+    env = dict(os.environ, LD_PRELOAD=shim, MPSFR_SHIM_DEVICES='4', MPSFR_SHIM_LOG=log)
+    r = subprocess.run([sys.executable, '-c', script], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+    by_thread = {}
+    for ln in open(log):
+        th, dev = ln.split()
+        by_thread.setdefault(th, set()).add(int(dev))
+    # (the log also holds the single-context call and the closing of the contexts on the main thread)
+    assert len([1 for d in by_thread.values() if d == {1}]) == 1, by_thread
+    assert len([1 for d in by_thread.values() if d == {2}]) == 1
+    assert len([1 for d in by_thread.values() if d == {3}]) == 1
