@@ -701,6 +701,53 @@ def test_line_pruning_changes_nothing_above_its_bound(api, dim, npl):
     assert vk[1, 0] < 0.25 * nv                          # and most of its half plane is dropped
 
 
+@pytest.mark.parametrize('prec', ['mixed', 'f64'])
+@pytest.mark.parametrize('dim,npl', [(128, 1), (256, 3), (512, 1), (512, 2), (1024, 1), (1280, 1)])
+def test_series_form_of_stage_a_against_the_full_size_transforms(api, dim, npl, prec):
+    """Two independent implementations of stage A held against each other: the series + patch form
+    (stage_a2.hip: polynomial in 1/L0^2 from per-context tables + pruned in-register transforms of the
+    corrected zone; option stage_a = 2) and the full-size fp64 transforms of the PSD (stage_a.hip;
+    stage_a = 0).  The structure function agrees to its storage rounding (fp32 in mixed mode: both are
+    fp64 values rounded once) / to 1e-14 of its maximum (f64 mode); L0 from the edge of the expansion
+    (7 m) to infinity, both laser geometries, fewer tasks than waves; a call with L0 < 7 m takes the
+    full-size transforms by itself, whatever the option says."""
+    see = np.array([0.45, 1.0, 1.6, 0.8, 1.2])
+    gl = np.array([0.93, 0.7, 0.3, 0.5, 0.05])
+    l0 = np.array([7.0, 25.0, 1.0e4, 29.9, 8.1])
+    three = np.array([0, 1, 0, 0, 1], np.uint8)
+    lb = np.array([465.0, 700.0, 930.0]) if dim != 1280 else np.array([490.0, 700.0, 930.0])
+    ps = api.grid_pixscale(dim)
+    ndir = npl * npl
+    res = {}
+    for mode in (0, 2):
+        ctx = api.Context(dim=dim, pixscale=ps, precision=prec)
+        ctx.set_option('stage_a', mode)
+        r = ctx.reconstruct(lb, see, gl, l0, three, H, npsflin=npl)
+        d0 = ctx.debug_fetch('dphi0', (see.size, ndir, dim // 2 + 1, dim))
+        if mode == 2:       # an outer scale below the radius of the expansion: the call falls back by itself
+            r_short = ctx.reconstruct(lb, see[:2], gl[:2], np.array([5.0, 25.0]), three[:2], H, npsflin=npl)
+        ctx.close()
+        res[mode] = (r, d0)
+    ctx = api.Context(dim=dim, pixscale=ps, precision=prec)
+    ctx.set_option('stage_a', 0)
+    r_short0 = ctx.reconstruct(lb, see[:2], gl[:2], np.array([5.0, 25.0]), three[:2], H, npsflin=npl)
+    ctx.close()
+    np.testing.assert_array_equal(r_short['psf'], r_short0['psf'])
+    (ra, da), (rb, db) = res[0], res[2]
+    tol_d = 1.5e-7 if prec == 'mixed' else 1e-14
+    for k in range(see.size):
+        assert np.abs(db[k] - da[k]).max() / np.abs(da[k]).max() < tol_d, (k, np.abs(db[k] - da[k]).max() / np.abs(da[k]).max())
+    peak = ra['psf'].max(axis=(2, 3), keepdims=True)
+    dst = float((np.abs(rb['psf'] - ra['psf']) / peak).max())
+    assert dst < (5e-7 if prec == 'mixed' else 1e-12), dst
+    if dim >= 512:
+        well = ra['fit'][:, :, 4] < 10
+        assert np.abs(rb['fit'][:, :, 5] - ra['fit'][:, :, 5])[well].max(initial=0) * ps < (5e-6 if prec == 'mixed' else 1e-8)
+        assert np.abs(rb['fit'][:, :, 4] - ra['fit'][:, :, 4])[well].max(initial=0) < (2e-5 if prec == 'mixed' else 1e-8)
+        record_margin('series_vs_full_size_%s' % prec, stamp=dst,
+                      beta=float(np.abs(rb['fit'][:, :, 4] - ra['fit'][:, :, 4])[well].max(initial=0)))
+
+
 def test_precision_tiers_of_the_matrix_core_stage(api):
     """The matrix-core stage skips blocks below 2^-29 of OTF[0][0] ("mf_floor") and runs blocks below
     2^-18 without the low half of the OTF ("mf_mid_log2"), where the fp16 halves it leaves out are
