@@ -87,7 +87,7 @@ const char* mpsfr_last_error(void);
  * "profile_only" (-1 = all kernels, else the kernel id of mpsfr_profile_name to time alone);
  * "prune_eps_f64" (f64 mode only, default 1e-13, at most 1e-6: the same bound for the line pruning
  * of the reference-precision mode; 0 = everything).
- * "stage_a" (default 1 = automatic: from 512^2 on the structure function of a task is the sum of a
+ * "stage_a" (default 1 = automatic: from 512^2 on (at 256^2 with several directions) the structure function of a task is the sum of a
  * per-pixel polynomial in 1/L0^2 -- the fitting term, from tables built once per context -- and a pruned
  * transform of the 80 x 80 corrected zone (stage_a2.hip); below, and for any call with L0 < 7 m, the
  * full-size fp64 transforms of the PSD (stage_a.hip); 0 = always the full-size transforms, 2 = the

@@ -81,8 +81,9 @@ struct mpsfr_ctx {
     int mf_permax = 6;           // wavelengths per workgroup of the thin-wave kernel (6: 12 waves, 7: 14 waves)
     double mf_mid_log2 = -18.01; // blocks below 2^this need no low half of the OTF (see otf_mfma2.hip)
     bool mf_clock = false;       // experiments: phase time stamps of the matrix-core kernel
-    int stage_a = 1;             // stage A: 1 = automatic (the series + patch form of stage_a2.hip from 512^2 on, the
-                                 // full-size transforms below: at 128^2 / 256^2 they are the faster), 0 = full-size
+    int stage_a = 1;             // stage A: 1 = automatic (the series + patch form of stage_a2.hip from 512^2 on, and at
+                                 // 256^2 with several directions; the full-size transforms otherwise: one direction at
+                                 // 256^2 19.2 against 18.3 M PSFs/s, nine directions 7.9 against 8.8), 0 = full-size
                                  // transforms, 2 = series + patch form on every grid
     DevBuf mfclk;
     // constant tables
@@ -720,7 +721,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     // Stage A in its series form needs every 1/L0^2 inside the radius of its expansion (L0 >= 7 m;
     // the SPARTA front end only lets 8 < L0 < 30 through, psfrec.py:1049-1051); a call with a shorter
     // outer scale takes the full-size transforms.
-    bool series = c->stage_a == 2 || (c->stage_a == 1 && N >= 512);
+    bool series = c->stage_a == 2 || (c->stage_a == 1 && (N >= 512 || (N >= 256 && npsflin >= 2)));
     for (int t = 0; t < ntask; ++t) series = series && tp[t].inv_l0sq <= series_eps_max();
 
     // ---- geometry of the AO tables (psfrec.py:61, 66, 86-93, 99, 154-158, 536-537, 594)

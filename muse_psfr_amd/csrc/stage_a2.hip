@@ -231,6 +231,16 @@ __device__ __forceinline__ void min32_x4(float& a, float& b, float& c, float& d)
         "s_nop 0"       /* (the next instruction may read d: written by a DPP instruction one state before) */
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+// the same over the rows of 16 lanes alone (no row_bcast step): every lane holds its row's minimum
+__device__ __forceinline__ void min16_x4(float& a, float& b, float& c, float& d) {
+    asm("s_nop 1\n\t"
+        MPSFR_MIN4("quad_perm:[1,0,3,2]")
+        MPSFR_MIN4("quad_perm:[2,3,0,1]")
+        MPSFR_MIN4("row_half_mirror")
+        MPSFR_MIN4("row_mirror")
+        "s_nop 0"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 #undef MPSFR_MIN4
 
 // The sums of a group of CNT residues r_i = R0 + RS i:  acc[i] = sum_j in[r_i + Q j] W_64^(j k2)
@@ -327,18 +337,31 @@ __device__ __forceinline__ void fold_sums(cx<double>* v, const double* xr, const
 // is a gather of 64 cache lines per instruction -- the 16 such gathers at the head of every wave of
 // K_PATCH_ROWS kept its vector-memory pipe full and the waves at 40 cycles per instruction.
 // ------------------------------------------------------------------------------------------
-template <int N>
+// L: lanes per line (64 in K_PATCH_ROWS; series_lanes<N>() in K_DPHI_SERIES), Q = N / L
+template <int N, int L>
 __global__ void __launch_bounds__(64) k_series_twiddles(const cx<double>* __restrict__ twg,
                                                         cx<double>* __restrict__ twk) {
-    constexpr int Q = N / 64, NJ = fold_nj<Q>(), JMIN = fold_jmin<Q>();
+    constexpr int Q = N / L, NJ = fold_nj<Q>(), JMIN = fold_jmin<Q>();
     const int row = blockIdx.x, k2 = threadIdx.x;
-    if (row < NJ) twk[row * 64 + k2] = twg[(((Q * (row + JMIN) * k2) % N) + N) % N];
-    else twk[row * 64 + k2] = twg[((row - NJ) * k2) % N];
+    if (k2 >= L) return;
+    if (row < NJ) twk[row * L + k2] = twg[(((Q * (row + JMIN) * k2) % N) + N) % N];
+    else twk[row * L + k2] = twg[((row - NJ) * k2) % N];
 }
+
+// Lanes per line of K_DPHI_SERIES.  A wave carries 64 / L lines (the same y, consecutive tasks): the
+// fold costs 320 multiply-adds per WAVE whatever L is -- each row of 16 lanes holds its own line's
+// inputs as broadcast operands -- while the in-lane transform grows with Q = N / L.  Q = 16 wherever
+// the grid allows it (512^2: two lines per wave, 560 -> 330 instructions per line; 256^2: four).
+template <int N>
+constexpr int series_lanes() { return N <= 256 ? 16 : (N == 512 ? 32 : 64); }
+template <int N, int L>
+constexpr size_t twiddle_entries() { return (size_t)(fold_nj<N / L>() + N / L) * L; }
 
 // ------------------------------------------------------------------------------------------
 // K_PATCH_GEN: P[td][su + 40][sv + 40] = max(F, AO) - F on the corrected zone (psfrec.py:148-149;
-// F and AO exactly as K_PSD_ROWFFT evaluates them).
+// F and AO exactly as K_PSD_ROWFFT evaluates them).  A thread is (task, pixel) and walks the task's
+// directions: the fitting term and the von Karman factor of the pixel -- two x^(-11/6), nearly all of
+// the arithmetic -- do not depend on the direction, only the tables do (nine directions: 21.6 -> us).
 // ------------------------------------------------------------------------------------------
 template <bool F64>
 __global__ void __launch_bounds__(256) k_patch_gen(int ndir, const TaskPar* __restrict__ tp,
@@ -347,50 +370,54 @@ __global__ void __launch_bounds__(256) k_patch_gen(int ndir, const TaskPar* __re
     constexpr int NEWTON = F64 ? 2 : 1;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= NAO * NAO) return;
-    const int td = blockIdx.y, task = td / ndir, d = td % ndir;
+    const int task = blockIdx.y;
     const TaskPar p = tp[task];
-    const double* tb = aotab + ((size_t)(p.geom * ndir + d) * 3) * (NAO * NAO);
     const int su = pix / NAO - NAO / 2, sv = pix % NAO - NAO / 2;
     const double fit = psd_fit_value<NEWTON>(su, sv, p, cfit);
-    P[(size_t)td * (NAO * NAO) + pix] = psd_with_ao<NEWTON>(fit, su, sv, p, tb) - fit;
+    const int ia = su < 0 ? su + NAO : su, ib = sv < 0 ? sv + NAO : sv;
+    const double g2 = (double)(su * su + sv * sv) * (1.0 / 256.0);
+    const double vk = 0.0229 * p.r0m53 * pow_m11_6<NEWTON>(g2 + p.inv_l0sq);        // :569-571
+    const int o = ia * NAO + ib;
+    for (int d = 0; d < ndir; ++d) {
+        const double* tb = aotab + ((size_t)(p.geom * ndir + d) * 3) * (NAO * NAO);
+        const double ao = vk * (p.cn2_0 * tb[o] + p.cn2_1 * tb[NAO * NAO + o]) + tb[2 * NAO * NAO + o];
+        P[((size_t)task * ndir + d) * (NAO * NAO) + pix] = fmax(fit, ao) - fit;         // :149
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // K_PATCH_ROWS: T[td][y][su + 40] = sum_sv P[su][sv] exp(-2 pi i sv y / N), y in [0, N/2], and
-// sp[td] = sum P.  A wave takes two or four adjacent rows su: lane k2 folds a row's 80 values (broadcast
+// sp[td] = sum P.  A wave takes one, two or four adjacent rows su at a time: lane k2 folds a row's 80 values (broadcast
 // operands) into Q sums with its own twiddles, transforms them in registers and owns y = k2, 64 + k2, ...
 // K_DPHI_SERIES reads the 80 values of one (td, y) as 1280 contiguous bytes (with T[td][su][y] every
 // line of it gathered 80 cache lines: 12 of its 50 us at 512^2), so a lane stores its rows' values
 // of one y as one 32- or 64-byte piece; the waves are independent (a transposition of 8 rows through LDS
 // for 128-byte pieces cost two barriers per workgroup and, at 1280^2, all of a CU's LDS: 31 -> 46 us).
 // ------------------------------------------------------------------------------------------
-template <int N>
-constexpr int rows_per_wave() { return N / 64 <= 8 ? 4 : 2; }      // (a row's results are N/128 + 1 complex registers)
-
+// L = series_lanes<N>() lanes per row, R = 64 / L rows per wave and pass (one per group of L lanes),
+// Q = N / L: the same fold and in-lane transform as K_DPHI_SERIES, with a real input and a complex
+// output of which y <= N/2 is kept.  A workgroup takes `qb` passes of one td, its four waves in turn.
 template <int N>
 __global__ void __launch_bounds__(256) k_patch_rows(const double* __restrict__ P,
                                                     const cx<double>* __restrict__ twk,
-                                                    cx<double>* __restrict__ T, double* __restrict__ sp) {
-    constexpr int Q = N / 64, H1 = N / 2 + 1, NJ = fold_nj<Q>(), JMIN = fold_jmin<Q>();
+                                                    cx<double>* __restrict__ T, double* __restrict__ sp, int qb) {
+    constexpr int L = series_lanes<N>(), R = 64 / L, Q = N / L, H1 = N / 2 + 1, NJ = fold_nj<Q>();
     constexpr bool WJREG = NJ <= 10;
-    constexpr int NY = Q / 2 + 1;                        // values y = 64 k1 + k2 <= N/2 of a lane
-    constexpr int RW = rows_per_wave<N>();
-    __shared__ cx<double> swj[WJREG ? 1 : NJ][64];
+    constexpr int NY = Q / 2 + 1;                        // values y = L k1 + k2 <= N/2 of a lane
+    constexpr int NQ = NAO / R;                          // passes per td
     __shared__ double sred[256];
     const int td = blockIdx.y;
     const double* Pg = P + (size_t)td * (NAO * NAO);
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, rho = lane / L, k2 = lane & (L - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n0 = RW * (blockIdx.x * 4 + wave);                        // rows su + 40 = n0 ... n0 + RW - 1
-    double xr[RW][kNX];
+    const int q_end = min(NQ, ((int)blockIdx.x + 1) * qb);
+    int q = blockIdx.x * qb + wave;
+    double xa[kNX], xb[kNX];
+    auto fetch = [&](int qq, double* xr) {
 #pragma unroll
-    for (int h = 0; h < RW; ++h)
-#pragma unroll
-        for (int a = 0; a < kNX; ++a) xr[h][a] = Pg[(n0 + h) * NAO + 16 * a + (lane & 15)];
-    if constexpr (!WJREG) {
-        for (int i = threadIdx.x; i < NJ * 64; i += 256) swj[i >> 6][i & 63] = twk[i];
-        __syncthreads();
-    }
+        for (int a = 0; a < kNX; ++a) xr[a] = Pg[(R * qq + rho) * NAO + 16 * a + (lane & 15)];
+    };
+    if (q < q_end) fetch(q, xa);
     if (blockIdx.x == 0) {      // sum of the patch, in an order fixed by the launch geometry
         double a = 0.0;
         for (int i = threadIdx.x; i < NAO * NAO; i += 256) a += Pg[i];
@@ -405,38 +432,40 @@ __global__ void __launch_bounds__(256) k_patch_rows(const double* __restrict__ P
     cx<double> wjr[WJREG ? NJ : 1], wr[Q];
     if constexpr (WJREG) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) wjr[j] = twk[j * 64 + lane];
+        for (int j = 0; j < NJ; ++j) wjr[j] = twk[j * L + k2];
     }
 #pragma unroll
-    for (int r = 1; r < Q; ++r) wr[r] = twk[(NJ + r) * 64 + lane];
-    cx<double> res[RW][NY];
-#pragma unroll
-    for (int h = 0; h < RW; ++h) {
+    for (int r = 1; r < Q; ++r) wr[r] = twk[(NJ + r) * L + k2];
+    auto pass = [&](int qq, const double* xr) {
         cx<double> S[Q];
         {
             constexpr int GC = Q % 5 == 0 ? 5 : (Q < 4 ? Q : 4);
             cx<double> wl[WJREG ? 1 : NJ];
             if constexpr (!WJREG) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) wl[j] = swj[j][lane];
+                for (int j = 0; j < NJ; ++j) wl[j] = twk[j * L + k2];
             }
             const cx<double>* wjp = WJREG ? wjr : wl;
             static_for<0, Q / GC>([&](auto gc) {
                 constexpr int R0 = decltype(gc)::value * GC;
-                fold_sums<Q, false, R0, 1, GC>(S + R0, xr[h], xr[h], wjp, [&](int r) { return wr[r]; });
+                fold_sums<Q, false, R0, 1, GC>(S + R0, xr, xr, wjp, [&](int r) { return wr[r]; });
             });
         }
         dftq<Q>(S);
+        cx<double>* Tt = T + ((size_t)td * H1 + k2) * NAO + R * qq + rho;
 #pragma unroll
-        for (int k1 = 0; k1 < NY; ++k1) res[h][k1] = S[k1];
+        for (int k1 = 0; k1 < NY; ++k1)
+            if (L * k1 + k2 <= N / 2) Tt[(size_t)L * k1 * NAO] = S[k1];
+    };
+    while (q < q_end) {
+        if (q + 4 < q_end) fetch(q + 4, xb);
+        pass(q, xa);
+        q += 4;
+        if (q >= q_end) break;
+        if (q + 4 < q_end) fetch(q + 4, xa);
+        pass(q, xb);
+        q += 4;
     }
-    cx<double>* Tt = T + ((size_t)td * H1 + lane) * NAO + n0;
-#pragma unroll
-    for (int k1 = 0; k1 < NY; ++k1)
-        if (64 * k1 + lane <= N / 2) {
-#pragma unroll
-            for (int h = 0; h < RW; ++h) Tt[(size_t)64 * k1 * NAO + h] = res[h][k1];
-        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -449,14 +478,16 @@ template <typename RO> struct SeriesCfg;
 template <> struct SeriesCfg<float> { static constexpr int K = 4; };
 template <> struct SeriesCfg<double> { static constexpr int K = 8; };
 
-// one line: xv = its inputs (lane l holds input 16 a + l % 16 in xv[a]), wjp[j - JMIN] = W_64^(j k2) of
-// the lane, swr[r * 64 + k2] = W_N^(r k2) (LDS), scoef = the coefficients of line y (LDS, [x][K])
-template <int N, typename RO>
+// The lines of a wave: xv = their inputs (lane l holds input 16 a + l % 16 of ITS line in xv[a]),
+// wjp[j - JMIN] = W_L^(j k2) of the lane, swr[r * L + k2] = W_N^(r k2) (LDS), scoef = the coefficients
+// of line y (LDS, [x][K]); r0m53, delta, spv, dst, dlin: the lane's line (td); k2 = lane % L.
+template <int N, typename RO, int L>
 __device__ __forceinline__ void series_line(const cx<double>* xv, const cx<double>* wjp,
                                             const cx<double>* swr, const RO* scoef, double r0m53,
                                             double delta, double spv, double scale2, RO* dst, float* dlin,
-                                            int lane, int dbg) {
-    constexpr int Q = N / 64, K = SeriesCfg<RO>::K;
+                                            bool valid, int lane, int dbg) {
+    constexpr int Q = N / L, K = SeriesCfg<RO>::K;
+    const int k2 = lane & (L - 1);
     double xr[kNX], xi[kNX];
 #pragma unroll
     for (int a = 0; a < kNX; ++a) {
@@ -468,7 +499,7 @@ __device__ __forceinline__ void series_line(const cx<double>* xv, const cx<doubl
 #pragma unroll
         for (int k1 = 0; k1 < Q; ++k1) out[k1] = xr[k1 % kNX] + k1;
     } else {
-        auto wrf = [&](int r) { return swr[r * 64 + lane]; };
+        auto wrf = [&](int r) { return swr[r * L + k2]; };
         if constexpr (Q == 2) {
             cx<double> S[2];
             fold_sums<Q, true, 0, 1, 2>(S, xr, xi, wjp, wrf);
@@ -502,31 +533,36 @@ __device__ __forceinline__ void series_line(const cx<double>* xv, const cx<doubl
     }
     // Block minima for the pruning of the per-wavelength stage, while the values are in registers
     // (K_DMIN read all of D back for them: 12 us at 512^2, 69 us at 1280^2): the minimum of max(D, 0)
-    // over the 32 columns [32 kb, 32 kb + 32) of this line, kb = 2 k1 + (lane >= 32), goes to
-    // dlin[kb]; K_DMIN16 takes the minima over 16 lines.  min32_x4 leaves them in lanes 16-31 and 48-63;
-    // lane 16 + k1 % 16 (48 + k1 % 16) keeps the result of k1.
-    float keep[(Q + 15) / 16], dq[Q < 4 ? 4 : Q];
+    // over the 32 columns [32 kb, 32 kb + 32) of the line goes to dlin[kb]; K_DMIN16 takes the minima
+    // over 16 lines.  A lane's values are x = L k1 + k2:
+    //   L = 64: kb = 2 k1 + (lane >= 32); min32_x4 leaves the minima in lanes 16-31 and 48-63, lane
+    //           16 + k1 % 16 (48 + k1 % 16) keeps the result of k1;
+    //   L = 32: kb = k1, the 32 lanes of a line; the same, lanes 16-31 / 48-63 are the two lines;
+    //   L = 16: kb = k1 / 2: the two values of a lane first, then the row of 16 lanes (min16_x4); lane
+    //           kb % 16 of the line's row keeps kb.
+    constexpr int NB = L == 16 ? Q / 2 : Q;              // values per lane that go into the lane minima
+    float keep[(NB + 15) / 16], dq[Q < 4 ? 4 : Q];
 #pragma unroll
-    for (int i = 0; i < (Q + 15) / 16; ++i) keep[i] = 0.f;
+    for (int i = 0; i < (NB + 15) / 16; ++i) keep[i] = 0.f;
     if constexpr (sizeof(RO) == 4) {
         const float df = (float)delta, rf = (float)r0m53;
 #pragma unroll
         for (int k1 = 0; k1 < Q; ++k1) {
-            const float4 h = *reinterpret_cast<const float4*>(scoef + (size_t)(64 * k1 + lane) * K);
+            const float4 h = *reinterpret_cast<const float4*>(scoef + (size_t)(L * k1 + k2) * K);
             const float dF = rf * fmaf(fmaf(fmaf(h.w, df, h.z), df, h.y), df, h.x);
             const float d = (float)(fma(scale2, spv - out[k1], (double)dF));
-            dst[64 * k1] = d;
+            if (valid) dst[L * k1] = d;
             dq[k1] = fmaxf(d, 0.f);
         }
     } else {
 #pragma unroll
         for (int k1 = 0; k1 < Q; ++k1) {
-            const double* h = scoef + (size_t)(64 * k1 + lane) * K;
+            const double* h = scoef + (size_t)(L * k1 + k2) * K;
             double a = h[K - 1];
 #pragma unroll
             for (int k = K - 2; k >= 0; --k) a = fma(a, delta, h[k]);
             const double d = fma(scale2, spv - out[k1], r0m53 * a);
-            dst[64 * k1] = d;
+            if (valid) dst[L * k1] = d;
             dq[k1] = fmaxf(__double2float_rd(d), 0.f);      // (rounded down: the bound stays a bound)
         }
     }
@@ -535,19 +571,39 @@ __device__ __forceinline__ void series_line(const cx<double>* xv, const cx<doubl
             dq[2] = dq[0];
             dq[3] = dq[1];
         }
+        if constexpr (L == 16) {
+            static_assert(Q % 8 == 0, "pairs of values, four pairs to a statement");
 #pragma unroll
-        for (int k1 = 0; k1 < (Q < 4 ? 4 : Q); k1 += 4) {
-            min32_x4(dq[k1], dq[k1 + 1], dq[k1 + 2], dq[k1 + 3]);
+            for (int kb = 0; kb < NB; ++kb) dq[kb] = fminf(dq[2 * kb], dq[2 * kb + 1]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (k1 + i < Q && (lane & 15) == ((k1 + i) & 15)) keep[(k1 + i) >> 4] = dq[k1 + i];
-        }
-    }
-    if (dlin != nullptr && (lane & 16)) {
+            for (int kb = 0; kb < NB; kb += 4) {
+                min16_x4(dq[kb], dq[kb + 1], dq[kb + 2], dq[kb + 3]);
 #pragma unroll
-        for (int i = 0; i < (Q + 15) / 16; ++i) {
-            const int k1 = 16 * i + (lane & 15);
-            if (k1 < Q) dlin[2 * k1 + (lane >> 5)] = keep[i];
+                for (int i = 0; i < 4; ++i)
+                    if ((lane & 15) == ((kb + i) & 15)) keep[(kb + i) >> 4] = dq[kb + i];
+            }
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < (NB + 15) / 16; ++i) {
+                    const int kb = 16 * i + (lane & 15);
+                    if (kb < NB) dlin[kb] = keep[i];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k1 = 0; k1 < (Q < 4 ? 4 : Q); k1 += 4) {
+                min32_x4(dq[k1], dq[k1 + 1], dq[k1 + 2], dq[k1 + 3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (k1 + i < Q && (lane & 15) == ((k1 + i) & 15)) keep[(k1 + i) >> 4] = dq[k1 + i];
+            }
+            if (valid && (lane & 16)) {
+#pragma unroll
+                for (int i = 0; i < (Q + 15) / 16; ++i) {
+                    const int k1 = 16 * i + (lane & 15);
+                    if (k1 < Q) dlin[L == 64 ? 2 * k1 + (lane >> 5) : k1] = keep[i];
+                }
+            }
         }
     }
 }
@@ -562,42 +618,47 @@ __device__ __forceinline__ void series_line(const cx<double>* xv, const cx<doubl
 // per launch).  [first form: one workgroup per (y, group of tasks) -- 2056 workgroups at 512^2, whose
 // set-up and +-1 task imbalance cost 20 of its 50 us]
 template <int N, typename RO>
-constexpr int series_threads() { return (N == 512 && sizeof(RO) == 4) ? 768 : (N <= 128 ? 256 : 512); }
+constexpr int series_threads() { return N <= 128 ? 256 : 512; }
 template <int N, typename RO>
 constexpr size_t series_smem() {
-    return 2 * (size_t)N * SeriesCfg<RO>::K * sizeof(RO) + (size_t)(N / 64) * 64 * sizeof(cx<double>);
+    return 2 * (size_t)N * SeriesCfg<RO>::K * sizeof(RO) + (size_t)N * sizeof(cx<double>);
 }
 template <int N, typename RO>
 constexpr bool series_fits() { return series_smem<N, RO>() <= 160 * 1024; }
 
+// A "unit" is what a wave takes at a time: the R = 64 / L lines (y; td = R q + rho, rho < R) of one y
+// and R consecutive tasks; units in y-major order, c = y nq + q with nq = ceil(ntd / R).
 template <int N, typename RO>
 __global__ void __launch_bounds__((series_threads<N, RO>()))
 k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
               const TaskPar* __restrict__ tp, int ndir, int ntd, const RO* __restrict__ coef,
               const cx<double>* __restrict__ twk, double scale2, RO* __restrict__ D0t,
               float* __restrict__ dlin, int* __restrict__ zero17, int dbg) {
-    constexpr int Q = N / 64, H1 = N / 2 + 1, K = SeriesCfg<RO>::K, THREADS = series_threads<N, RO>();
-    constexpr int NW = THREADS / 64, NJ = fold_nj<Q>(), JMIN = fold_jmin<Q>();
-    constexpr bool WJREG = NJ <= 10;         // the twiddles W_64^(j k2) of a lane in registers
+    constexpr int L = series_lanes<N>(), R = 64 / L, Q = N / L, H1 = N / 2 + 1, K = SeriesCfg<RO>::K;
+    constexpr int THREADS = series_threads<N, RO>(), NW = THREADS / 64, NJ = fold_nj<Q>();
+    constexpr bool WJREG = NJ <= 10;         // the twiddles W_L^(j k2) of a lane in registers
     constexpr int LINE = N * K;              // coefficients of a line
     extern __shared__ __align__(16) unsigned char smem[];
     RO* scoef = reinterpret_cast<RO*>(smem);                                       // [2][N][K]
-    cx<double>* swr = reinterpret_cast<cx<double>*>(smem + 2 * (size_t)LINE * sizeof(RO));   // [Q][64]
-    const int lane = threadIdx.x & 63;
+    cx<double>* swr = reinterpret_cast<cx<double>*>(smem + 2 * (size_t)LINE * sizeof(RO));   // [Q][L]
+    const int lane = threadIdx.x & 63, rho = lane / L, k2 = lane & (L - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long C = (long)H1 * ntd;
+    const int nq = (ntd + R - 1) / R;
+    const long C = (long)H1 * nq;
     const int c0 = (int)(C * blockIdx.x / gridDim.x), c1 = (int)(C * (blockIdx.x + 1) / gridDim.x);
     if (zero17 != nullptr && blockIdx.x == 0 && threadIdx.x < 17) zero17[threadIdx.x] = 0;
     if (c0 >= c1) return;
+    // (two register sets: the inputs of a unit are requested a whole unit ahead)
     cx<double> xva[kNX], xvb[kNX];
     auto fetch = [&](int c, cx<double>* xv) {
-        const int y = c / ntd, td = c - y * ntd;
+        const int y = c / nq, td = min(R * (c - y * nq) + rho, ntd - 1);
         const cx<double>* src = T + ((size_t)td * H1 + y) * NAO + (lane & 15);
 #pragma unroll
         for (int a = 0; a < kNX; ++a) xv[a] = src[16 * a];
     };
-    int c = c0 + wave;
-    if (c < c1 && wave < min(NW, ntd)) fetch(c, xva);
+    const int nwe = min(NW, nq);
+    const bool active = wave < nwe;
+    if (active && c0 + wave < c1) fetch(c0 + wave, xva);
     using V4 = typename std::conditional<sizeof(RO) == 4, float4, double2>::type;
     constexpr int NV = (int)((size_t)LINE * sizeof(RO) / 16);
     auto load_line = [&](int y) {          // (all threads) coefficients of line y -> slot y & 1
@@ -606,57 +667,56 @@ k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
         V4* dst = reinterpret_cast<V4*>(scoef + (size_t)(y & 1) * LINE);
         for (int i = threadIdx.x; i < NV; i += THREADS) dst[i] = src[i];
     };
-    int ylo = c0 / ntd;
+    int ylo = c0 / nq;
     load_line(ylo);
     load_line(ylo + 1);
-    for (int i = threadIdx.x; i < Q * 64; i += THREADS) swr[i] = twk[NJ * 64 + i];
+    for (int i = threadIdx.x; i < Q * L; i += THREADS) swr[i] = twk[NJ * L + i];
     cx<double> wjr[WJREG ? NJ : 1];
     if constexpr (WJREG) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) wjr[j] = twk[j * 64 + lane];
+        for (int j = 0; j < NJ; ++j) wjr[j] = twk[j * L + k2];
     }
     __syncthreads();
-    auto line = [&](int c, const cx<double>* xv) {
-        const int y = c / ntd, td = c - y * ntd;
+    auto unit = [&](int c, const cx<double>* xv) {
+        const int y = c / nq, tdr = R * (c - y * nq) + rho;
+        const bool valid = tdr < ntd;
+        const int td = valid ? tdr : ntd - 1;
         const int task = td / ndir;
         const double r0m53 = tp[task].r0m53, delta = tp[task].inv_l0sq - kEps0;
         const double spv = sp[td];
         cx<double> wl[WJREG ? 1 : NJ];
         if constexpr (!WJREG) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) wl[j] = twk[j * 64 + lane];
+            for (int j = 0; j < NJ; ++j) wl[j] = twk[j * L + k2];
         }
-        series_line<N, RO>(xv, WJREG ? wjr : wl, swr, scoef + (size_t)(y & 1) * LINE, r0m53, delta, spv, scale2,
-                           D0t + ((size_t)td * H1 + y) * N + lane,
-                           dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, lane, dbg);
+        series_line<N, RO, L>(xv, WJREG ? wjr : wl, swr, scoef + (size_t)(y & 1) * LINE, r0m53, delta, spv, scale2,
+                              D0t + ((size_t)td * H1 + y) * N + k2,
+                              dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, valid, lane, dbg);
     };
     // every wave runs the same number of rounds (the barriers below are met by all of them); a round
-    // is one line per active wave: c = cb + wave.  (With fewer tasks than waves a round would span more
-    // than two y: only ntd waves work then.)
-    const int nwe = min(NW, ntd);
+    // is one unit per active wave: c = cb + wave.  (With fewer units per y than waves a round would
+    // span more than two y: only nq waves work then.)
     auto new_y = [&](int cb) {
-        const int yb = cb / ntd;                 // the y of wave 0's line: uniform over the workgroup
-        if (yb != ylo) {                         // (yb = ylo + 1: a round is at most ntd lines long)
+        const int yb = cb / nq;                  // the y of wave 0's unit: uniform over the workgroup
+        if (yb != ylo) {                         // (yb = ylo + 1: a round is at most nq units long)
             __syncthreads();                     // nobody reads line ylo any more
             for (int yy = ylo + 2; yy <= yb + 1; ++yy) load_line(yy);
             ylo = yb;
             __syncthreads();
         }
     };
-    const bool active = wave < nwe;
-    c = c0 + wave;
     for (int cb = c0; cb < c1; cb += 2 * nwe) {
         new_y(cb);
         {
             const int c = cb + wave;
             if (active && c + nwe < c1 && !(dbg & 1)) fetch(c + nwe, xvb);
-            if (active && c < c1) line(c, xva);
+            if (active && c < c1) unit(c, xva);
         }
         if (cb + nwe < c1) {
             new_y(cb + nwe);
             const int c = cb + nwe + wave;
             if (active && c + nwe < c1 && !(dbg & 1)) fetch(c + nwe, xva);
-            if (active && c < c1) line(c, xvb);
+            if (active && c < c1) unit(c, xvb);
         }
     }
 }
@@ -717,9 +777,9 @@ k_dphi_series1(const cx<double>* __restrict__ T, const double* __restrict__ sp,
 #pragma unroll
             for (int j = 0; j < NJ; ++j) wl[j] = twk[j * 64 + lane];
         }
-        series_line<N, RO>(xv, WJREG ? wjr : wl, swr, scoef, r0m53, delta, spv, scale2,
-                           D0t + ((size_t)td * H1 + y) * N + lane,
-                           dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, lane, dbg);
+        series_line<N, RO, 64>(xv, WJREG ? wjr : wl, swr, scoef, r0m53, delta, spv, scale2,
+                               D0t + ((size_t)td * H1 + y) * N + lane,
+                               dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, true, lane, dbg);
     };
     constexpr int STEP = THREADS / 64;
     while (td < td_end) {
@@ -769,16 +829,21 @@ void launch_dmin16(hipStream_t s, int N, int ntd, const float* d_dlin, float* d_
     hipLaunchKernelGGL(k_dmin16, dim3((H1 + 15) / 16, ntd), dim3(128), 0, s, H1, N / 32, d_dlin, d_dline, d_dblk);
 }
 
+// the twiddle buffer: the table for 64 lanes per line (K_PATCH_ROWS, K_DPHI_SERIES1), then the one for
+// series_lanes<N>() lanes per line (K_DPHI_SERIES)
 size_t series_twiddle_bytes(int N) {
     size_t n = 0;
-    DISPATCH_N(N, { n = (size_t)(fold_nj<NN / 64>() + NN / 64) * 64 * sizeof(cx<double>); })
+    DISPATCH_N(N, { n = (twiddle_entries<NN, 64>() + twiddle_entries<NN, series_lanes<NN>()>()) * sizeof(cx<double>); })
     return n;
 }
 
 void launch_series_twiddles(hipStream_t s, int N, const void* d_tw64, void* d_twk) {
     DISPATCH_N(N, {
-        hipLaunchKernelGGL((k_series_twiddles<NN>), dim3(fold_nj<NN / 64>() + NN / 64), dim3(64), 0, s,
+        constexpr int L = series_lanes<NN>();
+        hipLaunchKernelGGL((k_series_twiddles<NN, 64>), dim3(fold_nj<NN / 64>() + NN / 64), dim3(64), 0, s,
                            (const cx<double>*)d_tw64, (cx<double>*)d_twk);
+        hipLaunchKernelGGL((k_series_twiddles<NN, L>), dim3(fold_nj<NN / L>() + NN / L), dim3(64), 0, s,
+                           (const cx<double>*)d_tw64, (cx<double>*)d_twk + twiddle_entries<NN, 64>());
     })
 }
 
@@ -797,14 +862,21 @@ void launch_series_coef(hipStream_t s, int N, const double* d_planes, void* d_co
 
 void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const double* d_aotab,
                   double cfit, const void* d_twk, double* d_P, void* d_T, double* d_sp, bool f64) {
-    const dim3 ggrid((NAO * NAO + 255) / 256, ntd);
+    const dim3 ggrid((NAO * NAO + 255) / 256, ntd / ndir);
     if (f64)
         hipLaunchKernelGGL(k_patch_gen<true>, ggrid, dim3(256), 0, s, ndir, d_tp, d_aotab, cfit, d_P);
     else
         hipLaunchKernelGGL(k_patch_gen<false>, ggrid, dim3(256), 0, s, ndir, d_tp, d_aotab, cfit, d_P);
     DISPATCH_N(N, {
-        hipLaunchKernelGGL((k_patch_rows<NN>), dim3(NAO / (4 * rows_per_wave<NN>()), ntd), dim3(256), 0, s, (const double*)d_P,
-                           (const cx<double>*)d_twk, (cx<double>*)d_T, d_sp);
+        constexpr int L = series_lanes<NN>(), NQ = NAO * L / 64;        // passes (of 64 / L rows) per td
+        // passes per workgroup: at least one per wave, and around a thousand workgroups in all
+        int nb = (1024 + ntd - 1) / ntd;
+        if (nb > NQ / 4) nb = NQ / 4;
+        if (nb < 1) nb = 1;
+        const int qb = (NQ + nb - 1) / nb;
+        nb = (NQ + qb - 1) / qb;
+        hipLaunchKernelGGL((k_patch_rows<NN>), dim3(nb, ntd), dim3(256), 0, s, (const double*)d_P,
+                           (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), (cx<double>*)d_T, d_sp, qb);
     })
 }
 
@@ -833,7 +905,7 @@ void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* 
                 allow_smem((k_dphi_series<NN, double>), sm);
                 hipLaunchKernelGGL((k_dphi_series<NN, double>), dim3(env_wg > 0 ? env_wg : ncu), dim3(series_threads<NN, double>()), sm, s,
                                    (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, (const double*)d_coef,
-                                   (const cx<double>*)d_twk, scale2, (double*)d_D0t, d_dlin, d_zero, env_dbg);
+                                   (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), scale2, (double*)d_D0t, d_dlin, d_zero, env_dbg);
             } else {
                 constexpr size_t sm = series1_smem<NN, double>();
                 allow_smem((k_dphi_series1<NN, double>), sm);
@@ -847,7 +919,7 @@ void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* 
             allow_smem((k_dphi_series<NN, float>), sm);
             hipLaunchKernelGGL((k_dphi_series<NN, float>), dim3(env_wg > 0 ? env_wg : ncu), dim3(series_threads<NN, float>()), sm, s,
                                (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, (const float*)d_coef,
-                               (const cx<double>*)d_twk, scale2, (float*)d_D0t, d_dlin, d_zero, env_dbg);
+                               (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), scale2, (float*)d_D0t, d_dlin, d_zero, env_dbg);
         }
     })
 }
