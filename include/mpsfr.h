@@ -159,6 +159,26 @@ int mpsfr_reconstruct_multi(mpsfr_ctx* const* ctxs, int nctx, int ntask, const d
 int mpsfr_fit_stamps(mpsfr_ctx* ctx, int nstamp, const double* stamps, double* fit_out,
                      int on_device);
 
+/* The stages of the path as the reference exports them (muse_psfr/__init__.py:16: `from .psfrec import *`),
+ * for a caller that holds its own PSD or its own stamps.  Host buffers, synchronous, float64; the same
+ * kernels as mpsfr_reconstruct entered or left at another stage.
+ *
+ * mpsfr_simul_psd      simul_psd_wfm (psfrec.py:36-151) for one (seeing, GL, L0): psd_out [npsflin^2][dim][dim],
+ *                      centred (DC at [dim/2][dim/2]) and in the reference's units (times (0.5 1000 / 2 pi)^2,
+ *                      psfrec.py:151).  Arguments as for mpsfr_reconstruct.
+ * mpsfr_psf_from_psd   psf_muse (psfrec.py:644-686): psd [ndir][dim][dim] as above -- ANY real image, not only
+ *                      the model's: every row is transformed -- to psf_out [nl][dimpsf][dimpsf], the stamps
+ *                      BEFORE the convolutions (mean over the ndir directions, normalised to sum 1).
+ * mpsfr_convolve_stamps  convolve_final_psf (psfrec.py:874-930): psf_in [ntask][nl][dimpsf][dimpsf] convolved
+ *                      with each task's tip-tilt Moffat kernel and the instrument's, into psf_out. */
+int mpsfr_simul_psd(mpsfr_ctx* ctx, double seeing, double gl, double l0, int three_lgs, const double h[2],
+                    double wind_speed, int npsflin, const uint8_t* mask_rec, const uint8_t* mask_res,
+                    double* psd_out);
+int mpsfr_psf_from_psd(mpsfr_ctx* ctx, int ndir, const double* psd, int nl, const double* lbda_nm,
+                       double* psf_out);
+int mpsfr_convolve_stamps(mpsfr_ctx* ctx, int ntask, const double* seeing, const double* gl, const double* l0,
+                          int nl, const double* lbda_nm, const double* psf_in, double* psf_out);
+
 /* Block until every call made so far has finished (and hand over the results of every
  * asynchronous host-output call). */
 int mpsfr_sync(mpsfr_ctx* ctx);

@@ -69,6 +69,12 @@ def load():
     lib.mpsfr_reconstruct_multi.restype = C.c_int
     lib.mpsfr_fit_stamps.argtypes = [p, C.c_int, p, p, C.c_int]
     lib.mpsfr_fit_stamps.restype = C.c_int
+    lib.mpsfr_simul_psd.argtypes = [p, C.c_double, C.c_double, C.c_double, C.c_int, dp, C.c_double, C.c_int, u8p, u8p, dp]
+    lib.mpsfr_simul_psd.restype = C.c_int
+    lib.mpsfr_psf_from_psd.argtypes = [p, C.c_int, dp, C.c_int, dp, dp]
+    lib.mpsfr_psf_from_psd.restype = C.c_int
+    lib.mpsfr_convolve_stamps.argtypes = [p, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp]
+    lib.mpsfr_convolve_stamps.restype = C.c_int
     lib.mpsfr_sync.argtypes = [p]
     lib.mpsfr_sync.restype = C.c_int
     lib.mpsfr_last_ticket.argtypes = [p]
@@ -102,7 +108,8 @@ def load():
 
 
 EXPORTS = ['mpsfr_create', 'mpsfr_destroy', 'mpsfr_last_error', 'mpsfr_set_option',
-           'mpsfr_reconstruct', 'mpsfr_reconstruct_multi', 'mpsfr_fit_stamps', 'mpsfr_sync', 'mpsfr_last_ticket', 'mpsfr_wait',
+           'mpsfr_reconstruct', 'mpsfr_reconstruct_multi', 'mpsfr_fit_stamps', 'mpsfr_simul_psd', 'mpsfr_psf_from_psd',
+           'mpsfr_convolve_stamps', 'mpsfr_sync', 'mpsfr_last_ticket', 'mpsfr_wait',
            'mpsfr_stream', 'mpsfr_wait_event',
            'mpsfr_host_time', 'mpsfr_debug_fetch',
            'mpsfr_profile_count', 'mpsfr_profile_name', 'mpsfr_profile_get',
@@ -262,6 +269,47 @@ class Context:
             self._h, seeing.size, _dptr(seeing), _dptr(gl), _dptr(l0), _u8ptr(three), _dptr(hh),
             float(wind_speed), int(npsflin), lbda.size, _dptr(lbda), _u8ptr(mrec), _u8ptr(mres),
             C.c_void_p(psf_ptr), C.c_void_p(sum_ptr), C.c_void_p(fit_ptr), 1))
+
+    def simul_psd(self, seeing, gl, l0, three_lgs=False, h=(100, 10000), wind_speed=None, npsflin=1, masks=None):
+        """simul_psd_wfm (psfrec.py:36-151): (npsflin^2, dim, dim) PSD, centred, reference units."""
+        if wind_speed is None:
+            wind_speed = float(np.full_like(np.array(h), 12.5)[0])      # psfrec.py:61
+        hh = np.ascontiguousarray(h, dtype=np.float64)
+        mrec = mres = None
+        if masks is not None:
+            mrec = np.ascontiguousarray(masks[0]).astype(np.uint8).reshape(-1)
+            mres = np.ascontiguousarray(masks[1]).astype(np.uint8).reshape(-1)
+        out = np.empty((int(npsflin) ** 2, self.dim, self.dim))
+        _check(self.lib.mpsfr_simul_psd(self._h, float(seeing), float(gl), float(l0), int(bool(three_lgs)), _dptr(hh),
+                                        float(wind_speed), int(npsflin), _u8ptr(mrec), _u8ptr(mres), _dptr(out)))
+        return out
+
+    def psf_from_psd(self, psd, lbda):
+        """psf_muse (psfrec.py:644-686): PSD (dim, dim) or (ndir, dim, dim) -> (nl, 40, 40) stamps before the
+        convolutions."""
+        psd = np.ascontiguousarray(psd, dtype=np.float64)
+        if psd.ndim == 2:
+            psd = psd[None]
+        if psd.shape[1:] != (self.dim, self.dim):
+            raise ValueError('the PSD must be %d x %d for this context' % (self.dim, self.dim))
+        lbda = np.ascontiguousarray(np.atleast_1d(lbda), dtype=np.float64)
+        out = np.empty((lbda.size, self.dimpsf, self.dimpsf))
+        _check(self.lib.mpsfr_psf_from_psd(self._h, psd.shape[0], _dptr(psd), lbda.size, _dptr(lbda), _dptr(out)))
+        return out
+
+    def convolve_stamps(self, lbda, seeing, gl, l0, psf):
+        """convolve_final_psf (psfrec.py:874-930) on (ntask, nl, 40, 40) stamps (or (nl, 40, 40) for one task)."""
+        lbda = np.ascontiguousarray(np.atleast_1d(lbda), dtype=np.float64)
+        seeing = np.ascontiguousarray(np.atleast_1d(seeing), dtype=np.float64)
+        gl = np.ascontiguousarray(np.atleast_1d(gl), dtype=np.float64)
+        l0 = np.ascontiguousarray(np.atleast_1d(l0), dtype=np.float64)
+        st = np.ascontiguousarray(psf, dtype=np.float64)
+        single = st.ndim == 3
+        st = st.reshape(seeing.size, lbda.size, self.dimpsf, self.dimpsf)
+        out = np.empty_like(st)
+        _check(self.lib.mpsfr_convolve_stamps(self._h, seeing.size, _dptr(seeing), _dptr(gl), _dptr(l0), lbda.size,
+                                              _dptr(lbda), _dptr(st), _dptr(out)))
+        return out[0] if single else out
 
     def fit_stamps(self, stamps):
         st = np.ascontiguousarray(stamps, dtype=np.float64).reshape(-1, self.dimpsf, self.dimpsf)

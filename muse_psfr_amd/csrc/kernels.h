@@ -82,6 +82,13 @@ void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const do
 // (f64: D / the telescope OTF are double; the minima are rounded down, the maxima up)
 void launch_dmin(hipStream_t s, int N, int ntd, const void* d_D0t, float* d_dline, float* d_dblk,
                  bool f64 = false);
+// Stage-level entry points (stage_a.hip): the PSD of one task as an image [ndir][N][N] (centred, in the
+// reference's units: `unit` = (lambda_ref 1000 / 2 pi)^2), and the structure function of an arbitrary
+// PSD image: d_Cm [ndir][N][N/2+1] complex workspace, scale = 2 / L^2 for a PSD in the reference's units.
+void launch_psd_image(hipStream_t s, int N, int ndir, const TaskPar& p, const double* d_aotab, double cfit,
+                      double unit, double* d_psd);
+void launch_dphi_from_psd(hipStream_t s, int N, int ndir, const double* d_psd, void* d_Cm, double scale,
+                          void* d_D0t, bool f64out, const void* d_tw64);
 // Series form of stage A (stage_a2.hip).  d_coef: [N/2+1][N][series_terms] structure functions of the
 // terms of the expansion of the fitting PSD in 1/L0^2 about series_eps0() (launch_series_coef from the
 // fp64 planes [terms][N/2+1][N] that launch_colfft_dphi produced for the basis tasks);

@@ -635,11 +635,20 @@ int mpsfr_wait_event(mpsfr_ctx* c, void* hip_event) {
     return MPSFR_OK;
 }
 
+// Hooks of the stage-level entry points (mpsfr_simul_psd, mpsfr_psf_from_psd, mpsfr_convolve_stamps):
+// the same pipeline, entered or left at another stage.  Host buffers, synchronous, one pipeline pass.
+struct StageIO {
+    double* psd_out = nullptr;        // [ndir][N][N]: leave with the PSD of task 0 (simul_psd_wfm)
+    const double* psd_in = nullptr;   // [ndir][N][N]: the PSD of the one task, instead of the model
+    const double* pre_in = nullptr;   // [ntask][nl][40][40]: stamps before the convolutions, instead of stages A + B
+    bool stop_pre = false;            // psf_out receives the stamps BEFORE the convolutions (psf_muse)
+};
+
 static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const double* gl,
                             const double* l0, const uint8_t* three_lgs, const double h[2],
                             double wind_speed, int npsflin, int nl, const double* lbda_nm,
                             const uint8_t* mask_rec, const uint8_t* mask_res, double* psf_out,
-                            double* psf_sum_out, double* fit_out, int on_device);
+                            double* psf_sum_out, double* fit_out, int on_device, const StageIO& io = StageIO());
 
 int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const double* gl,
                       const double* l0, const uint8_t* three_lgs, const double h[2],
@@ -670,8 +679,10 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
                             const double* l0, const uint8_t* three_lgs, const double h[2],
                             double wind_speed, int npsflin, int nl, const double* lbda_nm,
                             const uint8_t* mask_rec, const uint8_t* mask_res, double* psf_out,
-                            double* psf_sum_out, double* fit_out, int on_device) {
+                            double* psf_sum_out, double* fit_out, int on_device, const StageIO& io) {
     const auto t_enter = std::chrono::steady_clock::now();
+    const bool staged = io.psd_out || io.psd_in || io.pre_in || io.stop_pre;
+    if (staged && on_device != 0) return fail(MPSFR_E_INVALID, "stage-level calls take host buffers");
     if (ntask < 1 || !seeing || !gl || !l0 || !h || !lbda_nm)
         return fail(MPSFR_E_INVALID, "ntask < 1 or NULL input array");
     if (nl < 1 || nl > 4096) return fail(MPSFR_E_INVALID, "nl=%d out of range", nl);
@@ -691,7 +702,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         lp[l].c = -0.5 * k * k;
         lp[l].npixc = npix_crop(lbda_nm[l], c->dimpsf, c->pixscale);
         lp[l].pad = 0;
-        if (lp[l].npixc > N || lp[l].npixc < NS)
+        if (!io.pre_in && !io.psd_out && (lp[l].npixc > N || lp[l].npixc < NS))
             return fail(MPSFR_E_GRID,
                         "lbda=%.3f nm needs a %d-pixel crop, outside [%d, dim=%d] "
                         "(psfrec.py:663-683)", lbda_nm[l], lp[l].npixc, NS, N);
@@ -722,6 +733,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     // the SPARTA front end only lets 8 < L0 < 30 through, psfrec.py:1049-1051); a call with a shorter
     // outer scale takes the full-size transforms.
     bool series = c->stage_a == 2 || (c->stage_a == 1 && (N >= 512 || (N >= 256 && npsflin >= 2)));
+    if (io.psd_in) series = false;
     for (int t = 0; t < ntask; ++t) series = series && tp[t].inv_l0sq <= series_eps_max();
 
     // ---- geometry of the AO tables (psfrec.py:61, 66, 86-93, 99, 154-158, 536-537, 594)
@@ -809,6 +821,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             nch = NLmax;
         TC = (ntask + nch - 1) / nch;
     }
+    if (staged) TC = ntask;                  // stage-level calls: one pass
     if (TC > ntask) TC = ntask;
     const int nchunks = (ntask + TC - 1) / TC;
     // never more lanes than chunks: a lane without a chunk would leave its partial stamp sum
@@ -1073,6 +1086,17 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         HIPCHK(hipEventRecord(c->tables_ready, s0));
         for (int j = 1; j < NL; ++j) HIPCHK(hipStreamWaitEvent(lane_of(j).stream, c->tables_ready, 0));
     }
+    if (io.psd_out) {          // simul_psd_wfm: the PSD of task 0, every direction, as an image
+        const size_t n = (size_t)ndir * N * N;
+        DevBuf img;
+        if ((rc = ensure(c, img, n * sizeof(double)))) return rc;
+        launch_psd_image(s0, N, ndir, tp[0], (const double*)c->aotab.p, cfit, dphi_scale2() * 128.0, (double*)img.p);
+        const hipError_t e1 = hipMemcpyAsync(io.psd_out, img.p, n * sizeof(double), hipMemcpyDeviceToHost, s0);
+        const hipError_t e2 = hipStreamSynchronize(s0);
+        release(img);
+        if (e1 != hipSuccess || e2 != hipSuccess) return fail(MPSFR_E_HIP, "copying the PSD image failed");
+        return MPSFR_OK;
+    }
     int nchunk_lane[mpsfr_ctx::MAX_LANES] = {0, 0, 0, 0};      // by lane position j in this call
     int ci = 0;
     for (int t0 = 0; t0 < ntask; t0 += TC, ++ci) {
@@ -1086,7 +1110,33 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             HIPCHK(hipStreamWaitEvent(ls, c->stagger_ev, 0));
             c->stagger_armed = false;
         }
-        if (series) {
+        if (io.pre_in) {
+            // convolve_final_psf on the caller's stamps: stages A and B are skipped
+            const size_t n = (size_t)tc * nl * per_stamp;
+            if (c->f64) {
+                HIPCHK(hipMemcpyAsync(ln.pre.p, io.pre_in + (size_t)t0 * nl * per_stamp, n * sizeof(double),
+                                      hipMemcpyHostToDevice, ls));
+                HIPCHK(hipStreamSynchronize(ls));
+            } else {
+                std::vector<float> tmp(n);
+                for (size_t i = 0; i < n; ++i) tmp[i] = (float)io.pre_in[(size_t)t0 * nl * per_stamp + i];
+                HIPCHK(hipMemcpyAsync(ln.pre.p, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, ls));
+                HIPCHK(hipStreamSynchronize(ls));
+            }
+        } else if (io.psd_in) {
+            // psf_muse on the caller's PSD (one task, ndir planes, centred, in the reference's units)
+            const size_t n = (size_t)ndir * N * N;
+            DevBuf img, cm;
+            if ((rc = ensure(c, img, n * sizeof(double)))) return rc;
+            if ((rc = ensure(c, cm, (size_t)ndir * N * H1 * 2 * sizeof(double)))) { release(img); return rc; }
+            hipError_t e1 = hipMemcpyAsync(img.p, io.psd_in, n * sizeof(double), hipMemcpyHostToDevice, ls);
+            launch_dphi_from_psd(ls, N, ndir, (const double*)img.p, cm.p, 2.0 / 256.0, ln.D0t.p, c->f64, c->tw64.p);
+            if (mf2 && e1 == hipSuccess) e1 = hipMemsetAsync(ln.msched.p, 0, 17 * sizeof(int), ls);
+            const hipError_t e2 = hipStreamSynchronize(ls);
+            release(img);
+            release(cm);
+            if (e1 != hipSuccess || e2 != hipSuccess) return fail(MPSFR_E_HIP, "the structure function of the PSD failed");
+        } else if (series) {
             {
                 ProfScope ps(c, K_PATCH, ls);
                 launch_patch(ls, N, ntd, ndir, d_tp + t0, (const double*)c->aotab.p, cfit, c->stwk.p,
@@ -1116,7 +1166,9 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             return 0;
         };
         if (stagger_here(1)) return fail(MPSFR_E_HIP, "hipEventRecord failed");
-        if (mf2) {
+        if (io.pre_in) {
+            // (nothing: the stamps are there)
+        } else if (mf2) {
             // thin-wave kernel: block minima (one direction: they are the minima over the directions),
             // then masks and work lists (otf_mfma2.hip); no line bounds needed
             ProfScope ps(c, K_MF_PREP, ls);
@@ -1136,7 +1188,9 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         }
         const int* d_vkeep = prune ? (const int*)ln.vkeep.p : nullptr;
         if (stagger_here(2)) return fail(MPSFR_E_HIP, "hipEventRecord failed");
-        if (mf2) {
+        if (io.pre_in) {
+            // (nothing)
+        } else if (mf2) {
             ProfScope ps(c, K_OTF_MFMA, ls);
             launch_otf_mfma2(ls, N, tc, nl, c->mf_permax, c->ncu, ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
                              c->gtab.p, ln.mown.p, ln.muni.p, ln.msched.p, ln.mpart.p, ln.pre.p,
@@ -1156,6 +1210,24 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             }
             ProfScope ps(c, K_COLPASS, ls);
             launch_colpass(ls, N, tc, nl, ln.Tq.p, c->G.p, ln.pre.p, c->f64, d_vkeep);
+        }
+        if (io.stop_pre) {         // psf_muse: the stamps before the convolutions, as float64
+            const size_t n = (size_t)tc * nl * per_stamp;
+            if (c->f64) {
+                HIPCHK(hipMemcpyAsync(psf_out + (size_t)t0 * nl * per_stamp, ln.pre.p, n * sizeof(double),
+                                      hipMemcpyDeviceToHost, ls));
+                HIPCHK(hipStreamSynchronize(ls));
+            } else {
+                std::vector<float> tmp(n);
+                HIPCHK(hipMemcpyAsync(tmp.data(), ln.pre.p, n * sizeof(float), hipMemcpyDeviceToHost, ls));
+                HIPCHK(hipStreamSynchronize(ls));
+                for (size_t i = 0; i < n; ++i) psf_out[(size_t)t0 * nl * per_stamp + i] = (double)tmp[i];
+            }
+            HIPCHK(hipGetLastError());
+            ++nchunk_lane[j];
+            c->last_chunk_tasks = tc;
+            c->last_lane = (L0 + j) % NLmax;
+            continue;
         }
         // final stamps: straight into the caller's device buffer (double), else a lane workspace --
         // float when the FFT convolution produces them and nobody outside reads them
@@ -1293,6 +1365,52 @@ int mpsfr_reconstruct_multi(mpsfr_ctx* const* ctxs, int nctx, int ntask, const d
             psf_sum_out[e] = t;
         }
     return MPSFR_OK;
+}
+
+int mpsfr_simul_psd(mpsfr_ctx* c, double seeing, double gl, double l0, int three_lgs, const double h[2],
+                    double wind_speed, int npsflin, const uint8_t* mask_rec, const uint8_t* mask_res,
+                    double* psd_out) {
+    if (!c || !psd_out) return fail(MPSFR_E_INVALID, "NULL argument");
+    const uint8_t t3 = three_lgs ? 1 : 0;
+    const double lb = 700.0;                 // (the per-wavelength tables are not used)
+    StageIO io;
+    io.psd_out = psd_out;
+    mpsfr_ctx* cc = c;
+    const unsigned lane_rr0 = cc->lane_rr, stage0 = cc->stage_next;
+    const int rc = reconstruct_impl(c, 1, &seeing, &gl, &l0, &t3, h, wind_speed, npsflin, 1, &lb, mask_rec, mask_res,
+                                    nullptr, nullptr, nullptr, 0, io);
+    if (rc != MPSFR_OK) { cc->lane_rr = lane_rr0; cc->stage_next = stage0; }
+    return rc;
+}
+
+int mpsfr_psf_from_psd(mpsfr_ctx* c, int ndir, const double* psd, int nl, const double* lbda_nm, double* psf_out) {
+    if (!c || !psd || !psf_out) return fail(MPSFR_E_INVALID, "NULL argument");
+    int npl = 0;
+    for (int k = 1; k <= 5; ++k)
+        if (k * k == ndir) npl = k;
+    if (npl == 0) return fail(MPSFR_E_INVALID, "ndir=%d is not the square of 1..5", ndir);
+    const double one = 1.0, half = 0.5, l0 = 20.0, h[2] = {100.0, 10000.0};
+    StageIO io;
+    io.psd_in = psd;
+    io.stop_pre = true;
+    const unsigned lane_rr0 = c->lane_rr, stage0 = c->stage_next;
+    const int rc = reconstruct_impl(c, 1, &one, &half, &l0, nullptr, h, 12.0, npl, nl, lbda_nm, nullptr, nullptr,
+                                    psf_out, nullptr, nullptr, 0, io);
+    if (rc != MPSFR_OK) { c->lane_rr = lane_rr0; c->stage_next = stage0; }
+    return rc;
+}
+
+int mpsfr_convolve_stamps(mpsfr_ctx* c, int ntask, const double* seeing, const double* gl, const double* l0,
+                          int nl, const double* lbda_nm, const double* psf_in, double* psf_out) {
+    if (!c || !psf_in || !psf_out) return fail(MPSFR_E_INVALID, "NULL argument");
+    const double h[2] = {100.0, 10000.0};
+    StageIO io;
+    io.pre_in = psf_in;
+    const unsigned lane_rr0 = c->lane_rr, stage0 = c->stage_next;
+    const int rc = reconstruct_impl(c, ntask, seeing, gl, l0, nullptr, h, 12.0, 1, nl, lbda_nm, nullptr, nullptr,
+                                    psf_out, nullptr, nullptr, 0, io);
+    if (rc != MPSFR_OK) { c->lane_rr = lane_rr0; c->stage_next = stage0; }
+    return rc;
 }
 
 int mpsfr_fit_stamps(mpsfr_ctx* c, int nstamp, const double* stamps, double* fit_out,

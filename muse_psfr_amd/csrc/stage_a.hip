@@ -370,6 +370,85 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpar
 }
 
 // ------------------------------------------------------------------------------------------
+// Stage-level entry points (mpsfr_simul_psd / mpsfr_psf_from_psd; psfrec.py:36-151, :644-686 with
+// :717-722).  Not on the hot path: a caller's PSD is an arbitrary real image, so none of the
+// symmetries of the model hold -- every row is transformed, the columns are gathered with their
+// natural stride.
+// K_PSD_IMAGE: the PSD of a task as the reference returns it: centred (DC at [N/2][N/2]), times
+// (lambda_ref 1000 / 2 pi)^2 (psfrec.py:151), psd[d][row][col].
+// K_PSDMEM_ROWS: Cm[d][r][y] = sum_c psd(r, c) W^(c y), r, c in FFT layout, y in [0, N/2].
+// K_PSDMEM_COLS: D0t[d][y][x] = scale (S00 - Re sum_r Cm[d][r][y] W^(r x)), S00 = Re sum_r Cm[d][r][0].
+// ------------------------------------------------------------------------------------------
+template <int NEWTON>
+__global__ void __launch_bounds__(256) k_psd_image(int N, int ndir, TaskPar p, const double* __restrict__ aotab,
+                                                   double cfit, double unit, double* __restrict__ psd) {
+    const int col = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y, d = blockIdx.z;
+    if (col >= N) return;
+    const int su = row - N / 2, sv = col - N / 2;           // centred image -> signed frequency index
+    const double* tb = aotab + ((size_t)(p.geom * ndir + d) * 3) * (NAO * NAO);
+    const double fit = psd_fit_value<NEWTON>(su, sv, p, cfit);
+    psd[((size_t)d * N + row) * N + col] = unit * psd_with_ao<NEWTON>(fit, su, sv, p, tb);
+}
+
+template <int N>
+constexpr size_t psdmem_smem() { return (size_t)(1 + 2 * LineCfg<N>::SLOTS) * LineCfg<N>::NPAD * sizeof(cx<double>); }
+
+template <int N>
+__global__ void __launch_bounds__((LineCfg<N>::THREADS))
+k_psdmem_rows(const double* __restrict__ psd, cx<double>* __restrict__ Cm, const cx<double>* __restrict__ twg) {
+    using L = LineCfg<N>;
+    constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD, EPT = N / TPR;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
+    cx<double>* bufA = tw + NPAD;
+    cx<double>* bufB = bufA + SLOTS * NPAD;
+    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR, d = blockIdx.y;
+    const int r = blockIdx.x * SLOTS + slot;               // FFT-layout row (N is a multiple of SLOTS)
+    for (int i = threadIdx.x; i < N; i += THREADS) tw[lds_pad(i)] = twg[i];
+    const double* src = psd + ((size_t)d * N + (r + N / 2) % N) * N;
+    cx<double> x[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) x[e] = {src[(t + e * TPR + N / 2) % N], 0.0};
+    __syncthreads();
+    const cx<double>* res = fft_forward_regs<double, N, false>(x, bufA + slot * NPAD, bufB + slot * NPAD, tw, t);
+    cx<double>* dst = Cm + ((size_t)d * N + r) * (N / 2 + 1);
+    for (int y = t; y <= N / 2; y += TPR) dst[y] = res[lds_out<N, 16>(y)];
+}
+
+template <int N, typename RO>
+__global__ void __launch_bounds__((LineCfg<N>::THREADS))
+k_psdmem_cols(const cx<double>* __restrict__ Cm, double scale, RO* __restrict__ D0t,
+              const cx<double>* __restrict__ twg) {
+    using L = LineCfg<N>;
+    constexpr int TPR = L::TPR, SLOTS = L::SLOTS, THREADS = L::THREADS, NPAD = L::NPAD, EPT = N / TPR, H1 = N / 2 + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double sdc[256];
+    cx<double>* tw = reinterpret_cast<cx<double>*>(smem);
+    cx<double>* bufA = tw + NPAD;
+    cx<double>* bufB = bufA + SLOTS * NPAD;
+    const int slot = threadIdx.x / TPR, t = threadIdx.x % TPR, d = blockIdx.y;
+    const int y = blockIdx.x * SLOTS + slot;
+    const bool on = y < H1;
+    const cx<double>* Cd = Cm + (size_t)d * N * H1;
+    for (int i = threadIdx.x; i < N; i += THREADS) tw[lds_pad(i)] = twg[i];
+    // S00: the column y = 0 summed in an order fixed by the launch geometry (every workgroup the same bits)
+    double a = 0.0;
+    for (int r = threadIdx.x; r < N; r += THREADS) a += Cd[(size_t)r * H1].x;
+    sdc[threadIdx.x] = a;
+    cx<double> x[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) x[e] = on ? Cd[(size_t)(t + e * TPR) * H1 + y] : cx<double>{0.0, 0.0};
+    __syncthreads();
+    double dc = 0.0;
+    for (int i = 0; i < THREADS; ++i) dc += sdc[i];
+    const cx<double>* res = fft_forward_regs<double, N, false>(x, bufA + slot * NPAD, bufB + slot * NPAD, tw, t);
+    if (on) {
+        RO* out = D0t + ((size_t)d * H1 + y) * N;
+        for (int xx = t; xx < N; xx += TPR) out[xx] = (RO)(scale * (dc - res[lds_out<N, 16>(xx)].x));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K_DMIN: minima of D for the pruning of the per-wavelength stage, one workgroup per (td, group of
 // 16 lines): dline[td][v] = min_u max(D[v][u], 0) and dblk[td][v / 16][u / 32] = the minimum over
 // the 16 x 32 block (the blocks of K_OTF_MFMA, otf_mfma.hip).  A separate pass over D (just
@@ -640,5 +719,32 @@ void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const do
     })
 }
 
+
+void launch_psd_image(hipStream_t s, int N, int ndir, const TaskPar& p, const double* d_aotab, double cfit,
+                      double unit, double* d_psd) {
+    const dim3 grid((N + 255) / 256, N, ndir);
+    hipLaunchKernelGGL(k_psd_image<2>, grid, dim3(256), 0, s, N, ndir, p, d_aotab, cfit, unit, d_psd);
+}
+
+void launch_dphi_from_psd(hipStream_t s, int N, int ndir, const double* d_psd, void* d_Cm, double scale,
+                          void* d_D0t, bool f64out, const void* d_tw64) {
+    DISPATCH_N(N, {
+        constexpr size_t sm = psdmem_smem<NN>();
+        constexpr int SL = LineCfg<NN>::SLOTS;
+        allow_smem((k_psdmem_rows<NN>), sm);
+        hipLaunchKernelGGL((k_psdmem_rows<NN>), dim3(NN / SL, ndir), dim3(LineCfg<NN>::THREADS), sm, s, d_psd,
+                           (cx<double>*)d_Cm, (const cx<double>*)d_tw64);
+        const dim3 grid((NN / 2 + 1 + SL - 1) / SL, ndir);
+        if (f64out) {
+            allow_smem((k_psdmem_cols<NN, double>), sm);
+            hipLaunchKernelGGL((k_psdmem_cols<NN, double>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
+                               (const cx<double>*)d_Cm, scale, (double*)d_D0t, (const cx<double>*)d_tw64);
+        } else {
+            allow_smem((k_psdmem_cols<NN, float>), sm);
+            hipLaunchKernelGGL((k_psdmem_cols<NN, float>), grid, dim3(LineCfg<NN>::THREADS), sm, s,
+                               (const cx<double>*)d_Cm, scale, (float*)d_D0t, (const cx<double>*)d_tw64);
+        }
+    })
+}
 
 }  // namespace mpsfr

@@ -241,6 +241,48 @@ def fit_psf_cube(lbda, psfcube, *, pixscale=0.2, precision='mixed', device=0):
     return _make_table(_fit_columns(lbda, ctx.fit_stamps(data), pixscale))
 
 
+def simul_psd_wfm(Cn2, h, seeing, L0, zenith=0., plot=False, npsflin=1, dim=1280, three_lgs_mode=False,
+                  verbose=True, *, precision='mixed', cutoff_masks='host', device=0):
+    """Residual phase PSD of the MUSE wide-field mode for each evaluation direction (psfrec.py:36-151):
+    (npsflin**2, dim, dim) float64, DC at [dim/2, dim/2], in nm^2 m^2 like the reference's.  Two layers
+    (`Cn2` = their weights, normalised here as psfrec.py:57-58 does); the zenith angle only rescales r0
+    (psfrec.py:108, 183-187)."""
+    Cn2 = np.array(Cn2, dtype=float)
+    if Cn2.size != 2 or len(h) != 2:
+        raise ValueError('exactly two layers are supported (psfrec.py:66 fixes two wind directions)')
+    Cn2 = Cn2 / Cn2.sum()
+    if verbose and three_lgs_mode:
+        logger.info('Using three lasers mode')
+    if plot:
+        direction_perf(npsflin, plot=True)
+    seeing_los = float(seeing) / np.cos(np.deg2rad(zenith)) ** (3 / 5)
+    ctx = get_context(dim, 0.2, 40, precision, device)
+    return ctx.simul_psd(seeing_los, Cn2[0], L0, three_lgs_mode, h, npsflin=npsflin,
+                         masks=_resolve_masks(cutoff_masks))
+
+
+def psf_muse(psd, lambdamuse, *, pixscale=0.2, precision='mixed', device=0):
+    """PSF stamps (nl, 40, 40) at the wavelengths `lambdamuse` [nm] from a residual PSD (psfrec.py:644-686:
+    structure function, OTF, crop to the field of the stamp, bilinear sampling; the mean over the
+    directions when the PSD has three dimensions).  Any real PSD image of a supported size."""
+    psd = np.asarray(psd, dtype=float)
+    ctx = get_context(psd.shape[-1], pixscale, 40, precision, device)
+    try:
+        return ctx.psf_from_psd(psd, np.atleast_1d(np.asarray(lambdamuse, dtype=float)))
+    except MpsfrError as e:
+        if e.code == E_GRID:
+            raise ValueError(str(e)) from None
+        raise
+
+
+def convolve_final_psf(lbda, seeing, GL, L0, psf, *, pixscale=0.2, precision='mixed', device=0):
+    """Convolve with the tip-tilt and MUSE PSFs to get the final PSF (psfrec.py:874-930).  `psf`:
+    (nl, 40, 40)."""
+    psf = np.asarray(psf, dtype=float)
+    ctx = get_context(128, pixscale, psf.shape[-1], precision, device)
+    return ctx.convolve_stamps(lbda, seeing, GL, L0, psf)
+
+
 def compute_psf(lbda, seeing, GL, L0, npsflin=1, h=(100, 10000), three_lgs_mode=False,
                 verbose=True, *, dim=1280, dimpsf=40, pixscale=0.2, precision='mixed',
                 cutoff_masks='host', device=0):

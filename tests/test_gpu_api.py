@@ -6,7 +6,8 @@ import os
 import numpy as np
 import pytest
 
-from conftest import H
+from conftest import H, rel_err, record_margin
+import psfr_oracle as O
 
 pytestmark = pytest.mark.gpu
 
@@ -316,3 +317,52 @@ def test_asynchronous_host_outputs_equal_the_blocking_call(api):
         np.testing.assert_array_equal(p3.wait()['fit'], want[2]['fit'])
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_stage_level_functions_against_the_reference_goldens(api, golden, ref_masks, prec):
+    """simul_psd_wfm / psf_muse / convolve_final_psf of the reference (psfrec.py:36, 644, 874) as entry
+    points of their own, on the reference's grid: the PSD against the fixtures G2 holds of it (centre
+    block, two rows, total: captured from the real reference), then chained -- PSD -> stamps -> final
+    stamps -- against G2's pre_* / fin_* stamps, one direction and nine."""
+    g = golden('g2_native1280')
+    lb = g['lbda']
+    tol = dict(f64=1e-9, mixed=2e-5)[prec]
+    for k in (0, 1, 4):
+        see, gl_, l0_, npl, three = g['meta'][k]
+        npl = int(npl)
+        psd = api.simul_psd_wfm([gl_, 1 - gl_], H, see, l0_, npsflin=npl, three_lgs_mode=bool(three),
+                                cutoff_masks=ref_masks, precision=prec, verbose=False)
+        assert psd.shape == (npl * npl, 1280, 1280)
+        c = 640
+        assert rel_err(psd[:, c - 48:c + 48, c - 48:c + 48], g['psd_centre_%d' % k]) < 1e-12
+        assert rel_err(psd[:, 0, :], g['psd_row0_%d' % k]) < 1e-12
+        assert rel_err(psd[:, c, :], g['psd_rowc_%d' % k]) < 1e-12
+        np.testing.assert_allclose(psd.sum(axis=(1, 2)), g['psd_sum_%d' % k], rtol=1e-11)
+        pre = api.psf_muse(psd if npl > 1 else psd[0], lb, precision=prec)
+        assert rel_err(pre, g['pre_%d' % k]) < tol
+        fin = api.convolve_final_psf(lb, see, gl_, l0_, pre, precision=prec)
+        assert rel_err(fin, g['fin_%d' % k]) < tol
+        # the convolution alone, on the reference's own stamps
+        fin2 = api.convolve_final_psf(lb, see, gl_, l0_, g['pre_%d' % k], precision=prec)
+        assert rel_err(fin2, g['fin_%d' % k]) < (1e-10 if prec == 'f64' else 2e-6)
+        record_margin('stage_functions_%s' % prec, stamp_pre=rel_err(pre, g['pre_%d' % k]), stamp=rel_err(fin, g['fin_%d' % k]))
+
+
+def test_psf_muse_takes_any_psd(api):
+    """psf_muse on a PSD that is NOT the model's (no symmetry between the rows su and -1-su, a tilted
+    ridge, another zenith angle): against the oracle's reference-shaped psf_stamps on a 256^2 grid."""
+    dim, ps = 256, api.grid_pixscale(256)
+    lb = np.array([480.0, 700.0, 930.0])
+    tabs = O.ao_tables(H, False, 1, exact_masks=True)
+    psd = O.residual_psd([0.6, 0.4], H, 0.9, 18.0, 1, dim, False, tables=tabs)[0]
+    yy, xx = np.mgrid[:dim, :dim] - dim // 2
+    psd = psd * (1.0 + 0.3 * np.exp(-((xx - 7) ** 2 + (yy + 3) ** 2) / 50.0) + 0.2 * (np.hypot(xx, yy) > 20) * (xx > 2 * yy))
+    want = O.psf_stamps_refshaped(psd[None], lb, 40, ps)
+    for prec, tol in (('f64', 1e-9), ('mixed', 2e-5)):
+        got = api.psf_muse(psd, lb, pixscale=ps, precision=prec)
+        assert rel_err(got, want) < tol, prec
+    # the zenith angle only rescales r0 (psfrec.py:108, 183-187)
+    a = api.simul_psd_wfm([0.6, 0.4], H, 0.9, 18.0, zenith=30.0, dim=256, cutoff_masks='exact', verbose=False)
+    b = O.residual_psd([0.6, 0.4], H, 0.9 / np.cos(np.deg2rad(30.0)) ** 0.6, 18.0, 1, 256, False, tables=tabs)
+    assert rel_err(a, b) < 1e-12
