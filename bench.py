@@ -33,6 +33,8 @@ PRIME_STEPS = 1200           # untimed, before the warm-up steps (~0.3 s: the GP
 PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector / fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak (same guide)
 PEAK_HBM_GBPS = 8000.0
+PEAK_FP64_TFLOPS = 78.6        # fp64 vector (= fp64 matrix) peak (same guide)
+PROFILE_ROUND = 'r04'          # profiles/<round>_kernel_util.json, _traffic.json, _parity_margins.json
 PIPELINE_HAS_TQ = True       # FFT form of the per-wavelength stage: the sampled first-pass lines go through HBM
 sys.path.insert(0, ROOT)
 
@@ -87,18 +89,33 @@ def fft_flops(dim):
     return 5.0 * dim * math.log2(dim)
 
 
-def hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac=1.0, has_tq=True):
-    """Algorithmic HBM bytes of one step of the RESTRUCTURED pipeline (DESIGN.md sections 3, 5):
+def series_form(dim, npsflin):
+    """The library's automatic choice of stage A (mpsfr_set_option "stage_a" = 1)."""
+    sa = os.environ.get('MPSFR_STAGE_A')
+    if sa is not None and int(float(sa)) != 1:
+        return int(float(sa)) == 2
+    return dim >= 512 or (dim >= 256 and npsflin >= 2)
+
+
+def hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac=1.0, has_tq=True, series=False):
+    """Algorithmic HBM bytes of one step of the pipeline AS BUILT (DESIGN.md sections 3, 5):
     every intermediate written once and read once by the next kernel, inputs/outputs once."""
     H1, NR = dim // 2 + 1, dim // 2 + 40
     p = 4 if mixed else 8
     td = rows * ndir
     psf = rows * nl
     b = {}
-    b['C (fp64 row transforms of the PSD, write + read)'] = 2 * td * 16 * H1 * NR
-    b['D_phi0 (write + read)'] = 2 * td * p * H1 * dim
-    if mixed and not has_tq:
-        b['D_phi0 (read once more: minima for the pruning)'] = td * p * H1 * dim
+    if series:
+        b['P (corrected-zone patch 80 x 80 fp64, write + read)'] = 2 * td * 80 * 80 * 8
+        b['T (row transforms of the patch, 80 x (N/2+1) complex fp64, write + read)'] = 2 * td * 16 * 80 * H1
+        b['series coefficients (one read per launch)'] = H1 * dim * (16 if mixed else 64)
+        b['D_phi0 (write + read)'] = 2 * td * p * H1 * dim
+        b['block minima per line (write + read)'] = 2 * td * H1 * (dim // 32) * 4
+    else:
+        b['C (fp64 row transforms of the PSD, write + read)'] = 2 * td * 16 * H1 * NR
+        b['D_phi0 (write + read)'] = 2 * td * p * H1 * dim
+        if mixed and not has_tq:
+            b['D_phi0 (read once more: minima for the pruning)'] = td * p * H1 * dim
     if PIPELINE_HAS_TQ and has_tq:
         b['Tq (sampled first-pass lines that survive the pruning, write + read)'] = int(
             2 * psf * 2 * p * 21 * H1 * kept_frac)
@@ -167,6 +184,16 @@ def rehearse(a, rank, world, bounds, total_rows, strong):
     dist.barrier()
     dist.destroy_process_group()
     return 0 if ok else 1
+
+
+def series_flops_per_line(dim):
+    """Algorithmic fp64 flops of one line (td, y) of K_DPHI_SERIES: the fold of the 80
+    complex inputs with the lanes' twiddles (80 complex multiply-adds x L lanes) and the Q-point in-lane
+    transforms (5 Q log2 Q / 2: real outputs only) over L lanes; the polynomial, the conversions and the
+    block minima are not counted."""
+    L = 16 if dim <= 256 else (32 if dim == 512 else 64)
+    Q = dim // L
+    return 80 * 8 * L + 2.5 * Q * math.log2(Q) * L
 
 
 def load_json(name):
@@ -429,6 +456,77 @@ def main():
                 'max_abs_err_beta': float(np.abs(fitg[:n, :, 4] - cpu_fits[:, :, 4]).max()),
                 'tolerance': 1e-4}
 
+    def kernel_times(Rx, nsteps):
+        """ms per launch of every kernel slot of the library (HIP events around every launch, on the
+        stream it is launched on), over `nsteps` untimed steps of the runner."""
+        for c in Rx['ctxs']:
+            c.set_option('profile_only', -1)
+            c.set_option('profile', 1)
+            c.profile_reset()
+        for _ in range(nsteps):
+            Rx['step']()
+        Rx['fence']()
+        tot = Rx['profile_sum']()
+        for c in Rx['ctxs']:
+            c.set_option('profile', 0)
+        return {k: v[0] / v[1] for k, v in tot.items() if v[1]}, {k: v[1] / nsteps for k, v in tot.items() if v[1]}
+
+    def probe_mf_work(ctx, lbv):
+        """Tile steps of the matrix-core stage per row, from one call over the first rows."""
+        nprobe = min(rows, 32)
+        pf = torch.zeros((nprobe, nl, NFIT), dtype=torch.float64, device=dev)
+        psm = torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev)
+        sp = slice(sl.start, sl.start + nprobe)
+        try:
+            ctx.reconstruct_device(lbv, see[sp], gl[sp], l0[sp], three[:nprobe], h, 12.0, a.npsflin,
+                                   None, None, psm.data_ptr(), pf.data_ptr())
+            ctx.sync()
+            w = ctx.debug_fetch('mf_work', (5,))
+        except Exception:
+            return None
+        return {'tile_steps_per_row': w[0] / nprobe, 'tiles_per_row': w[1] / nprobe,
+                'tile_steps_unpruned_per_row': w[2] / nprobe,
+                'full_steps_per_row': w[3] / nprobe, 'mid_steps_per_row': w[4] / nprobe}
+
+    def mfma_roofline(mfw, ntask_launch, ms_launch, dimv):
+        """`roofline` object of the matrix-core per-wavelength stage for a launch over ntask_launch rows."""
+        nmfma = (mfw['full_steps_per_row'] * 9 + mfw['mid_steps_per_row'] * 6) * ntask_launch
+        tiles = mfw['tiles_per_row'] * ntask_launch
+        fl = nmfma * 2 * 16 * 16 * 32 + tiles * 24 * 2 * 16 * 16 * 16
+        nmt = (dimv // 2 + 1 + 15) // 16
+        fl32_all = (mfw['tile_steps_unpruned_per_row'] * 2 * 16 * 32 * 42 + nmt * nl * 2 * 2 * 16 * 21 * 21) * ntask_launch
+        t = ms_launch * 1e-3
+        return {'bound': 'mfma', 'kernel': 'otf_mfma (k_otf_mfma2 + k_mf_finish)', 'achieved': round(fl / t / 1e12, 2),
+                'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(fl / t / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                'avg_launch_ms': round(ms_launch, 4), 'executed_flops_per_launch': fl,
+                'tile_steps_executed_fraction': round(mfw['tile_steps_per_row'] / mfw['tile_steps_unpruned_per_row'], 4),
+                'unpruned_fp32_equivalent': {
+                    'flops_per_launch': fl32_all, 'rate_TFLOPs': round(fl32_all / t / 1e12, 1),
+                    'over_fp32_peak': round(fl32_all / t / 1e12 / PEAK_FP32_TFLOPS, 3),
+                    'note': 'the whole contraction of the launch (every block of the half plane, one product per '
+                            'element, no padding) per second: work that does not shrink when the pruning improves, '
+                            'so the figure only rises when the launch gets faster (> 1 x the fp32 peak = what the '
+                            'pruning and the matrix cores buy over a dense fp32 evaluation)'}}
+
+    def stage_a_roofline(ktimes, ntd_launch, dimv, mixedv):
+        """fp64 vector-pipe roofline of the series form of stage A (K_DPHI_SERIES), when it ran."""
+        if 'dphi_series' not in ktimes:
+            return None
+        lines = ntd_launch * (dimv // 2 + 1)
+        fl = lines * series_flops_per_line(dimv)
+        t = ktimes['dphi_series'] * 1e-3
+        byt = lines * (80 * 16 + dimv * (4 if mixedv else 8) + (dimv // 32) * 4)
+        return {'bound': 'valu_fp64', 'kernel': 'dphi_series (k_dphi_series)', 'achieved': round(fl / t / 1e12, 2),
+                'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(fl / t / 1e12 / PEAK_FP64_TFLOPS, 4),
+                'avg_launch_ms': round(ktimes['dphi_series'], 4), 'flops_per_line': series_flops_per_line(dimv),
+                'lines_per_launch': lines,
+                'sustained_fp64_peak_note': 'a loop of independent v_fma_f64 on every SIMD of this chip sustains 58 TFLOP/s '
+                                            '(the clock falls to ~1.45 GHz under fp64 load: scripts/ubench/dpp64.hip, '
+                                            'profiles/%s_ubench_dpp64.txt)' % PROFILE_ROUND,
+                'hbm_GBps': round(byt / t / 1e9, 1), 'hbm_frac': round(byt / t / 1e9 / PEAK_HBM_GBPS, 4),
+                'model': '80 complex multiply-adds x L lanes + in-lane Q-point transforms (real outputs) per line; '
+                         'bytes: 1280 in + 4 N (8 N in f64 mode) out + N/8 of block minima per line'}
+
     # the steps are queued from Python: a cyclic-GC pass in the middle of the timed loop (tens of
     # ms with torch loaded) would starve the GPU, so collection is parked for the measurement
     gc.collect()
@@ -584,10 +682,24 @@ def main():
             Rn['step']()
         dtn, _ = Rn['timed'](nnat)
         fitn = Rn['fits'][0].cpu().numpy()
+        ktn, kln = kernel_times(Rn, 6)
+        mfn = probe_mf_work(Rn['ctxs'][0], lb_nat)
         Rn['close']()
         native = {'value': round(rows * nl * nnat / dtn, 1), 'unit': 'PSFs/sec', 'steps': nnat,
                   'ms_per_step': round(dtn / nnat * 1e3, 4),
-                  'workload': '%d rows x %d lambda (490-930 nm), 1280^2 grid, pixscale 0.2' % (rows, nl)}
+                  'workload': '%d rows x %d lambda (490-930 nm), 1280^2 grid, pixscale 0.2' % (rows, nl),
+                  'kernel_ms_per_launch': {k: round(v, 4) for k, v in ktn.items()}}
+        if mfn is not None and 'otf_mfma' in ktn:
+            native['roofline'] = mfma_roofline(mfn, rows / kln['otf_mfma'], ktn['otf_mfma'], 1280)
+            mb = hbm_model_bytes(1280, nl, rows, 1, True, has_tq=False, series=series_form(1280, 1))
+            native['roofline']['hbm'] = {'model_bytes_per_step': sum(mb.values()), 'model_terms': mb,
+                                         'achieved_GBps': round(sum(mb.values()) / (dtn / nnat) / 1e9, 1),
+                                         'peak': PEAK_HBM_GBPS,
+                                         'frac': round(sum(mb.values()) / (dtn / nnat) / 1e9 / PEAK_HBM_GBPS, 4)}
+            native['roofline']['hbm_frac'] = native['roofline']['hbm']['frac']
+        sa = stage_a_roofline(ktn, rows / kln.get('dphi_series', 1), 1280, True)
+        if sa:
+            native['roofline_stage_a'] = sa
         if nat_fits is not None:
             n = nat_fits.shape[0]
             native['parity'] = {'rows_checked': n, 'wavelengths_checked': [float(lb_nat[i]) for i in nat_sel],
@@ -598,6 +710,7 @@ def main():
     # ---- the dominant kernel with one call in flight (no other kernel beside it on the GPU): what
     # the kernel itself achieves, as opposed to its share of the GPU in the pipelined run
     alone_ms = None
+    kt_alone, kl_alone = {}, {}
     if mixed and a.profile_steps != 0:
         R4 = make_runner(a.precision, 1, streams=1)
         for _ in range(8):
@@ -608,6 +721,7 @@ def main():
         R4['timed'](40)
         ms4, n4 = R4['profile_sum']()[dominant]
         alone_ms = ms4 / max(n4, 1)
+        kt_alone, kl_alone = kernel_times(R4, 20)       # every kernel, one call in flight
         R4['close']()
 
     # ---- the same workload with every line of the half plane transformed (prune_eps = 0)
@@ -635,9 +749,38 @@ def main():
             R2['step']()
         dt2, _ = R2['timed'](nf64)
         fit2 = R2['fits'][0].cpu().numpy()
+        kt2, kl2 = kernel_times(R2, 6)
+        vk2 = None
+        try:
+            vk2 = R2['ctxs'][0].debug_fetch('vkeep', (min(rows, 512), (nl + 1) // 2)) if rows <= 512 else None
+        except Exception:
+            vk2 = None
         R2['close']()
         f64 = {'value': round(total_rows * nl * nf64 / dt2, 1), 'unit': 'PSFs/sec',
-               'steps': nf64, 'ms_per_step': round(dt2 / nf64 * 1e3, 4), 'dtype': 'f64'}
+               'steps': nf64, 'ms_per_step': round(dt2 / nf64 * 1e3, 4), 'dtype': 'f64',
+               'kernel_ms_per_launch': {k: round(v, 4) for k, v in kt2.items()}}
+        if 'otf_rowfft' in kt2:
+            # dominant kernel of the f64 mode: the fp64 line transforms of the per-wavelength stage (two
+            # wavelengths per complex N-point transform, pruned lines not counted) + two exponentials per
+            # OTF element and pair; bounded by the fp64 vector pipe (profiles/r04_pmc_f64.txt)
+            kf = float(vk2.mean() / (dim // 2 + 1)) if vk2 is not None else 1.0
+            ntr = rows / kl2['otf_rowfft'] * (dim // 2 + 1) * ((nl + 1) // 2) * kf
+            fl = ntr * (fft_flops(dim) + 2 * dim * 21)
+            t = kt2['otf_rowfft'] * 1e-3
+            f64['roofline'] = {'bound': 'valu_fp64', 'kernel': 'otf_rowfft (k_otf_rowfft<double>)',
+                               'achieved': round(fl / t / 1e12, 2), 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(fl / t / 1e12 / PEAK_FP64_TFLOPS, 4), 'avg_launch_ms': round(kt2['otf_rowfft'], 4),
+                               'lines_transformed_fraction': round(kf, 4),
+                               'model': 'lines transformed x (5 N log2 N + 2 N exponentials of ~21 fp64 operations)',
+                               'traffic': None}
+            mb = hbm_model_bytes(dim, nl, rows, a.npsflin ** 2, False, kept_frac=kf, series=series_form(dim, a.npsflin))
+            f64['roofline']['hbm'] = {'model_bytes_per_step': sum(mb.values()),
+                                      'achieved_GBps': round(sum(mb.values()) / (dt2 / nf64) / 1e9, 1), 'peak': PEAK_HBM_GBPS,
+                                      'frac': round(sum(mb.values()) / (dt2 / nf64) / 1e9 / PEAK_HBM_GBPS, 4)}
+            f64['roofline']['hbm_frac'] = f64['roofline']['hbm']['frac']
+        sa2 = stage_a_roofline(kt2, rows * a.npsflin ** 2 / kl2.get('dphi_series', 1), dim, False)
+        if sa2:
+            f64['roofline_stage_a'] = sa2
         if cpu_fits is not None and rank == 0:
             f64['parity'] = parity_block(fit2, cpu_fits.shape[0])
     gc.enable()
@@ -687,12 +830,11 @@ def main():
                          'ceil(nl/2) per row) x 5 N log2 N flops per complex N-point transform; HIP events on '
                          'the launch stream, timed region')
         achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0
-        util_name = next((n for n in ('r03_kernel_util.json', 'r02_kernel_util.json', 'r01_kernel_util.json')
-                          if load_json(n)), None)
+        util_name = next((n for n in (PROFILE_ROUND + '_kernel_util.json',) if load_json(n)), None)
         util = load_json(util_name) if util_name else {}
         kkey = 'k_otf_mfma' if mf_work is not None else 'k_' + dominant
         u = next((v for k, v in util.items() if k.startswith(kkey)), None) if (dim, mixed) == (512, True) else None
-        tj = load_json('r03_traffic.json') or load_json('r02_traffic.json') or load_json('r01_traffic.json')
+        tj = load_json(PROFILE_ROUND + '_traffic.json')
         traffic = None
         traffic_step = None
         if tj and (dim, nl, rows, a.npsflin, mixed) == (512, 35, 100, 1, True):
@@ -702,7 +844,9 @@ def main():
                 traffic = per_unit * units_per_launch
             traffic_step = sum((v.get('fetch_kib', 0) + v.get('write_kib', 0)) * 1024.0
                                for v in tj['kernels'].values())
-        model = hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac, has_tq=mf_work is None)
+        series = 'dphi_series' in prof_all or ('dphi_series' in prof)
+        model = hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac, has_tq=mf_work is None,
+                                series=series or (not prof_all and series_form(dim, a.npsflin)))
         if tj and 'model_extra' in tj:          # e.g. an intermediate the current pipeline keeps
             model.update(tj['model_extra'])
         model_step = float(sum(model.values()))
@@ -755,7 +899,23 @@ def main():
                          'valu_issue': u and u.get('valu_issue'),
                          'mfma_busy': u and u.get('mfma_busy'),
                          'lds_busy': u and u.get('lds_array_busy'),
-                         'pmc_source': u and 'profiles/%s (scripts/prof_table.sh, one step in flight)' % util_name},
+                         'pmc_source': u and 'profiles/%s (scripts/prof_table.sh, one step in flight)' % util_name,
+                         # the whole step against HBM (the pipe north_star names): algorithmic bytes of the
+                         # pipeline as built over the step time; `alone_frac`: the kernel with nothing beside it
+                         'hbm_frac': round(model_step / step_s / 1e9 / PEAK_HBM_GBPS, 4),
+                         'achieved_GBps': round(model_step / step_s / 1e9, 1),
+                         'alone_frac': alone_ms and round(flops / (alone_ms * 1e-3) / 1e12 / peak, 4),
+                         'unpruned_fp32_equivalent': (mf_work is not None) and mfma_roofline(
+                             mf_work, tasks_per_launch, avg_s * 1e3, dim)['unpruned_fp32_equivalent'],
+                         'hbm': {'model_bytes_per_step': model_step, 'model_terms': model,
+                                 'traffic_bytes_per_step': traffic_step,
+                                 'waste_ratio': traffic_step and round(traffic_step / model_step, 3),
+                                 'achieved_GBps': round(model_step / step_s / 1e9, 1), 'peak': PEAK_HBM_GBPS,
+                                 'frac': round(model_step / step_s / 1e9 / PEAK_HBM_GBPS, 4),
+                                 'note': 'the pipeline moves few bytes by construction (the N^2 row transforms of the PSD '
+                                         'are gone with the series form of stage A, the N^2 PSF is never formed): it is '
+                                         'bound by the fp64 vector pipe (stage A), the feeding of the matrix cores '
+                                         '(per-wavelength stage) and the vector pipe of the fit, not by HBM'}},
             # whole step against HBM: algorithmic bytes of the restructured pipeline, what the
             # PMC counters saw, and the ratio (wasted re-reads / padding / fp64 intermediates)
             'roofline_hbm': {'model_bytes_per_step': model_step, 'model_terms': model,
@@ -770,6 +930,9 @@ def main():
             'kernel_ms_per_step': {k: round(v[0] / max(nprof, 1), 4) for k, v in prof_all.items() if v[1]},
             'kernel_ms_per_step_note': 'second, untimed pass of %d steps with every launch '
                                        'bracketed by HIP events' % nprof,
+            # stage A in its series form (this round's kernel): fp64 vector pipe, one call in flight
+            'roofline_stage_a': kt_alone and stage_a_roofline(kt_alone, rows * ndir / kl_alone.get('dphi_series', 1), dim, mixed),
+            'kernel_ms_one_call_in_flight': {k: round(v, 4) for k, v in kt_alone.items()},
             'fit_iterations': {'mean': round(float(fitg[:, :, 7].mean()), 2),
                                'max': int(fitg[:, :, 7].max())},
             'prime_steps': a.prime,
@@ -807,13 +970,23 @@ def main():
         if cpu is not None:
             out['cpu_baseline'] = cpu
             out['parity'] = parity_block(fitg, cpu_fits.shape[0])
-            pm = load_json('r03_parity_margins.json')
+            pm = load_json(PROFILE_ROUND + '_parity_margins.json')
             if pm and 'wide_parameter_range_vs_oracle' in pm.get('tests', {}):
                 # worst case of tests/test_gpu_parity.py::test_wide_parameter_range_against_the_oracle
                 # (seeing 0.3-2.5", GL 0.02-0.98, L0 8.1-29.9 m), recorded by the test run on the GPU
                 out['parity']['wide_parameter_range'] = dict(
-                    pm['tests']['wide_parameter_range_vs_oracle'], source='profiles/r03_parity_margins.json')
+                    pm['tests']['wide_parameter_range_vs_oracle'], source='profiles/%s_parity_margins.json' % PROFILE_ROUND)
             out['speedup_vs_cpu_baseline'] = round(out['value'] / cpu['value'], 1)
+            # the port is slower than the real reference (profiles/r02_cpu_calibration.json: the reference
+            # against the port on this workload's grid, one process): the speed-up against the reference
+            ratio = None
+            cal = cpu.get('calibration') or {}
+            for cfg in cal.get('configs', []):
+                if cfg.get('dim') == dim and cfg.get('reference_over_port_time'):
+                    ratio = 1.0 / float(cfg['reference_over_port_time'])       # reference PSFs/s over the port's
+            if ratio:
+                out['speedup_vs_reference_calibrated'] = round(out['value'] / (cpu['value'] * ratio), 1)
+                out['speedup_calibration'] = {'reference_psfs_per_s_over_port': round(ratio, 3), 'source': 'profiles/r02_cpu_calibration.json'}
         print(json.dumps(out), flush=True)
     if xchg:
         dist.destroy_process_group()

@@ -145,7 +145,9 @@ void mf2_groups(int nl, int permax, int* per, int* ngr);
 // (d_dminb = nullptr: no pruning); d_sched[0..16] must be zero (launch_colfft_dphi does that)
 void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const LamPar* d_lp,
                     const float* d_dminb, const float* d_tlb, float thr, float thr_mid, void* d_own,
-                    void* d_uni, void* d_sched);
+                    void* d_uni, void* d_sched, const float* d_dlin = nullptr);
+// (d_dlin: instead of d_dminb, the per-line block minima of launch_dphi_series -- the minimum over a
+// block's 16 lines is then taken by the kernel itself and launch_dmin16 is not needed)
 // K_OTF_MFMA2 (persistent, ncu workgroups) + K_MF_FINISH
 void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int ncu, const void* d_D0t,
                       const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,

@@ -1172,11 +1172,13 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             // thin-wave kernel: block minima (one direction: they are the minima over the directions),
             // then masks and work lists (otf_mfma2.hip); no line bounds needed
             ProfScope ps(c, K_MF_PREP, ls);
-            if (prune && series) launch_dmin16(ls, N, ntd, (const float*)ln.dlin.p, (float*)ln.dmin.p, (float*)ln.dblk.p);
-            else if (prune) launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p);
-            launch_mf_prep(ls, N, tc, nl, c->mf_permax, d_lp, prune ? (const float*)ln.dblk.p : nullptr, (const float*)c->tlb.p,
-                           thr_blk, (prune && c->mf_floor) ? (float)c->mf_mid_log2 : -1.0e30f, ln.mown.p,
-                           ln.muni.p, ln.msched.p);
+            // (series form of stage A: the per-line minima go straight to K_MF_PREP, which takes the minimum
+            // over a block's 16 lines itself -- K_DMIN16 was 6 us of latency at 512^2, 13 at 1280^2)
+            const bool from_lines = prune && series && !io.psd_in;
+            if (prune && !from_lines) launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p);
+            launch_mf_prep(ls, N, tc, nl, c->mf_permax, d_lp, (prune && !from_lines) ? (const float*)ln.dblk.p : nullptr,
+                           (const float*)c->tlb.p, thr_blk, (prune && c->mf_floor) ? (float)c->mf_mid_log2 : -1.0e30f,
+                           ln.mown.p, ln.muni.p, ln.msched.p, from_lines ? (const float*)ln.dlin.p : nullptr);
         } else if (prune) {
             ProfScope ps(c, mf ? K_MF_PREP : K_VKEEP, ls);
             if (series) launch_dmin16(ls, N, ntd, (const float*)ln.dlin.p, (float*)ln.dmin.p, (float*)ln.dblk.p);

@@ -81,6 +81,8 @@ struct MaskArgs {
     int N, nl, per, ngr;
     const LamPar* lp;
     const float* dminb;      // [ntask][nmt][nks] block minima of D (K_DMIN), or nullptr = no pruning
+    const float* dlin;       // instead of dminb: [ntask][N/2+1][nks] minima per LINE and block of 32 columns
+                             // (K_DPHI_SERIES); the minimum over a block's 16 lines is taken here
     const float* tlb;        // [nmt][nks]
     float thr, thr_mid;
     u64* own;
@@ -103,7 +105,17 @@ __global__ void __launch_bounds__(64 * 8) k_mf_prep(const MaskArgs a) {
     const int N = a.N, nks = mf_nks(N), nmt = mf_nmt(N), nsw = (nmt + kT2 - 1) / kT2;
     const int nthr = 64 * a.per;
     for (int e = threadIdx.x; e < nmt * nks; e += nthr) {
-        s_dm[e] = a.dminb != nullptr ? a.dminb[(size_t)task * nmt * nks + e] : 0.f;
+        float dm = 0.f;
+        if (a.dlin != nullptr) {
+            const int mt = e / nks, ks = e - mt * nks, H1 = N / 2 + 1;
+            const float* src = a.dlin + ((size_t)task * H1 + MTL * mt) * nks + ks;
+            const int nline = min(MTL, H1 - MTL * mt);
+            dm = __builtin_inff();
+            for (int i = 0; i < nline; ++i) dm = fminf(dm, src[(size_t)i * nks]);
+        } else if (a.dminb != nullptr) {
+            dm = a.dminb[(size_t)task * nmt * nks + e];
+        }
+        s_dm[e] = dm;
         s_tb[e] = a.tlb[e];
     }
     const int l = grp * a.per + w;
@@ -114,8 +126,9 @@ __global__ void __launch_bounds__(64 * 8) k_mf_prep(const MaskArgs a) {
     u64 myf = 0, mym = 0;                    // lane mt keeps the two words of m-tile mt
     for (int mt = 0; mt < nmt; ++mt) {
         const float e = fmaf(c2, s_dm[mt * nks + kk], s_tb[mt * nks + kk]);
-        const bool keep = lv && lane < nks && (a.dminb == nullptr || e > a.thr);
-        const bool full = keep && (a.dminb == nullptr || e > a.thr_mid);
+        const bool nopr = a.dminb == nullptr && a.dlin == nullptr;
+        const bool keep = lv && lane < nks && (nopr || e > a.thr);
+        const bool full = keep && (nopr || e > a.thr_mid);
         const u64 bf = __ballot(full), bm = __ballot(keep && !full);
         if (lane == mt) { myf = bf; mym = bm; }
     }
@@ -696,8 +709,9 @@ SchedPtrs sched_ptrs(void* d_sched, int ntask, int nl) {
 // does that).  d_dminb = nullptr: no pruning.
 void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const LamPar* d_lp,
                     const float* d_dminb, const float* d_tlb, float thr, float thr_mid, void* d_own,
-                    void* d_uni, void* d_sched) {
+                    void* d_uni, void* d_sched, const float* d_dlin) {
     MaskArgs a;
+    a.dlin = d_dlin;
     a.N = N; a.nl = nl;
     mf2_groups(nl, permax, &a.per, &a.ngr);
     a.lp = d_lp; a.dminb = d_dminb; a.tlb = d_tlb;

@@ -84,10 +84,36 @@ __device__ __forceinline__ R exp_scale(R c) {
     if constexpr (FAST && sizeof(R) == 4) return c * (R)1.44269504088896340736;
     else return c;
 }
+// exp(x) in fp64 for the OTF of the f64 mode (x = c D <= 0 up to rounding): n = rint(x log2 e),
+// r = x - n ln 2 in two pieces (|r| <= 0.347), the Taylor polynomial of degree 12 (next term 1.7e-16),
+// v_ldexp_f64.  21 instructions where the library's exp -- with its table, its special cases and its
+// error-free reductions for the full range -- took half of K_OTF_ROWFFT<double> (71 % vector-pipe busy,
+// two exponentials per OTF element and wavelength pair: profiles/r04_pmc_f64.txt).  Results below the
+// normal range underflow through ldexp like the library's; NaN stays NaN.
+__device__ __forceinline__ double exp_otf64(double x) {
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);      // ln 2, high part (the reduction is exact for |n| < 2^10)
+    r = fma(n, -1.90821492927058770002e-10, r);             // low part
+    double p = 1.0 / 479001600.0;
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)fmax(n, -2000.0));
+}
+
 template <typename R, bool FAST>
 __device__ __forceinline__ R exp_sel(R x) {
     if constexpr (sizeof(R) == 8) {
-        return exp(x);
+        return exp_otf64(x);
     } else if constexpr (FAST) {
         return __builtin_amdgcn_exp2f(x);
     } else {

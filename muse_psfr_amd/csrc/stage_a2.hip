@@ -378,10 +378,30 @@ __global__ void __launch_bounds__(256) k_patch_gen(int ndir, const TaskPar* __re
     const double g2 = (double)(su * su + sv * sv) * (1.0 / 256.0);
     const double vk = 0.0229 * p.r0m53 * pow_m11_6<NEWTON>(g2 + p.inv_l0sq);        // :569-571
     const int o = ia * NAO + ib;
-    for (int d = 0; d < ndir; ++d) {
-        const double* tb = aotab + ((size_t)(p.geom * ndir + d) * 3) * (NAO * NAO);
+    if (ndir == 1) {
+        const double* tb = aotab + ((size_t)p.geom * 3) * (NAO * NAO);
         const double ao = vk * (p.cn2_0 * tb[o] + p.cn2_1 * tb[NAO * NAO + o]) + tb[2 * NAO * NAO + o];
-        P[((size_t)task * ndir + d) * (NAO * NAO) + pix] = fmax(fit, ao) - fit;         // :149
+        P[(size_t)task * (NAO * NAO) + pix] = fmax(fit, ao) - fit;                           // :149
+        return;
+    }
+    // (nine directions at a time with their table loads in flight together: one at a time, the loop was
+    // nine memory latencies long)
+    for (int d0 = 0; d0 < ndir; d0 += 9) {
+        double t0[9], t1[9], t2[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int d = min(d0 + i, ndir - 1);
+            const double* tb = aotab + ((size_t)(p.geom * ndir + d) * 3) * (NAO * NAO);
+            t0[i] = tb[o];
+            t1[i] = tb[NAO * NAO + o];
+            t2[i] = tb[2 * NAO * NAO + o];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            if (d0 + i >= ndir) break;
+            const double ao = vk * (p.cn2_0 * t0[i] + p.cn2_1 * t1[i]) + t2[i];
+            P[((size_t)task * ndir + d0 + i) * (NAO * NAO) + pix] = fmax(fit, ao) - fit;     // :149
+        }
     }
 }
 
@@ -396,7 +416,13 @@ __global__ void __launch_bounds__(256) k_patch_gen(int ndir, const TaskPar* __re
 // ------------------------------------------------------------------------------------------
 // L = series_lanes<N>() lanes per row, R = 64 / L rows per wave and pass (one per group of L lanes),
 // Q = N / L: the same fold and in-lane transform as K_DPHI_SERIES, with a real input and a complex
-// output of which y <= N/2 is kept.  A workgroup takes `qb` passes of one td, its four waves in turn.
+// output of which y <= N/2 is kept.  A workgroup takes `qb` groups of 4 R adjacent rows of one td, one
+// group per pass, a row set per wave.  The results of a pass meet in an LDS tile [y][4 R rows] and leave
+// as pieces of 4 R x 16 bytes (64 bytes at 1280^2, 256 at 256^2): a lane storing its own y values wrote
+// 16-byte pieces 1280 bytes apart, and at 1280^2 that alone took 25 of the kernel's 45 us.
+template <int N>
+constexpr size_t patch_rows_smem() { return (size_t)(N / 2 + 1) * (4 * (64 / series_lanes<N>()) + 1) * sizeof(cx<double>); }
+
 template <int N>
 __global__ void __launch_bounds__(256) k_patch_rows(const double* __restrict__ P,
                                                     const cx<double>* __restrict__ twk,
@@ -404,20 +430,23 @@ __global__ void __launch_bounds__(256) k_patch_rows(const double* __restrict__ P
     constexpr int L = series_lanes<N>(), R = 64 / L, Q = N / L, H1 = N / 2 + 1, NJ = fold_nj<Q>();
     constexpr bool WJREG = NJ <= 10;
     constexpr int NY = Q / 2 + 1;                        // values y = L k1 + k2 <= N/2 of a lane
-    constexpr int NQ = NAO / R;                          // passes per td
+    constexpr int RG = 4 * R, RS = RG + 1;               // rows per pass of the workgroup; padded tile row
+    constexpr int NG = NAO / RG;                         // passes per td
+    extern __shared__ __align__(16) unsigned char smem[];
+    cx<double>* tile = reinterpret_cast<cx<double>*>(smem);          // [H1][RS]
     __shared__ double sred[256];
     const int td = blockIdx.y;
     const double* Pg = P + (size_t)td * (NAO * NAO);
     const int lane = threadIdx.x & 63, rho = lane / L, k2 = lane & (L - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q_end = min(NQ, ((int)blockIdx.x + 1) * qb);
-    int q = blockIdx.x * qb + wave;
+    const int g_end = min(NG, ((int)blockIdx.x + 1) * qb);
+    int g = blockIdx.x * qb;
     double xa[kNX], xb[kNX];
-    auto fetch = [&](int qq, double* xr) {
+    auto fetch = [&](int gg, double* xr) {
 #pragma unroll
-        for (int a = 0; a < kNX; ++a) xr[a] = Pg[(R * qq + rho) * NAO + 16 * a + (lane & 15)];
+        for (int a = 0; a < kNX; ++a) xr[a] = Pg[(RG * gg + R * wave + rho) * NAO + 16 * a + (lane & 15)];
     };
-    if (q < q_end) fetch(q, xa);
+    if (g < g_end) fetch(g, xa);
     if (blockIdx.x == 0) {      // sum of the patch, in an order fixed by the launch geometry
         double a = 0.0;
         for (int i = threadIdx.x; i < NAO * NAO; i += 256) a += Pg[i];
@@ -436,7 +465,7 @@ __global__ void __launch_bounds__(256) k_patch_rows(const double* __restrict__ P
     }
 #pragma unroll
     for (int r = 1; r < Q; ++r) wr[r] = twk[(NJ + r) * L + k2];
-    auto pass = [&](int qq, const double* xr) {
+    auto pass = [&](int gg, const double* xr) {
         cx<double> S[Q];
         {
             constexpr int GC = Q % 5 == 0 ? 5 : (Q < 4 ? Q : 4);
@@ -452,19 +481,25 @@ __global__ void __launch_bounds__(256) k_patch_rows(const double* __restrict__ P
             });
         }
         dftq<Q>(S);
-        cx<double>* Tt = T + ((size_t)td * H1 + k2) * NAO + R * qq + rho;
 #pragma unroll
         for (int k1 = 0; k1 < NY; ++k1)
-            if (L * k1 + k2 <= N / 2) Tt[(size_t)L * k1 * NAO] = S[k1];
+            if (L * k1 + k2 <= N / 2) tile[(L * k1 + k2) * RS + R * wave + rho] = S[k1];
+        __syncthreads();
+        cx<double>* Tt = T + (size_t)td * H1 * NAO + RG * gg;
+        for (int e = threadIdx.x; e < H1 * RG; e += 256) {
+            const int y = e / RG, i = e % RG;
+            Tt[(size_t)y * NAO + i] = tile[y * RS + i];
+        }
+        __syncthreads();
     };
-    while (q < q_end) {
-        if (q + 4 < q_end) fetch(q + 4, xb);
-        pass(q, xa);
-        q += 4;
-        if (q >= q_end) break;
-        if (q + 4 < q_end) fetch(q + 4, xa);
-        pass(q, xb);
-        q += 4;
+    while (g < g_end) {
+        if (g + 1 < g_end) fetch(g + 1, xb);
+        pass(g, xa);
+        g += 1;
+        if (g >= g_end) break;
+        if (g + 1 < g_end) fetch(g + 1, xa);
+        pass(g, xb);
+        g += 1;
     }
 }
 
@@ -617,8 +652,11 @@ __device__ __forceinline__ void series_line(const cx<double>* xv, const cx<doubl
 // the next line's into the slot that fell free (a share is 1 - 3 lines y long: a handful of barriers
 // per launch).  [first form: one workgroup per (y, group of tasks) -- 2056 workgroups at 512^2, whose
 // set-up and +-1 task imbalance cost 20 of its 50 us]
+#ifndef MPSFR_SERIES_THREADS
+#define MPSFR_SERIES_THREADS 512
+#endif
 template <int N, typename RO>
-constexpr int series_threads() { return N <= 128 ? 256 : 512; }
+constexpr int series_threads() { return N <= 128 ? 256 : MPSFR_SERIES_THREADS; }
 template <int N, typename RO>
 constexpr size_t series_smem() {
     return 2 * (size_t)N * SeriesCfg<RO>::K * sizeof(RO) + (size_t)N * sizeof(cx<double>);
@@ -629,7 +667,7 @@ constexpr bool series_fits() { return series_smem<N, RO>() <= 160 * 1024; }
 // A "unit" is what a wave takes at a time: the R = 64 / L lines (y; td = R q + rho, rho < R) of one y
 // and R consecutive tasks; units in y-major order, c = y nq + q with nq = ceil(ntd / R).
 template <int N, typename RO>
-__global__ void __launch_bounds__((series_threads<N, RO>()))
+__global__ void __launch_bounds__((series_threads<N, RO>()), (512 / series_threads<N, RO>() > 1 ? 2 : 1))
 k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
               const TaskPar* __restrict__ tp, int ndir, int ntd, const RO* __restrict__ coef,
               const cx<double>* __restrict__ twk, double scale2, RO* __restrict__ D0t,
@@ -868,14 +906,16 @@ void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, 
     else
         hipLaunchKernelGGL(k_patch_gen<false>, ggrid, dim3(256), 0, s, ndir, d_tp, d_aotab, cfit, d_P);
     DISPATCH_N(N, {
-        constexpr int L = series_lanes<NN>(), NQ = NAO * L / 64;        // passes (of 64 / L rows) per td
-        // passes per workgroup: at least one per wave, and around a thousand workgroups in all
+        constexpr int NG = NAO * series_lanes<NN>() / 256;       // passes (of 4 x 64 / L rows) per td
+        // passes per workgroup: around a thousand workgroups in all
         int nb = (1024 + ntd - 1) / ntd;
-        if (nb > NQ / 4) nb = NQ / 4;
+        if (nb > NG) nb = NG;
         if (nb < 1) nb = 1;
-        const int qb = (NQ + nb - 1) / nb;
-        nb = (NQ + qb - 1) / qb;
-        hipLaunchKernelGGL((k_patch_rows<NN>), dim3(nb, ntd), dim3(256), 0, s, (const double*)d_P,
+        const int qb = (NG + nb - 1) / nb;
+        nb = (NG + qb - 1) / qb;
+        constexpr size_t sm = patch_rows_smem<NN>();
+        allow_smem((k_patch_rows<NN>), sm);
+        hipLaunchKernelGGL((k_patch_rows<NN>), dim3(nb, ntd), dim3(256), sm, s, (const double*)d_P,
                            (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), (cx<double>*)d_T, d_sp, qb);
     })
 }
