@@ -109,9 +109,13 @@ __global__ void __launch_bounds__(64 * 8) k_mf_prep(const MaskArgs a) {
         if (a.dlin != nullptr) {
             const int mt = e / nks, ks = e - mt * nks, H1 = N / 2 + 1;
             const float* src = a.dlin + ((size_t)task * H1 + MTL * mt) * nks + ks;
-            const int nline = min(MTL, H1 - MTL * mt);
-            dm = __builtin_inff();
-            for (int i = 0; i < nline; ++i) dm = fminf(dm, src[(size_t)i * nks]);
+            const int last = min(MTL, H1 - MTL * mt) - 1;
+            float v[MTL];
+#pragma unroll
+            for (int i = 0; i < MTL; ++i) v[i] = src[(size_t)min(i, last) * nks];      // all sixteen in flight
+            dm = v[0];
+#pragma unroll
+            for (int i = 1; i < MTL; ++i) dm = fminf(dm, v[i]);
         } else if (a.dminb != nullptr) {
             dm = a.dminb[(size_t)task * nmt * nks + e];
         }

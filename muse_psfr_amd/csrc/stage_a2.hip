@@ -520,7 +520,7 @@ template <int N, typename RO, int L>
 __device__ __forceinline__ void series_line(const cx<double>* xv, const cx<double>* wjp,
                                             const cx<double>* swr, const RO* scoef, double r0m53,
                                             double delta, double spv, double scale2, RO* dst, float* dlin,
-                                            bool valid, int lane, int dbg) {
+                                            bool valid, int lane) {
     constexpr int Q = N / L, K = SeriesCfg<RO>::K;
     const int k2 = lane & (L - 1);
     double xr[kNX], xi[kNX];
@@ -530,10 +530,7 @@ __device__ __forceinline__ void series_line(const cx<double>* xv, const cx<doubl
         xi[a] = xv[a].y;
     }
     double out[Q];
-    if (dbg & 2) {
-#pragma unroll
-        for (int k1 = 0; k1 < Q; ++k1) out[k1] = xr[k1 % kNX] + k1;
-    } else {
+    {
         auto wrf = [&](int r) { return swr[r * L + k2]; };
         if constexpr (Q == 2) {
             cx<double> S[2];
@@ -561,10 +558,6 @@ __device__ __forceinline__ void series_line(const cx<double>* xv, const cx<doubl
                 },
                 out);
         }
-    }
-    if (dbg & 4) {
-        if (out[0] == 1.2345) dst[0] = 0;
-        return;
     }
     // Block minima for the pruning of the per-wavelength stage, while the values are in registers
     // (K_DMIN read all of D back for them: 12 us at 512^2, 69 us at 1280^2): the minimum of max(D, 0)
@@ -671,7 +664,7 @@ __global__ void __launch_bounds__((series_threads<N, RO>()), (512 / series_threa
 k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
               const TaskPar* __restrict__ tp, int ndir, int ntd, const RO* __restrict__ coef,
               const cx<double>* __restrict__ twk, double scale2, RO* __restrict__ D0t,
-              float* __restrict__ dlin, int* __restrict__ zero17, int dbg) {
+              float* __restrict__ dlin, int* __restrict__ zero17) {
     constexpr int L = series_lanes<N>(), R = 64 / L, Q = N / L, H1 = N / 2 + 1, K = SeriesCfg<RO>::K;
     constexpr int THREADS = series_threads<N, RO>(), NW = THREADS / 64, NJ = fold_nj<Q>();
     constexpr bool WJREG = NJ <= 10;         // the twiddles W_L^(j k2) of a lane in registers
@@ -700,7 +693,7 @@ k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
     using V4 = typename std::conditional<sizeof(RO) == 4, float4, double2>::type;
     constexpr int NV = (int)((size_t)LINE * sizeof(RO) / 16);
     auto load_line = [&](int y) {          // (all threads) coefficients of line y -> slot y & 1
-        if (y > N / 2 || (dbg & 8)) return;
+        if (y > N / 2) return;
         const V4* src = reinterpret_cast<const V4*>(coef + (size_t)y * LINE);
         V4* dst = reinterpret_cast<V4*>(scoef + (size_t)(y & 1) * LINE);
         for (int i = threadIdx.x; i < NV; i += THREADS) dst[i] = src[i];
@@ -729,7 +722,7 @@ k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
         }
         series_line<N, RO, L>(xv, WJREG ? wjr : wl, swr, scoef + (size_t)(y & 1) * LINE, r0m53, delta, spv, scale2,
                               D0t + ((size_t)td * H1 + y) * N + k2,
-                              dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, valid, lane, dbg);
+                              dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, valid, lane);
     };
     // every wave runs the same number of rounds (the barriers below are met by all of them); a round
     // is one unit per active wave: c = cb + wave.  (With fewer units per y than waves a round would
@@ -747,13 +740,13 @@ k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
         new_y(cb);
         {
             const int c = cb + wave;
-            if (active && c + nwe < c1 && !(dbg & 1)) fetch(c + nwe, xvb);
+            if (active && c + nwe < c1) fetch(c + nwe, xvb);
             if (active && c < c1) unit(c, xva);
         }
         if (cb + nwe < c1) {
             new_y(cb + nwe);
             const int c = cb + nwe + wave;
-            if (active && c + nwe < c1 && !(dbg & 1)) fetch(c + nwe, xva);
+            if (active && c + nwe < c1) fetch(c + nwe, xva);
             if (active && c < c1) unit(c, xvb);
         }
     }
@@ -772,7 +765,7 @@ __global__ void __launch_bounds__(256)
 k_dphi_series1(const cx<double>* __restrict__ T, const double* __restrict__ sp,
                const TaskPar* __restrict__ tp, int ndir, int ntd, int tg, const RO* __restrict__ coef,
                const cx<double>* __restrict__ twk, double scale2, RO* __restrict__ D0t,
-               float* __restrict__ dlin, int* __restrict__ zero17, int dbg) {
+               float* __restrict__ dlin, int* __restrict__ zero17) {
     constexpr int Q = N / 64, H1 = N / 2 + 1, K = SeriesCfg<RO>::K, THREADS = 256;
     constexpr int NJ = fold_nj<Q>(), JMIN = fold_jmin<Q>();
     constexpr bool WJREG = NJ <= 10;
@@ -817,7 +810,7 @@ k_dphi_series1(const cx<double>* __restrict__ T, const double* __restrict__ sp,
         }
         series_line<N, RO, 64>(xv, WJREG ? wjr : wl, swr, scoef, r0m53, delta, spv, scale2,
                                D0t + ((size_t)td * H1 + y) * N + lane,
-                               dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, true, lane, dbg);
+                               dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, true, lane);
     };
     constexpr int STEP = THREADS / 64;
     while (td < td_end) {
@@ -907,8 +900,8 @@ void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, 
         hipLaunchKernelGGL(k_patch_gen<false>, ggrid, dim3(256), 0, s, ndir, d_tp, d_aotab, cfit, d_P);
     DISPATCH_N(N, {
         constexpr int NG = NAO * series_lanes<NN>() / 256;       // passes (of 4 x 64 / L rows) per td
-        // passes per workgroup: around a thousand workgroups in all
-        int nb = (1024 + ntd - 1) / ntd;
+        // passes per workgroup: around 512 workgroups in all (1024: +2 us at 512^2, +4 at 1280^2; 256: +2)
+        int nb = (512 + ntd - 1) / ntd;
         if (nb > NG) nb = NG;
         if (nb < 1) nb = 1;
         const int qb = (NG + nb - 1) / nb;
@@ -924,8 +917,6 @@ void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* 
                         const double* d_sp, const void* d_coef, const void* d_twk, double scale2,
                         void* d_D0t, float* d_dlin, bool f64out, int* d_zero, int ncu) {
     const int H1 = N / 2 + 1;
-    static const int env_dbg = getenv("MPSFR_SERIES_DBG") ? atoi(getenv("MPSFR_SERIES_DBG")) : 0;    // experiments
-    static const int env_wg = getenv("MPSFR_SERIES_WG") ? atoi(getenv("MPSFR_SERIES_WG")) : 0;
     auto first_form = [&](auto kernel, size_t sm) {
         // task groups: enough workgroups to fill the GPU several times over, every workgroup's table load
         // shared by as many tasks as that allows, every wave of a workgroup the same number of lines
@@ -943,23 +934,23 @@ void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* 
             if constexpr (series_fits<NN, double>()) {
                 constexpr size_t sm = series_smem<NN, double>();
                 allow_smem((k_dphi_series<NN, double>), sm);
-                hipLaunchKernelGGL((k_dphi_series<NN, double>), dim3(env_wg > 0 ? env_wg : ncu), dim3(series_threads<NN, double>()), sm, s,
+                hipLaunchKernelGGL((k_dphi_series<NN, double>), dim3(ncu), dim3(series_threads<NN, double>()), sm, s,
                                    (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, (const double*)d_coef,
-                                   (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), scale2, (double*)d_D0t, d_dlin, d_zero, env_dbg);
+                                   (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), scale2, (double*)d_D0t, d_dlin, d_zero);
             } else {
                 constexpr size_t sm = series1_smem<NN, double>();
                 allow_smem((k_dphi_series1<NN, double>), sm);
                 const auto gt = first_form(0, sm);
                 hipLaunchKernelGGL((k_dphi_series1<NN, double>), gt.first, dim3(256), sm, s,
                                    (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, gt.second, (const double*)d_coef,
-                                   (const cx<double>*)d_twk, scale2, (double*)d_D0t, d_dlin, d_zero, env_dbg);
+                                   (const cx<double>*)d_twk, scale2, (double*)d_D0t, d_dlin, d_zero);
             }
         } else {
             constexpr size_t sm = series_smem<NN, float>();
             allow_smem((k_dphi_series<NN, float>), sm);
-            hipLaunchKernelGGL((k_dphi_series<NN, float>), dim3(env_wg > 0 ? env_wg : ncu), dim3(series_threads<NN, float>()), sm, s,
+            hipLaunchKernelGGL((k_dphi_series<NN, float>), dim3(ncu), dim3(series_threads<NN, float>()), sm, s,
                                (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, (const float*)d_coef,
-                               (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), scale2, (float*)d_D0t, d_dlin, d_zero, env_dbg);
+                               (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), scale2, (float*)d_D0t, d_dlin, d_zero);
         }
     })
 }

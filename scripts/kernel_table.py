@@ -34,6 +34,7 @@ print('| kernel | avg us | VALU issue | MFMA busy | LDS array busy | of which ba
 print('|---|---|---|---|---|---|---|')
 util = {}
 for k in ('k_otf_mfma2', 'k_mf_finish', 'k_mf_prep', 'k_otf_mfma1', 'k_otf_mfma', 'k_otf_r16', 'k_otf_rowfft', 'k_fit', 'k_conv_fft', 'k_colpass_m',
+          'k_colpass', 'k_dphi_series', 'k_patch_rows', 'k_patch_gen', 'k_dmin16',
           'k_psd_rowfft', 'k_colfft_dphi', 'k_dmin', 'k_vkeep', 'k_task_order', 'k_khat', 'k_stamp_sum',
           ):
     if k not in dur:

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/pmc_$1; shift
-mkdir -p $OUT/trace
+rm -rf $OUT; mkdir -p $OUT/trace
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 "$@" > $OUT/trace.log 2>&1 || exit 1
 i=0
 while read -r P; do
