@@ -235,7 +235,7 @@ def main():
                          'host; -1: min(steps, 50), 0: skip)')
     ap.add_argument('--native-steps', type=int, default=-1,
                     help='steps of the native-grid leg (1280^2, pixscale 0.2, 490-930 nm: what the reference\'s '
-                         'compute_psf runs; -1: 20 at the default workload, 0: skip)')
+                         'compute_psf runs; -1: 60 at the default workload, 0: skip)')
     ap.add_argument('--min-seconds', type=float, default=0.2,
                     help='if the timed region is shorter, repeat it (value stays the first, value_min/max '
                          'report the spread)')
@@ -296,7 +296,7 @@ def main():
             cpu['calibration'] = cal
 
     # ---- oracle sample for the native-grid leg (1280^2, pixscale 0.2: what the reference's compute_psf runs)
-    nnat = (20 if default_workload else 0) if a.native_steps < 0 else a.native_steps
+    nnat = (60 if default_workload else 0) if a.native_steps < 0 else a.native_steps
     if world > 1 or not mixed:
         nnat = 0
     lb_nat = np.linspace(490.0, 930.0, nl)
@@ -678,8 +678,8 @@ def main():
     native = None
     if nnat > 0:
         Rn = make_runner('mixed', 1, dim=1280, ps=0.2, lb=lb_nat)
-        for _ in range(8):
-            Rn['step']()
+        for _ in range(100):        # (priming: 60 ms of load, like the 1200 steps before the main region -- with 8 the
+            Rn['step']()            # 20-step region came out 10 % below the same workload run on its own)
         dtn, _ = Rn['timed'](nnat)
         fitn = Rn['fits'][0].cpu().numpy()
         ktn, kln = kernel_times(Rn, 6)
