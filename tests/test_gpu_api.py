@@ -366,3 +366,31 @@ def test_psf_muse_takes_any_psd(api):
     a = api.simul_psd_wfm([0.6, 0.4], H, 0.9, 18.0, zenith=30.0, dim=256, cutoff_masks='exact', verbose=False)
     b = O.residual_psd([0.6, 0.4], H, 0.9 / np.cos(np.deg2rad(30.0)) ** 0.6, 18.0, 1, 256, False, tables=tabs)
     assert rel_err(a, b) < 1e-12
+
+
+def test_large_table_in_asynchronous_parts_equals_one_call(api, monkeypatch):
+    """compute_psf_from_sparta on a table of >= 250 tasks runs as asynchronous parts with the FIT_ROWS
+    records assembled part by part (psfrec._reconstruct_pipelined): same table, bit for bit, as the
+    single blocking call; PSF_MEAN to rounding (the parts' stamp sums are added in order)."""
+    from muse_psfr_amd import psfrec
+    n = 300
+    see, gl, l0 = api.synthetic_rows(n)
+    tbl = api.create_sparta_table(nlines=n)
+    for k in range(1, 5):
+        tbl.data['LGS%d_SEEING' % k][:] = see
+        tbl.data['LGS%d_TUR_GND' % k][:] = gl
+        tbl.data['LGS%d_L0' % k][:] = l0
+    tbl.data['LGS2_L0'][::7] = 150.0             # three-laser rows
+    kw = dict(verbose=False, dim=256, pixscale=api.grid_pixscale(256), lmin=500, lmax=900, nl=5, mean_of_lgs=False)
+    if psfrec._astropy()[0] is not None:
+        pytest.skip('the part-wise assembly is the path without astropy')
+    a = api.compute_psf_from_sparta(_hdul(tbl), **kw)
+    monkeypatch.setattr(psfrec, 'PIPELINE_MIN_TASKS', 10 ** 9)
+    b = api.compute_psf_from_sparta(_hdul(tbl), **kw)
+    ra, rb = a['FIT_ROWS'].data, b['FIT_ROWS'].data
+    assert ra.dtype == rb.dtype and ra.shape == rb.shape == (1200 * 5 - 5 * len(range(0, n, 7)),)
+    for name in ra.dtype.names:
+        np.testing.assert_array_equal(ra[name], rb[name], err_msg=name)
+    np.testing.assert_allclose(a['PSF_MEAN'].data, b['PSF_MEAN'].data, rtol=1e-12)
+    for name in a['FIT_MEAN'].data.dtype.names:
+        np.testing.assert_allclose(a['FIT_MEAN'].data[name], b['FIT_MEAN'].data[name], rtol=1e-9, atol=1e-12)

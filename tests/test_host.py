@@ -267,3 +267,30 @@ def test_fanout_devices(monkeypatch):
     monkeypatch.delenv('WORLD_SIZE')
     monkeypatch.delenv('LOCAL_RANK')
     assert f(None, None, 100000, -1) == [0]
+
+
+def test_fit_rows_records_equal_the_column_wise_table():
+    """The FIT_ROWS table assembled row-wise in one structured array (compute_psf_from_sparta without
+    astropy) holds the same dtype and values as the column-by-column form (psfrec.py:1086-1101)."""
+    from muse_psfr_amd import psfrec as P, _minifits as mf
+    rng = np.random.default_rng(4)
+    nt, nl = 9, 6
+    fit = rng.random((nt, nl, 16)) + 0.5
+    fit[:, :, 4] += 1.5
+    fit[2, 3, 4] = 1.0                      # n = 1: the relative error of the flux divides by n - 1
+    lb = np.linspace(490, 930, nl)
+    stats, las = rng.random((nt, 3)), np.arange(nt) % 4 + 1
+    rec = P._fit_rows_records(lb, fit, 0.2, stats, las)
+    part, blk = P._fit_rows_template(lb, stats, las)          # filled in two parts, as the asynchronous path does
+    P._fit_rows_fill(blk[:4 * nl], fit[:4], 0.2)
+    P._fit_rows_fill(blk[4 * nl:], fit[4:], 0.2)
+    cols = P._fit_columns(np.tile(lb, nt), fit.reshape(nt * nl, -1), 0.2)
+    for j, k in enumerate(('SEEING', 'GL', 'L0')):
+        cols[k] = np.repeat(stats[:, j], nl)
+    cols['row_idx'] = np.repeat(np.arange(1, nt + 1), nl)
+    cols['lgs_idx'] = np.repeat(las, nl)
+    ref = mf.BinTableHDU.from_columns(cols, mf.Header(), 'FIT_ROWS').data
+    assert rec.dtype == ref.dtype and rec.shape == ref.shape
+    for name in ref.dtype.names:
+        np.testing.assert_array_equal(rec[name], ref[name])
+        np.testing.assert_array_equal(part[name], ref[name])
