@@ -291,7 +291,7 @@ k_otf_mfma2(const Mf2Args a) {
 #if MPSFR_MF_CLOCK
     unsigned long long* const clk = a.clk != nullptr && lane0 == 0 ? a.clk + ((size_t)blockIdx.x * 16 + wave0) * 16 : nullptr;
     unsigned long long t_kloop = 0, t_stage = 0, t_tiles = 0, t_wload = 0, t_wbar = 0, t_pass2 = 0, t_masks = 0, t_tail = 0;
-    unsigned long long n_ks = 0, n_tiles = 0, n_dma = 0, n_items = 0;
+    unsigned long long n_ks = 0, n_tiles = 0, n_dma = 0, n_items = 0, t_first = 0;
 #define MF2_NOW() __builtin_readcyclecounter()
     const unsigned long long t_begin = MF2_NOW();
 #else
@@ -412,6 +412,7 @@ k_otf_mfma2(const Mf2Args a) {
         __builtin_amdgcn_s_barrier();
 #if MPSFR_MF_CLOCK
         const unsigned long long tk0 = MF2_NOW();
+        t_first += tk0 - tm1;
 #endif
         for (;;) {
             const int ks = __builtin_ctzll(rest);
@@ -639,7 +640,7 @@ k_otf_mfma2(const Mf2Args a) {
         const unsigned long long t_end = MF2_NOW();
         clk[0] = t_begin; clk[1] = t_masks; clk[2] = t_kloop; clk[3] = t_stage; clk[4] = t_tiles;
         clk[5] = t_wload; clk[6] = t_wbar; clk[7] = t_pass2; clk[8] = t_end; clk[9] = n_ks;
-        clk[10] = n_tiles; clk[11] = t_tail; clk[12] = n_dma; clk[13] = n_items;
+        clk[10] = n_tiles; clk[11] = t_tail; clk[12] = n_dma; clk[13] = n_items; clk[14] = t_first;
     }
 #endif
 #undef MF2_NOW

@@ -31,6 +31,7 @@ tot = w[:, 8] - w[:, 0]
 print('wave lifetime: mean %.0f  p50 %.0f  max %.0f' % (tot.mean(), np.median(tot), tot.max()))
 for i in (1, 2, 3, 4, 5, 6, 7, 11):
     print('  %-18s mean %8.0f  max %8.0f   (%.1f %% of the mean lifetime)' % (names[i], w[:, i].mean(), w[:, i].max(), 100 * w[:, i].mean() / tot.mean()))
+print('  first stage of an item (issue + wait + barrier): mean %.0f (%.1f %% of the mean lifetime), items per wave %.1f' % (w[:, 14].mean(), 100 * w[:, 14].mean() / tot.mean(), w[:, 13].mean()))
 print('  per wave: k-steps %.1f  tile steps %.1f  dma instructions %.1f' % (w[:, 9].mean(), w[:, 10].mean(), w[:, 12].mean()))
 print('  per k-step: stage %.0f  tiles %.0f  wait loads %.0f  barrier %.0f' % tuple(w[:, i].sum() / w[:, 9].sum() for i in (3, 4, 5, 6)))
 print('  per tile step (cycles of the wave): %.0f' % (w[:, 4].sum() / max(w[:, 10].sum(), 1)))
