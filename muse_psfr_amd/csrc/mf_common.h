@@ -18,11 +18,14 @@ constexpr int MTL = 16;      // lines per m-tile
 constexpr int KBL = 32;      // columns (u) per k-step
 constexpr int NCT = 3;       // column tiles of the first pass: 48 >= 42 real columns
 constexpr int NJT = 2;       // column tiles of the second pass: 32 >= 21
-// The OTF (<= 1) is generated times 2^kShift = 32768: the matrix cores flush fp16 subnormals, so the
-// low half of an element (<= 2^-12 of it) survives down to elements of 2^-14 / 2^-12 / 2^15 = 7.6e-6;
-// smaller ones keep 11 bits (an absolute 2e-9 of the largest), and an element below 2^-29 is
-// flushed altogether.  The first-pass sums, scaled back by the table factors, stay below 2^kShift
-// as well.  The stamp is normalised to sum 1 at the end (psfrec.py:685), so the factor drops out.
+// The OTF (<= 1) is generated times 2^kShift = 32768, so that the low half of an element (<= 2^-12 of
+// it) is a NORMAL fp16 number -- full 11 bits -- down to elements of 2^-14 / 2^-12 / 2^15 = 7.6e-6; below
+// that the low half is subnormal (fewer bits: an absolute 2e-9 of the largest element at worst), and an
+// element below 2^-29 has both halves subnormal.  (The gfx950 matrix cores multiply subnormal fp16
+// inputs like any other -- they do not flush them: tests/test_gpu_parity.py::
+// test_precision_tiers_of_the_matrix_core_stage.)  The first-pass sums, scaled back by the table factors,
+// stay below 2^kShift as well.  The stamp is normalised to sum 1 at the end (psfrec.py:685), so the
+// factor drops out.
 constexpr float kShift = 15.0f;
 // The E and G tables (|E| <= 1, |G| <= 2) are stored times 2^kTabShift for the same reason: the low
 // half of an entry (<= 2^-12 of it) would otherwise sit in the fp16 subnormal range.

@@ -22,8 +22,8 @@ namespace {
 
 thread_local std::string g_err;
 
-// log2 of the smallest OTF element (relative to OTF[0][0] = 1) whose fp16 halves are not flushed by
-// the matrix cores, with a margin for the fp32 rounding of the bound (otf_mfma.hip: kShift = 15)
+// log2 of the smallest OTF element (relative to OTF[0][0] = 1) that still has a normal fp16 high half
+// (mf_common.h: kShift = 15), with a margin for the fp32 rounding of the bound
 constexpr float kMfFloorLog2 = -29.01f;
 
 int fail(int code, const char* fmt, ...) {
@@ -1025,9 +1025,9 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     float thr_blk = (prune && mf)
         ? (float)std::log2(0.5 * eps_prune / (2.0 * ndir * 16 * 32 * mf_block_count(N))) : 0.f;
     // Representation floor of the split-fp16 operands: the OTF is generated times 2^15, so an element
-    // below 2^-29 of OTF[0][0] has both fp16 halves in the subnormal range, which the matrix cores
-    // flush to zero -- a block whose bound is below 2^-29.01 contributes exactly nothing, and skipping
-    // it changes no bit of the result.
+    // below 2^-29 of OTF[0][0] has both fp16 halves in the subnormal range -- a block whose bound is below
+    // 2^-29.01 carries at most a few bits per element, and is dropped.  (An approximation of the size of the
+    // pruning itself, not a bit-neutral one: the matrix cores do not flush subnormals; option "mf_floor".)
     if (prune && mf && c->mf_floor && thr_blk < kMfFloorLog2) thr_blk = kMfFloorLog2;
     for (int j = 0; j < NL; ++j) {
         mpsfr_ctx::Lane& ln = lane_of(j);

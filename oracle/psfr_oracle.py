@@ -467,7 +467,9 @@ def psf_stamps_restructured(psd, lbda_nm, dimpsf=40, pixscale=0.2):
 
 def _split16(x, flush=True):
     """x = hi + lo in fp16 (round to nearest even), as the matrix-core kernel splits its operands;
-    flush: fp16 subnormals are flushed to zero, as the MFMA inputs are."""
+    flush: fp16 subnormals set to zero -- the model the kernel was designed against; the gfx950 matrix
+    cores themselves keep subnormal inputs (tests/test_gpu_parity.py, precision tiers), which only makes
+    the product more accurate than this model."""
     x = np.asarray(x, dtype=np.float32)
     hi = x.astype(np.float16)
     lo = (x - hi.astype(np.float32)).astype(np.float16)
