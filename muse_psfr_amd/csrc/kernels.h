@@ -42,6 +42,11 @@ struct AoGeom {
     double dir[2][25];      // [xy][dir] arcmin
 };
 
+// work lists of the thin-wave matrix-core kernel: one per work class (a lane of the consumer's wave keeps the
+// bounds of one list), then the queue head
+constexpr int kMfLists = 64;
+constexpr int kMfSchedInts = kMfLists + 1;
+
 enum KernelId {
     K_AO_TABLES = 0,
     K_TEL_OTF,
@@ -72,7 +77,7 @@ int psd_rowfft_groups(int N);
 void launch_psd_rowfft(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp,
                        const double* d_aotab, double cfit, void* d_C, const void* d_tw64,
                        double* d_dcpart, bool f64);
-// d_zero: 17 ints the kernel sets to zero (the work-list counters of launch_mf_prep), or nullptr
+// d_zero: kMfSchedInts ints the kernel sets to zero (the work-list counters of launch_mf_prep), or nullptr
 void launch_colfft_dphi(hipStream_t s, int N, int ntd, const void* d_C, const double* d_dcpart,
                         double scale2, void* d_D0t, bool f64out, const void* d_tw64,
                         int* d_zero = nullptr);
@@ -138,7 +143,7 @@ void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const vo
 // workgroup (7: 14 waves of 128 registers; 6: 12 waves of 168).
 size_t mf2_own_bytes(int N, int ntask, int nl);
 size_t mf2_uni_bytes(int N, int ntask, int nl);
-size_t mf2_sched_bytes(int N, int ntask, int nl);
+size_t mf2_sched_bytes(int N, int ntask, int nl, int permax);
 size_t mf2_part_bytes(int N, int ntask, int nl);
 void mf2_groups(int nl, int permax, int* per, int* ngr);
 // K_MF_PREP: block masks and the work lists of launch_otf_mfma2 from the block minima of launch_dmin

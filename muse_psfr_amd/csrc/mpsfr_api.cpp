@@ -1054,7 +1054,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         if (mf2) {
             if ((rc = ensure(c, ln.mown, mf2_own_bytes(N, TC, nl)))) return rc;
             if ((rc = ensure(c, ln.muni, mf2_uni_bytes(N, TC, nl)))) return rc;
-            if ((rc = ensure(c, ln.msched, mf2_sched_bytes(N, TC, nl)))) return rc;
+            if ((rc = ensure(c, ln.msched, mf2_sched_bytes(N, TC, nl, c->mf_permax)))) return rc;
             if ((rc = ensure(c, ln.mpart, mf2_part_bytes(N, TC, nl)))) return rc;
         }
         if (prune) {
@@ -1131,7 +1131,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             if ((rc = ensure(c, cm, (size_t)ndir * N * H1 * 2 * sizeof(double)))) { release(img); return rc; }
             hipError_t e1 = hipMemcpyAsync(img.p, io.psd_in, n * sizeof(double), hipMemcpyHostToDevice, ls);
             launch_dphi_from_psd(ls, N, ndir, (const double*)img.p, cm.p, 2.0 / 256.0, ln.D0t.p, c->f64, c->tw64.p);
-            if (mf2 && e1 == hipSuccess) e1 = hipMemsetAsync(ln.msched.p, 0, 17 * sizeof(int), ls);
+            if (mf2 && e1 == hipSuccess) e1 = hipMemsetAsync(ln.msched.p, 0, kMfSchedInts * sizeof(int), ls);
             const hipError_t e2 = hipStreamSynchronize(ls);
             release(img);
             release(cm);

@@ -69,9 +69,12 @@ constexpr int kSlab = 6 * 1024;         // E slab of one wavelength and k-step: 
 //   ksum[task][l][sw], kuni[task][grp][sw]   the k-steps with work, per sweep of eight m-tiles
 //   gsw[task][grp]        bit sw: the sweep has work
 //   items[cls][]          the work lists of K_OTF_MFMA2: {task, grp, sweep, sweeps of the (task, grp)} of
-//                         every sweep with work, filed by work class (blocks staged / 8, at most 15)
-//                         with one atomic add on the class counter sched[cls].  The order inside a
-//                         class is left to the hardware and changes no result (items are independent).
+//                         every sweep with work, filed by work class -- the blocks it stages, in 64 steps up
+//                         to the eight m-tiles x nks of a full sweep -- with one atomic add on the class
+//                         counter sched[cls].  (Sixteen classes were sixteen hot words: the launch took
+//                         13 ns per item, 12 / 30 / 60 us for 900 / 1800 / 4500 items, whatever else it
+//                         did; 64 take 11 / 25 / 41 us and order the queue more finely.)  The order inside
+//                         a class is left to the hardware and changes no result (items are independent).
 // A block is kept if its bound e = c' dmin + log2 telmax is above thr (every element of a dropped
 // block is below 2^thr); it is full if e is above thr_mid.  Without pruning (dminb = nullptr) every
 // block of the half plane is full.  (The line pruning of the FFT path, K_VKEEP, is not needed here:
@@ -90,8 +93,8 @@ struct MaskArgs {
     u64* ksum;
     u64* kuni;
     int* gsw;
-    int* sched;              // [0..15] items per work class (zeroed by K_COLFFT_DPHI), [16] queue head of K_OTF_MFMA2
-    int4* items;             // [16][cap]
+    int* sched;              // [0..63] items per list (zeroed by stage A), [64] queue head of K_OTF_MFMA2
+    int4* items;             // [kMfLists][cap]
     int cap;                 // ntask ngr nsw
 };
 
@@ -168,7 +171,7 @@ __global__ void __launch_bounds__(64 * 8) k_mf_prep(const MaskArgs a) {
         for (int sw = 0; sw < 8; ++sw) sweeps |= (int)((has >> (8 * sw)) & 1) << sw;
         if (lane == 0) a.gsw[task * a.ngr + grp] = sweeps;
         if (lead && ku != 0) {               // file the item in its work class
-            const int cls = min(15, pc >> 3);
+            const int cls = min(kMfLists - 1, pc * (kMfLists / kT2) / nks);
             a.items[(size_t)cls * a.cap + atomicAdd(a.sched + cls, 1)] =
                 make_int4(task, grp, lane >> 3, __builtin_popcount(sweeps));
         }
@@ -214,8 +217,8 @@ struct Mf2Args {
     const u64* uni;
     const u64* ksum;
     const u64* kuni;
-    int* sched;              // [0..15] items per work class (K_MF_PREP), [16] queue head
-    const int4* items;       // [16][cap]
+    int* sched;              // [0..63] items per list (K_MF_PREP), [64] queue head
+    const int4* items;       // [kMfLists][cap]
     int cap;
     f4* part;                // [ntask][nl][nsw][8][64]: partial tiles of (task, group)s with several sweeps
     unsigned long long* clk; // experiments (-DMPSFR_MF_CLOCK=1): per-wave phase times, or nullptr
@@ -278,13 +281,12 @@ k_otf_mfma2(const Mf2Args a) {
     // masks: 13 % of a wave's lifetime when they sat at the head of every item).  (Drawn a whole
     // item ahead, the queue balances worse: the launch ended 12 us later on its last workgroups.)
     volatile int* s_next = reinterpret_cast<volatile int*>(smem + 2 * kStage2 + 2 * per * kSlab);
-    // the 16 lists as one queue, heaviest class first: item i of the queue is entry i - first[c] of
-    // the class c with first[c] <= i < first[c] + count[c]
-    // (lane c < 16 keeps the bounds of class c)
-    const int ccnt = lane0 < 16 ? a.sched[lane0] : 0;
+    // the 64 lists as one queue, heaviest class first: item i of the queue is entry i - first[c] of
+    // the list c with first[c] <= i < first[c] + count[c]  (lane c keeps the bounds of list c)
+    const int ccnt = a.sched[lane0];
     int cfirst = 0, nitems = 0;
 #pragma unroll
-    for (int c = 15; c >= 0; --c) {
+    for (int c = kMfLists - 1; c >= 0; --c) {
         if (lane0 == c) cfirst = nitems;
         nitems += __builtin_amdgcn_readlane(ccnt, c);
     }
@@ -299,7 +301,7 @@ k_otf_mfma2(const Mf2Args a) {
 #endif
     // descriptor {task, group, sweep, sweeps of the (task, group)} of queue item `item`
     auto load_item = [&](int item) -> int4 {
-        const int cls = __builtin_ctzll(__ballot(lane0 < 16 && item >= cfirst && item < cfirst + ccnt));
+        const int cls = __builtin_ctzll(__ballot(item >= cfirst && item < cfirst + ccnt));
         const int ipos = item - __builtin_amdgcn_readlane(cfirst, cls);
         return a.items[(size_t)cls * a.cap + ipos];
     };
@@ -321,7 +323,7 @@ k_otf_mfma2(const Mf2Args a) {
         else if (lane0 == 25) mw = a.kuni[tg_ * nsw + sw];
         return mw;
     };
-    if (threadIdx.x == 0) *s_next = atomicAdd(a.sched + 16, 1);
+    if (threadIdx.x == 0) *s_next = atomicAdd(a.sched + kMfLists, 1);
     __syncthreads();
     int item = __builtin_amdgcn_readfirstlane(*s_next);
     int4 it = make_int4(0, 0, 0, 0);
@@ -419,7 +421,7 @@ k_otf_mfma2(const Mf2Args a) {
             rest &= rest - 1;
             // the next item's number is drawn during the last k-step (the atomic is in flight behind
             // its tile steps) and read behind the barrier that ends the k-loop
-            if (rest == 0 && threadIdx.x == 0) *s_next = atomicAdd(a.sched + 16, 1);
+            if (rest == 0 && threadIdx.x == 0) *s_next = atomicAdd(a.sched + kMfLists, 1);
             unsigned fb = 0, mb = 0;
 #pragma unroll
             for (int i = 0; i < kTW; ++i) {
@@ -685,9 +687,13 @@ size_t mf2_own_bytes(int N, int ntask, int nl) { return (size_t)ntask * nl * mf_
 size_t mf2_uni_bytes(int N, int ntask, int nl) {
     return (size_t)ntask * nl * (mf_nmt(N) + 2 * mf2_nsw(N)) * sizeof(u64);
 }
-// sched[20] | gsw | items (int4) [16 classes][ntask ngr nsw]
-size_t mf2_sched_bytes(int N, int ntask, int nl) {
-    return (20 + (size_t)ntask * nl + 4 + 16 * (size_t)ntask * nl * mf2_nsw(N) * 4) * sizeof(int);
+void mf2_groups(int nl, int permax, int* per, int* ngr);
+// sched[68] | gsw | items (int4) [kMfLists][ntask ngr nsw]
+static size_t mf2_cap(int N, int ntask, int ngr) { return (size_t)ntask * ngr * mf2_nsw(N); }
+size_t mf2_sched_bytes(int N, int ntask, int nl, int permax) {
+    int per, ngr;
+    mf2_groups(nl, permax, &per, &ngr);
+    return (68 + (size_t)ntask * nl + 4 + kMfLists * mf2_cap(N, ntask, ngr) * 4) * sizeof(int);
 }
 size_t mf2_part_bytes(int N, int ntask, int nl) { return (size_t)ntask * nl * mf2_nsw(N) * 4 * NJT * 64 * sizeof(f4); }
 
@@ -704,8 +710,8 @@ struct SchedPtrs { int* sched; int* gsw; int4* items; };
 SchedPtrs sched_ptrs(void* d_sched, int ntask, int nl) {
     SchedPtrs p;
     p.sched = (int*)d_sched;
-    p.gsw = p.sched + 20;
-    p.items = (int4*)(p.sched + 20 + (((size_t)ntask * nl + 3) & ~(size_t)3));
+    p.gsw = p.sched + 68;
+    p.items = (int4*)(p.sched + 68 + (((size_t)ntask * nl + 3) & ~(size_t)3));
     return p;
 }
 }  // namespace
@@ -726,7 +732,7 @@ void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const L
     a.kuni = a.ksum + (size_t)ntask * nl * mf2_nsw(N);
     const SchedPtrs p = sched_ptrs(d_sched, ntask, nl);
     a.gsw = p.gsw; a.sched = p.sched; a.items = p.items;
-    a.cap = ntask * a.ngr * (int)mf2_nsw(N);
+    a.cap = (int)mf2_cap(N, ntask, a.ngr);
     hipLaunchKernelGGL(k_mf_prep, dim3(a.ngr, ntask), dim3(64 * a.per), 0, s, a);
 }
 
@@ -744,7 +750,7 @@ void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int n
     a.kuni = a.ksum + (size_t)ntask * nl * mf2_nsw(N);
     const SchedPtrs p = sched_ptrs(d_sched, ntask, nl);
     a.sched = p.sched; a.items = p.items;
-    a.cap = ntask * a.ngr * (int)mf2_nsw(N);
+    a.cap = (int)mf2_cap(N, ntask, a.ngr);
     a.part = (f4*)d_part;
     a.clk = (unsigned long long*)d_clk;
     int lg = 0;

@@ -316,7 +316,7 @@ k_colfft_dphi(const cx<double>* __restrict__ C, const double* __restrict__ dcpar
         __syncthreads();        // the table is the one thing the waves of the workgroup share
     }
     // the counters of the matrix-core stage's work lists (K_MF_PREP, K_OTF_MFMA2) start from zero
-    if (zero17 != nullptr && td == 0 && blockIdx.x == 0 && threadIdx.x < 17) zero17[threadIdx.x] = 0;
+    if (zero17 != nullptr && td == 0 && blockIdx.x == 0 && threadIdx.x < kMfSchedInts) zero17[threadIdx.x] = 0;
     // S00 = the shares of K_PSD_ROWFFT's workgroups, added in an order fixed by N alone (every wave
     // of every workgroup gets the same bits)
     double dc = 0.0;

@@ -687,7 +687,7 @@ k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
     const int nq = (ntd + R - 1) / R;
     const long C = (long)H1 * nq;
     const int c0 = (int)(C * blockIdx.x / gridDim.x), c1 = (int)(C * (blockIdx.x + 1) / gridDim.x);
-    if (zero17 != nullptr && blockIdx.x == 0 && threadIdx.x < 17) zero17[threadIdx.x] = 0;
+    if (zero17 != nullptr && blockIdx.x == 0 && threadIdx.x < kMfSchedInts) zero17[threadIdx.x] = 0;
     if (c0 >= c1) return;
     // (two register sets: the inputs of a unit are requested a whole unit ahead)
     cx<double> xva[kNX], xvb[kNX];
@@ -802,7 +802,7 @@ k_dphi_series1(const cx<double>* __restrict__ T, const double* __restrict__ sp,
         for (int i = threadIdx.x; i < NV; i += THREADS) dst[i] = src[i];
         for (int i = threadIdx.x; i < Q * 64; i += THREADS) swr[i] = twk[NJ * 64 + i];
     }
-    if (zero17 != nullptr && y == 0 && g == 0 && threadIdx.x < 17) zero17[threadIdx.x] = 0;
+    if (zero17 != nullptr && y == 0 && g == 0 && threadIdx.x < kMfSchedInts) zero17[threadIdx.x] = 0;
     cx<double> wjr[WJREG ? NJ : 1];
     if constexpr (WJREG) {
 #pragma unroll
