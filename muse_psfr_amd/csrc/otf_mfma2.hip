@@ -323,9 +323,10 @@ k_otf_mfma2(const Mf2Args a) {
         else if (lane0 == 25) mw = a.kuni[tg_ * nsw + sw];
         return mw;
     };
-    if (threadIdx.x == 0) *s_next = atomicAdd(a.sched + kMfLists, 1);
-    __syncthreads();
-    int item = __builtin_amdgcn_readfirstlane(*s_next);
+    // The first round is dealt without a draw -- workgroup b starts on item b (the heaviest items, in
+    // queue order) -- and the counter numbers the items behind it: 256 workgroups drawing from one word
+    // at the same moment waited ~3 us for the last answer.
+    int item = blockIdx.x;
     int4 it = make_int4(0, 0, 0, 0);
     u64 mw = 0;
     float c2 = 0.f;
@@ -421,7 +422,7 @@ k_otf_mfma2(const Mf2Args a) {
             rest &= rest - 1;
             // the next item's number is drawn during the last k-step (the atomic is in flight behind
             // its tile steps) and read behind the barrier that ends the k-loop
-            if (rest == 0 && threadIdx.x == 0) *s_next = atomicAdd(a.sched + kMfLists, 1);
+            if (rest == 0 && threadIdx.x == 0) *s_next = (int)gridDim.x + atomicAdd(a.sched + kMfLists, 1);
             unsigned fb = 0, mb = 0;
 #pragma unroll
             for (int i = 0; i < kTW; ++i) {
