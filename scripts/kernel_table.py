@@ -22,6 +22,8 @@ def get(k, c):
 dur = {}
 for r in csv.DictReader(open(d + '/kernel_stats.csv')):
     m = re.search(r'k_\w+', r['Name'])
+    if m and int(r['Calls']) < 10:      # table builders of the first call, not part of a step
+        continue
     if m and m.group(0) not in dur:
         dur[m.group(0)] = float(r['AverageNs']) * 1e-9
 print('# Per-kernel resource use (one lane: `bench.py --streams 1`, 100 rows x 35 lambda x 512^2)\n')
