@@ -553,8 +553,16 @@ def main():
     for c in ctxs:
         c.set_option('profile_only', c.profile_names().index(dominant))
         c.set_option('profile', 1)
-    # the W warm-up steps run in exactly the mode of the timed ones, right before them (the library's
-    # pool of HIP events for the bracketed kernel fills here, not inside the timed region)
+    # The library's pool of HIP events for the bracketed kernel must hold a whole timed region's worth
+    # before that region starts (an event created inside it costs ~10 us of host time: with K = 20 and
+    # W = 5 the first region lost 3-7 % to the fifteen pairs it had to create): K untimed steps in the mode
+    # of the timed ones, their events handed back to the pool.
+    for _ in range(a.steps):
+        R['step']()
+    R['fence']()
+    for c in ctxs:
+        c.profile_reset()
+    # the W warm-up steps run in exactly the mode of the timed ones, right before them
     for _ in range(a.warmup):
         R['step']()
     dt, t_enq = R['timed'](a.steps)
