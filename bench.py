@@ -227,12 +227,12 @@ def main():
     ap.add_argument('--cpu-rows', type=int, default=-1,
                     help='rows of the CPU-baseline sample (-1: automatic, 0: skip)')
     ap.add_argument('--f64-steps', type=int, default=-1,
-                    help='steps of the fp64-mode leg (-1: steps/8, 0: skip)')
+                    help='steps of the fp64-mode leg (-1: max(50, steps/8), 0: skip)')
     ap.add_argument('--unpruned-steps', type=int, default=-1,
-                    help='steps of the leg without line pruning (-1: steps/4, 0: skip)')
+                    help='steps of the leg without line pruning (-1: max(50, steps/4), 0: skip)')
     ap.add_argument('--host-steps', type=int, default=-1,
                     help='steps of the host-output leg (synchronous call, fit table + stamp sum copied to the '
-                         'host; -1: min(steps, 50), 0: skip)')
+                         'host; -1: 50, 0: skip)')
     ap.add_argument('--native-steps', type=int, default=-1,
                     help='steps of the native-grid leg (1280^2, pixscale 0.2, 490-930 nm: what the reference\'s '
                          'compute_psf runs; -1: 60 at the default workload, 0: skip)')
@@ -640,7 +640,7 @@ def main():
     # in flight: the results of call k are collected while call k + 1 runs, like the passes of a table
     # larger than one call; `sync` beside it is the blocking call, one at a time.
     host_leg = None
-    nhost = (min(a.steps, 50) if a.host_steps < 0 else a.host_steps) if world == 1 else 0
+    nhost = (50 if a.host_steps < 0 else a.host_steps) if world == 1 else 0
     if nhost > 0:
         c = Context(dim=dim, pixscale=ps, precision=a.precision, device=local)
         apply_options(c, a.precision)
@@ -740,10 +740,10 @@ def main():
     # ---- the same workload with every line of the half plane transformed (prune_eps = 0)
     unpruned = None
     pruned = mixed and a.prune_eps != 0 and not os.environ.get('MPSFR_PRUNE_FIXED')
-    nunp = (max(20, a.steps // 4) if a.unpruned_steps < 0 else a.unpruned_steps) if pruned else 0
+    nunp = (max(50, a.steps // 4) if a.unpruned_steps < 0 else a.unpruned_steps) if pruned else 0
     if nunp > 0:
         R3 = make_runner('mixed', max(1, a.inflight), prune_eps=0.0)
-        for _ in range(8):
+        for _ in range(100):        # (priming, as for the native leg)
             R3['step']()
         dt3, _ = R3['timed'](nunp)
         fit3 = R3['fits'][0].cpu().numpy()
@@ -755,11 +755,12 @@ def main():
 
     # ---- the same workload at the reference's own precision (fp64 everywhere), fewer steps
     f64 = None
-    nf64 = (max(8, a.steps // 8) if a.f64_steps < 0 else a.f64_steps) if mixed else 0
+    # (at least 50 steps: a region of a few calls is mostly the fill and drain of the pipeline)
+    nf64 = (max(50, a.steps // 8) if a.f64_steps < 0 else a.f64_steps) if mixed else 0
     if nf64 > 0:
         R2 = make_runner('f64', max(1, a.inflight))
-        for _ in range(4):
-            R2['step']()
+        for _ in range(100):        # (priming, as for the native leg: with 4 the leg read 4.7 M where the
+            R2['step']()            # primed run of the same workload gives 4.9 M)
         dt2, _ = R2['timed'](nf64)
         fit2 = R2['fits'][0].cpu().numpy()
         R2['close']()
