@@ -1,5 +1,6 @@
 // Micro-benchmark: issue cost of packed fp32 arithmetic (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32) against
-// the plain instructions, 1..4 waves per SIMD, 8 independent accumulators.
+// the plain instructions, and of the transcendental ones (v_exp_f32, v_rcp_f32), 1..4 waves per SIMD,
+// 8 independent accumulators.
 // Build: hipcc --offload-arch=gfx950 -O3 -o pk32 pk32.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -50,6 +51,21 @@ __global__ void k(float* out, int iters) {
                     "v_fmac_f32_e32 %0, %8, %9\n\tv_fmac_f32_e32 %1, %8, %9\n\tv_fmac_f32_e32 %2, %8, %9\n\tv_fmac_f32_e32 %3, %8, %9\n\t"
                     "v_fmac_f32_e32 %4, %8, %9\n\tv_fmac_f32_e32 %5, %8, %9\n\tv_fmac_f32_e32 %6, %8, %9\n\tv_fmac_f32_e32 %7, %8, %9"
                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(x), "v"(w));
+            } else if constexpr (MODE == 5) {
+                asm volatile(
+                    "v_exp_f32_e32 %0, %0\n\tv_exp_f32_e32 %1, %1\n\tv_exp_f32_e32 %2, %2\n\tv_exp_f32_e32 %3, %3\n\t"
+                    "v_exp_f32_e32 %4, %4\n\tv_exp_f32_e32 %5, %5\n\tv_exp_f32_e32 %6, %6\n\tv_exp_f32_e32 %7, %7"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(x), "v"(w));
+            } else if constexpr (MODE == 6) {
+                asm volatile(
+                    "v_rcp_f32_e32 %0, %0\n\tv_rcp_f32_e32 %1, %1\n\tv_rcp_f32_e32 %2, %2\n\tv_rcp_f32_e32 %3, %3\n\t"
+                    "v_rcp_f32_e32 %4, %4\n\tv_rcp_f32_e32 %5, %5\n\tv_rcp_f32_e32 %6, %6\n\tv_rcp_f32_e32 %7, %7"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(x), "v"(w));
+            } else if constexpr (MODE == 7) {      // the OTF element of the matrix-core stage: fma + exp
+                asm volatile(
+                    "v_fma_f32 %0, %8, %9, %0\n\tv_exp_f32_e32 %1, %0\n\tv_fma_f32 %2, %8, %9, %2\n\tv_exp_f32_e32 %3, %2\n\t"
+                    "v_fma_f32 %4, %8, %9, %4\n\tv_exp_f32_e32 %5, %4\n\tv_fma_f32 %6, %8, %9, %6\n\tv_exp_f32_e32 %7, %6"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(x), "v"(w));
             } else {
                 asm volatile(
                     "v_add_f32_e32 %0, %8, %0\n\tv_add_f32_e32 %1, %8, %1\n\tv_add_f32_e32 %2, %8, %2\n\tv_add_f32_e32 %3, %8, %3\n\t"
@@ -90,5 +106,8 @@ int main() {
     run<2>("v_pk_mul_f32");
     run<3>("v_fmac_f32");
     run<4>("v_add_f32");
+    run<5>("v_exp_f32");
+    run<6>("v_rcp_f32");
+    run<7>("fma + exp pairs");
     return 0;
 }
