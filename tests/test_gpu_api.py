@@ -394,3 +394,21 @@ def test_large_table_in_asynchronous_parts_equals_one_call(api, monkeypatch):
     np.testing.assert_allclose(a['PSF_MEAN'].data, b['PSF_MEAN'].data, rtol=1e-12)
     for name in a['FIT_MEAN'].data.dtype.names:
         np.testing.assert_allclose(a['FIT_MEAN'].data[name], b['FIT_MEAN'].data[name], rtol=1e-9, atol=1e-12)
+
+
+def test_large_table_on_a_grid_too_small_raises_like_the_reference(api):
+    """The part-wise path keeps the error behaviour of the single call: a wavelength whose stamp field does not
+    fit the grid is a ValueError (the reference fails in scipy's interpn, psfrec.py:663-683), and the context
+    stays usable."""
+    n = 260
+    see, gl, l0 = api.synthetic_rows(n)
+    tbl = api.create_sparta_table(nlines=n)
+    for k in range(1, 5):
+        tbl.data['LGS%d_SEEING' % k][:] = see
+        tbl.data['LGS%d_TUR_GND' % k][:] = gl
+        tbl.data['LGS%d_L0' % k][:] = l0
+    kw = dict(verbose=False, dim=128, pixscale=api.grid_pixscale(128), nl=3)
+    with pytest.raises(ValueError):
+        api.compute_psf_from_sparta(_hdul(tbl), lmin=200, lmax=300, **kw)
+    res = api.compute_psf_from_sparta(_hdul(tbl), lmin=500, lmax=900, **kw)
+    assert len(res['FIT_ROWS'].data) == n * 3
