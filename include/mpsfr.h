@@ -192,6 +192,13 @@ int mpsfr_sync(mpsfr_ctx* ctx);
 long mpsfr_last_ticket(mpsfr_ctx* ctx);
 int mpsfr_wait(mpsfr_ctx* ctx, long ticket);
 
+/* Give up every asynchronous host-output call that has not been handed over yet: wait for the GPU to
+ * drain, then forget the callers' arrays WITHOUT writing to them.  The error path of a caller whose output
+ * arrays are about to go away (an exception between the call and its mpsfr_wait): after this, no later
+ * mpsfr_wait / mpsfr_sync / mpsfr_reconstruct of the context touches those arrays.  The abandoned tickets
+ * count as completed; the context stays usable. */
+int mpsfr_abandon(mpsfr_ctx* ctx);
+
 /* The context's hipStream_t (as void*): it is ordered after every asynchronous (on_device = 1)
  * call made so far, so a caller can queue its own GPU work behind the results without a host
  * sync, e.g. torch.cuda.current_stream().wait_stream(torch.cuda.ExternalStream(...)). */

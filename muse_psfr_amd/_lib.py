@@ -81,6 +81,8 @@ def load():
     lib.mpsfr_last_ticket.restype = C.c_long
     lib.mpsfr_wait.argtypes = [p, C.c_long]
     lib.mpsfr_wait.restype = C.c_int
+    lib.mpsfr_abandon.argtypes = [p]
+    lib.mpsfr_abandon.restype = C.c_int
     lib.mpsfr_stream.argtypes = [p]
     lib.mpsfr_stream.restype = C.c_void_p
     lib.mpsfr_wait_event.argtypes = [p, C.c_void_p]
@@ -109,7 +111,7 @@ def load():
 
 EXPORTS = ['mpsfr_create', 'mpsfr_destroy', 'mpsfr_last_error', 'mpsfr_set_option',
            'mpsfr_reconstruct', 'mpsfr_reconstruct_multi', 'mpsfr_fit_stamps', 'mpsfr_simul_psd', 'mpsfr_psf_from_psd',
-           'mpsfr_convolve_stamps', 'mpsfr_sync', 'mpsfr_last_ticket', 'mpsfr_wait',
+           'mpsfr_convolve_stamps', 'mpsfr_sync', 'mpsfr_last_ticket', 'mpsfr_wait', 'mpsfr_abandon',
            'mpsfr_stream', 'mpsfr_wait_event',
            'mpsfr_host_time', 'mpsfr_debug_fetch',
            'mpsfr_profile_count', 'mpsfr_profile_name', 'mpsfr_profile_get',
@@ -147,11 +149,18 @@ class Context:
         _check(self.lib.mpsfr_create(C.byref(h), int(device), self.dim, self.dimpsf,
                                      self.pixscale, prec))
         self._h = h
+        # Output arrays of asynchronous host-output calls not yet handed over, by ticket: the library holds
+        # raw pointers to them (it writes them in mpsfr_wait, in mpsfr_sync, or when the ring of four comes
+        # round again), so the context keeps them alive until then -- a PendingResult that is dropped
+        # without wait() leaves no dangling pointer behind.
+        self._pending = {}
+        self._abandoned = set()
 
     def close(self):
         if getattr(self, '_h', None):
-            self.lib.mpsfr_destroy(self._h)
+            self.lib.mpsfr_destroy(self._h)        # (destroys the ring without writing to any caller array)
             self._h = None
+            self._pending = {}
 
     __del__ = close
 
@@ -160,6 +169,20 @@ class Context:
 
     def sync(self):
         _check(self.lib.mpsfr_sync(self._h))
+        self._pending.clear()
+
+    def abandon(self):
+        """Drop every asynchronous host-output call not yet waited for (mpsfr_abandon): the GPU drains, the
+        library forgets the output arrays without writing to them, the context stays usable.  For error paths."""
+        try:
+            _check(self.lib.mpsfr_abandon(self._h))
+        finally:
+            self._abandoned.update(self._pending)
+            self._pending.clear()
+
+    def _handed_over(self, upto):
+        for t in [t for t in self._pending if t <= upto]:
+            del self._pending[t]
 
     def wait_event(self, hip_event):
         """The next reconstruct call waits on the GPU for this recorded hipEvent_t (an integer
@@ -212,7 +235,11 @@ class Context:
             float(wind_speed), int(npsflin), nl, _dptr(lbda), _u8ptr(mrec), _u8ptr(mres),
             vp(psf), vp(psum), vp(fit), 2 if _async else 0))
         if _async:
-            return PendingResult(self, int(self.lib.mpsfr_last_ticket(self._h)), dict(psf=psf, psf_sum=psum, fit=fit))
+            ticket = int(self.lib.mpsfr_last_ticket(self._h))
+            arrays = dict(psf=psf, psf_sum=psum, fit=fit)
+            self._pending[ticket] = arrays
+            self._handed_over(ticket - 4)        # the call itself handed over the ticket four calls back
+            return PendingResult(self, ticket, arrays)
         return dict(psf=psf, psf_sum=psum, fit=fit)
 
     @staticmethod
@@ -352,7 +379,11 @@ class PendingResult:
 
     def wait(self):
         if not self._done:
-            _check(self.ctx.lib.mpsfr_wait(self.ctx._h, self.ticket))
+            if self.ticket in self.ctx._pending:         # (not abandoned, not completed by a sync)
+                _check(self.ctx.lib.mpsfr_wait(self.ctx._h, self.ticket))
+                self.ctx._handed_over(self.ticket)
+            elif self.ticket in self.ctx._abandoned:
+                raise MpsfrError(-1, 'ticket %d was abandoned (Context.abandon): its results were dropped' % self.ticket)
             self._done = True
         return self._arrays
 

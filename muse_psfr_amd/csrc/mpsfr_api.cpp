@@ -611,6 +611,23 @@ int mpsfr_sync(mpsfr_ctx* c) {
     return MPSFR_OK;
 }
 
+int mpsfr_abandon(mpsfr_ctx* c) {
+    if (!c) return fail(MPSFR_E_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = MPSFR_OK;
+    for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
+        if (c->lane[k].stream && hipStreamSynchronize(c->lane[k].stream) != hipSuccess) rc = MPSFR_E_HIP;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = MPSFR_E_HIP;
+    // the results stay in the library's staging sets; the caller's arrays are never written
+    for (int k = 0; k < mpsfr_ctx::NTICKET; ++k) {
+        mpsfr_ctx::Ticket& tk = c->ticket[k];
+        tk.pending = false;
+        tk.u_psf = tk.u_sum = tk.u_fit = nullptr;
+    }
+    if (rc != MPSFR_OK) return fail(rc, "a stream failed while the pending calls were drained");
+    return MPSFR_OK;
+}
+
 long mpsfr_last_ticket(mpsfr_ctx* c) { return c ? c->ticket_next - 1 : -1; }
 
 int mpsfr_wait(mpsfr_ctx* c, long ticket) {
@@ -650,18 +667,18 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
                             const uint8_t* mask_rec, const uint8_t* mask_res, double* psf_out,
                             double* psf_sum_out, double* fit_out, int on_device, const StageIO& io = StageIO());
 
-int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const double* gl,
-                      const double* l0, const uint8_t* three_lgs, const double h[2],
-                      double wind_speed, int npsflin, int nl, const double* lbda_nm,
-                      const uint8_t* mask_rec, const uint8_t* mask_res, double* psf_out,
-                      double* psf_sum_out, double* fit_out, int on_device) {
-    if (!c) return fail(MPSFR_E_INVALID, "ctx is NULL");
-    // A call that fails leaves the pipelining state as it found it: the lane rotation and the ring
-    // of parameter slots do not advance, and an event registered with mpsfr_wait_event is consumed
-    // (the caller may destroy it after the call, whatever the outcome).
+// Every entry point that runs the pipeline goes through this guard.  A call that fails leaves the
+// pipelining state as it found it: the lane rotation and the ring of parameter slots do not advance, and
+// an event registered with mpsfr_wait_event is consumed (the caller may destroy it after the call,
+// whatever the outcome).
+static int guarded_call(mpsfr_ctx* c, int ntask, const double* seeing, const double* gl,
+                        const double* l0, const uint8_t* three_lgs, const double h[2],
+                        double wind_speed, int npsflin, int nl, const double* lbda_nm,
+                        const uint8_t* mask_rec, const uint8_t* mask_res, double* psf_out,
+                        double* psf_sum_out, double* fit_out, int on_device, const StageIO& io) {
     const unsigned lane_rr0 = c->lane_rr, stage0 = c->stage_next;
     const int rc = reconstruct_impl(c, ntask, seeing, gl, l0, three_lgs, h, wind_speed, npsflin, nl, lbda_nm,
-                                    mask_rec, mask_res, psf_out, psf_sum_out, fit_out, on_device);
+                                    mask_rec, mask_res, psf_out, psf_sum_out, fit_out, on_device, io);
     if (rc != MPSFR_OK) {
         // whatever the failed call has queued (it may have cleared a slot's guard and started chunks
         // on other lanes) must have drained before the next call reuses the slot and the workspaces
@@ -673,6 +690,16 @@ int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const doubl
         c->wait_next = nullptr;
     }
     return rc;
+}
+
+int mpsfr_reconstruct(mpsfr_ctx* c, int ntask, const double* seeing, const double* gl,
+                      const double* l0, const uint8_t* three_lgs, const double h[2],
+                      double wind_speed, int npsflin, int nl, const double* lbda_nm,
+                      const uint8_t* mask_rec, const uint8_t* mask_res, double* psf_out,
+                      double* psf_sum_out, double* fit_out, int on_device) {
+    if (!c) return fail(MPSFR_E_INVALID, "ctx is NULL");
+    return guarded_call(c, ntask, seeing, gl, l0, three_lgs, h, wind_speed, npsflin, nl, lbda_nm, mask_rec, mask_res,
+                        psf_out, psf_sum_out, fit_out, on_device, StageIO());
 }
 
 static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const double* gl,
@@ -821,7 +848,9 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             nch = NLmax;
         TC = (ntask + nch - 1) / nch;
     }
-    if (staged) TC = ntask;                  // stage-level calls: one pass
+    // stage-level calls on one task's PSD: one pass.  (convolve_final_psf on caller stamps keeps the normal
+    // chunking: its host copies are per chunk, and it needs none of the workspaces of stages A and B.)
+    if (staged && !io.pre_in) TC = ntask;
     if (TC > ntask) TC = ntask;
     const int nchunks = (ntask + TC - 1) / TC;
     // never more lanes than chunks: a lane without a chunk would leave its partial stamp sum
@@ -958,13 +987,16 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         memcpy(key.data() + sizeof(AoGeom) + 1, mask_rec, NAO * NAO);
         memcpy(key.data() + sizeof(AoGeom) + 1 + NAO * NAO, mask_res, NAO * NAO);
     }
-    const bool ao_cached = key == c->cache_geom && c->cache_ao_ptr == c->aotab.p;
+    // (stage-level calls pass placeholder geometry or wavelengths for the stages they skip: those tables are
+    // neither built nor do they displace the cached ones of the last real call)
+    const bool need_ao = !io.pre_in && !io.psd_in, need_lam = !io.psd_out;
+    const bool ao_cached = !need_ao || (key == c->cache_geom && c->cache_ao_ptr == c->aotab.p);
     const std::vector<double> lb_key(lbda_nm, lbda_nm + nl);
-    const bool lam_cached = lb_key == c->cache_lbda && c->cache_lbda_mode == (use_fft_conv ? 1 : 0) &&
+    const bool lam_cached = !need_lam || (lb_key == c->cache_lbda && c->cache_lbda_mode == (use_fft_conv ? 1 : 0) &&
                             c->cache_G_ptr == c->G.p && c->cache_kmuse_ptr == c->kmuse.p &&
                             (!r16 || (c->cache_xtab_valid && c->cache_xtab_ptr == c->xtab.p)) &&
                             (!mf || (c->cache_mf_valid && c->cache_etab_ptr == c->etab.p &&
-                                     c->cache_gtab_ptr == c->gtab.p));
+                                     c->cache_gtab_ptr == c->gtab.p)));
     if (!ao_cached || !lam_cached) {
         for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
             if (c->lane[k].busy && c->lane[k].stream != s0)
@@ -1031,6 +1063,9 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     if (prune && mf && c->mf_floor && thr_blk < kMfFloorLog2) thr_blk = kMfFloorLog2;
     for (int j = 0; j < NL; ++j) {
         mpsfr_ctx::Lane& ln = lane_of(j);
+        if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * (c->f64 ? 8 : 4)))) return rc;
+        if ((rc = ensure(c, ln.fin, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
+        if (io.pre_in) continue;            // convolutions only: no workspace of stages A and B
         if (series) {
             if ((rc = ensure(c, ln.pP, (size_t)TC * ndir * NAO * NAO * sizeof(double)))) return rc;
             if ((rc = ensure(c, ln.pT, (size_t)TC * ndir * H1 * NAO * 2 * sizeof(double)))) return rc;
@@ -1049,8 +1084,6 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             if (ln.D0t.cap != cap_before) HIPCHK(hipMemset(ln.D0t.p, 0, ln.D0t.cap));
         }
         if (!mf && (rc = ensure(c, ln.Tq, (size_t)TC * nl * H1 * NSH * 2 * rsize(c)))) return rc;
-        if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * (c->f64 ? 8 : 4)))) return rc;
-        if ((rc = ensure(c, ln.fin, (size_t)TC * nl * per_stamp * sizeof(double)))) return rc;
         if (mf2) {
             if ((rc = ensure(c, ln.mown, mf2_own_bytes(N, TC, nl)))) return rc;
             if ((rc = ensure(c, ln.muni, mf2_uni_bytes(N, TC, nl)))) return rc;
@@ -1377,12 +1410,8 @@ int mpsfr_simul_psd(mpsfr_ctx* c, double seeing, double gl, double l0, int three
     const double lb = 700.0;                 // (the per-wavelength tables are not used)
     StageIO io;
     io.psd_out = psd_out;
-    mpsfr_ctx* cc = c;
-    const unsigned lane_rr0 = cc->lane_rr, stage0 = cc->stage_next;
-    const int rc = reconstruct_impl(c, 1, &seeing, &gl, &l0, &t3, h, wind_speed, npsflin, 1, &lb, mask_rec, mask_res,
-                                    nullptr, nullptr, nullptr, 0, io);
-    if (rc != MPSFR_OK) { cc->lane_rr = lane_rr0; cc->stage_next = stage0; }
-    return rc;
+    return guarded_call(c, 1, &seeing, &gl, &l0, &t3, h, wind_speed, npsflin, 1, &lb, mask_rec, mask_res,
+                        nullptr, nullptr, nullptr, 0, io);
 }
 
 int mpsfr_psf_from_psd(mpsfr_ctx* c, int ndir, const double* psd, int nl, const double* lbda_nm, double* psf_out) {
@@ -1395,11 +1424,8 @@ int mpsfr_psf_from_psd(mpsfr_ctx* c, int ndir, const double* psd, int nl, const 
     StageIO io;
     io.psd_in = psd;
     io.stop_pre = true;
-    const unsigned lane_rr0 = c->lane_rr, stage0 = c->stage_next;
-    const int rc = reconstruct_impl(c, 1, &one, &half, &l0, nullptr, h, 12.0, npl, nl, lbda_nm, nullptr, nullptr,
-                                    psf_out, nullptr, nullptr, 0, io);
-    if (rc != MPSFR_OK) { c->lane_rr = lane_rr0; c->stage_next = stage0; }
-    return rc;
+    return guarded_call(c, 1, &one, &half, &l0, nullptr, h, 12.0, npl, nl, lbda_nm, nullptr, nullptr,
+                        psf_out, nullptr, nullptr, 0, io);
 }
 
 int mpsfr_convolve_stamps(mpsfr_ctx* c, int ntask, const double* seeing, const double* gl, const double* l0,
@@ -1408,11 +1434,8 @@ int mpsfr_convolve_stamps(mpsfr_ctx* c, int ntask, const double* seeing, const d
     const double h[2] = {100.0, 10000.0};
     StageIO io;
     io.pre_in = psf_in;
-    const unsigned lane_rr0 = c->lane_rr, stage0 = c->stage_next;
-    const int rc = reconstruct_impl(c, ntask, seeing, gl, l0, nullptr, h, 12.0, 1, nl, lbda_nm, nullptr, nullptr,
-                                    psf_out, nullptr, nullptr, 0, io);
-    if (rc != MPSFR_OK) { c->lane_rr = lane_rr0; c->stage_next = stage0; }
-    return rc;
+    return guarded_call(c, ntask, seeing, gl, l0, nullptr, h, 12.0, 1, nl, lbda_nm, nullptr, nullptr,
+                        psf_out, nullptr, nullptr, 0, io);
 }
 
 int mpsfr_fit_stamps(mpsfr_ctx* c, int nstamp, const double* stamps, double* fit_out,

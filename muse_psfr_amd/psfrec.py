@@ -217,18 +217,23 @@ def _reconstruct_pipelined(lbda, stats, three, laser_idx, npsflin, h, dim, dimps
     see, gl, l0 = (np.ascontiguousarray(stats[:, k], dtype=float) for k in range(3))
     t3 = np.asarray(three).astype(np.uint8)
     psum = None
+    # Whatever goes wrong between the first asynchronous call and the last wait -- a library error in a
+    # later part, a MemoryError in the template, a KeyboardInterrupt -- the parts already queued are
+    # abandoned (the library drains and forgets their output arrays, which the context kept alive until
+    # now): nothing is left behind that a later call on the cached context could write through.
     try:
-        pend = [ctx.reconstruct_async(lbda, see[a:b], gl[a:b], l0[a:b], t3[a:b], h, npsflin=npsflin,
-                                      masks=masks, want_psf=False)
-                for a, b in zip(bounds[:-1], bounds[1:])]
+        pend = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            pend.append(ctx.reconstruct_async(lbda, see[a:b], gl[a:b], l0[a:b], t3[a:b], h, npsflin=npsflin,
+                                              masks=masks, want_psf=False))
         rec, blk = _fit_rows_template(lbda, stats, laser_idx)          # (while the GPU works)
         for (a, b), p in zip(zip(bounds[:-1], bounds[1:]), pend):
             r = p.wait()
             _fit_rows_fill(blk[a * nlam:b * nlam], r['fit'], pixscale)
             psum = r['psf_sum'] if psum is None else psum + r['psf_sum']
-    except MpsfrError as e:
-        ctx.sync()
-        if e.code == E_GRID:
+    except BaseException as e:
+        ctx.abandon()
+        if isinstance(e, MpsfrError) and e.code == E_GRID:
             raise ValueError(str(e)) from None
         raise
     return dict(psf_sum=psum, devices=[dev], rec=True), rec
@@ -480,14 +485,16 @@ def compute_psf_from_sparta(filename, extname='SPARTA_ATM_DATA', npsflin=1, lmin
 
     ntask, nlam = len(stats), lbda.size
     devs = _fanout_devices(devices, device, ntask, n_jobs)
-    if fits is None and len(devs) == 1 and ntask >= 2 * PIPELINE_MIN_TASKS:
+    if len(devs) == 1 and ntask >= 2 * PIPELINE_MIN_TASKS:
         # A large table on one device goes through the library as up to four asynchronous host-output
         # calls (mpsfr_reconstruct on_device = 2): the records of one part are assembled while the GPU
         # works on the next ones.  Per-task results do not depend on the split; the stamp sums of the
         # parts are added in order.
         r, rec = _reconstruct_pipelined(lbda, stats, three, laser_idx, npsflin, h, dim, dimpsf, pixscale, precision,
                                         cutoff_masks, devs[0])
-        out.append(_minifits.BinTableHDU(rec, _minifits.Header(), 'FIT_ROWS'))
+        # (with astropy -- the reference's environment -- the same record array becomes an astropy table HDU)
+        out.append(_minifits.BinTableHDU(rec, _minifits.Header(), 'FIT_ROWS') if fits is None
+                   else fits.BinTableHDU(data=rec, name='FIT_ROWS'))
     else:
         r = _reconstruct(lbda, to_compute, npsflin, h, dim, dimpsf, pixscale, precision, cutoff_masks,
                          device, want_psf=False, devices=devices, n_jobs=n_jobs)

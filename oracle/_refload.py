@@ -37,17 +37,22 @@ class _Image:
                    verbose=False):
         import psfr_oracle as O
         assert circular and not fit_back and unit_center is None and unit_fwhm is None
-        (peak, p0, q0, fwhm_arcsec, n), chi2, _ = O.moffat_fit(self.data, 0.2, full=True)
+        f = O.moffat_fit(self.data, 0.2, errors=True)
         r = _FitResult()
-        fw = fwhm_arcsec / 0.2                      # pixels: psfrec.py:868 multiplies by 0.2
-        a = fw / (2 * np.sqrt(2 ** (1 / n) - 1))
-        r.center = np.array([p0, q0])
-        r.flux = peak * np.pi * a * a / (n - 1)
+        fw = f['fwhm'] / 0.2                        # pixels: psfrec.py:868 multiplies by 0.2
+        r.center = f['center'].copy()
+        r.flux = f['flux']
         r.fwhm = np.array([fw, fw])
-        r.cont, r.n, r.rot, r.peak = 0.0, n, 0.0, peak
-        r.err_center = np.zeros(2)
-        r.err_flux, r.err_fwhm, r.err_cont, r.err_n, r.err_rot, r.err_peak = (
-            0.0, np.zeros(2), 0.0, 0.0, 0.0, 0.0)
+        r.cont, r.n, r.rot, r.peak = 0.0, f['n'], 0.0, f['peak']
+        # mpdaf's error recipe as restated in psfr_oracle.moffat_fit (cov_x * chi2 / dof)
+        # (attribute order = mpdaf's Moffat2D: it becomes the column order of the reference's table)
+        r.err_center = f['err_center'].copy()
+        r.err_flux = f['err_flux']
+        r.err_fwhm = np.array([f['err_fwhm'], f['err_fwhm']]) / 0.2      # psfrec.py:869 multiplies by 0.2
+        r.err_cont = 0.0
+        r.err_n = f['err_n']
+        r.err_rot = 0.0
+        r.err_peak = f['err_peak']
         r.ima = None
         return r
 

@@ -212,9 +212,13 @@ def section_lgs(ref):
             mean, time.time() - t, len(res['FIT_ROWS'].data)), flush=True)
         assert [h.name for h in res] == ['PRIMARY', 'SPARTA_ATM_DATA', 'FIT_ROWS', 'FIT_MEAN', 'PSF_MEAN']
         fr, fm = res['FIT_ROWS'].data, res['FIT_MEAN'].data
-        for c in ('lbda', 'fwhm', 'n', 'peak', 'center', 'SEEING', 'GL', 'L0', 'row_idx', 'lgs_idx'):
+        assert fr.columns.names[:11] == ['lbda', 'center', 'flux', 'fwhm', 'n', 'peak', 'err_center', 'err_flux',
+                                         'err_fwhm', 'err_n', 'err_peak'], fr.columns.names
+        for c in ('lbda', 'fwhm', 'n', 'peak', 'center', 'flux', 'err_center', 'err_flux', 'err_fwhm', 'err_n',
+                  'err_peak', 'SEEING', 'GL', 'L0', 'row_idx', 'lgs_idx'):
             out['%s_rows_%s' % (tag, c)] = np.array(fr[c])
-        for c in ('lbda', 'fwhm', 'n'):
+        for c in ('lbda', 'fwhm', 'n', 'peak', 'center', 'flux', 'err_center', 'err_flux', 'err_fwhm', 'err_n',
+                  'err_peak'):
             out['%s_mean_%s' % (tag, c)] = np.array(fm[c])
         hdr = res['FIT_MEAN'].header
         out['%s_mean_hdr' % tag] = np.array([hdr['SEEING'], hdr['GL'], hdr['L0']])

@@ -378,9 +378,23 @@ def moffat_model(v, P, Q):
     return v[0] * (1 + ((P - v[1]) / v[3]) ** 2 + ((Q - v[2]) / v[3]) ** 2) ** (-v[4])
 
 
-def moffat_fit(im, pixscale=0.2, full=False):
+def moffat_fit(im, pixscale=0.2, full=False, errors=False):
     """Stand-in for mpdaf Image.moffat_fit(circular=True, fit_back=False) (psfrec.py:863-865),
-    SURVEY.md Appendix A.  Returns (peak, p0, q0, fwhm_arcsec, beta)."""
+    SURVEY.md Appendix A.  Returns (peak, p0, q0, fwhm_arcsec, beta).
+
+    errors=True returns a dict with, besides those five, the columns psfrec.py:866-870 keeps from
+    mpdaf's result object: flux, err_peak, err_center, err_n, err_fwhm (arcsec), err_flux (and
+    alpha, err_alpha, chi2, dof).  mpdaf's published error recipe: MINPACK's `cov_x` (the inverse
+    of J^T J at the solution) scaled by the reduced chi square,
+        err_i = sqrt(|cov_x[i, i]| * chi2 / dof),    dof = npix - 5,
+    for the fitted variables (I, p0, q0, a, n); flux = I pi a^2 / (n - 1) (the integral of the
+    circular Moffat).  Derived quantities by first-order propagation: err_fwhm through
+    fwhm = 2 a sqrt(2^(1/n) - 1) with the (a, n) block of the covariance (the two are strongly
+    anti-correlated: the variance of the FWHM is what a fit in (fwhm, n) would report directly);
+    err_flux from the relative errors of I, a^2 and (n - 1) added in quadrature.  mpdaf is absent
+    (SURVEY.md 8c): the formulas mpdaf itself uses for those two derived columns are NOT pinned
+    by anything in the reference -- "parity unpinned" for err_fwhm / err_flux beyond this
+    definition."""
     from scipy.optimize import leastsq
     P, Q = np.indices(im.shape)
     P = P.ravel().astype(float)
@@ -389,14 +403,35 @@ def moffat_fit(im, pixscale=0.2, full=False):
     c = np.unravel_index(im.argmax(), im.shape)
     n0 = 2.0
     a0 = 4.0 / (2 * np.sqrt(2 ** (1 / n0) - 1))
-    v, _, info, _, ier = leastsq(lambda v: moffat_model(v, P, Q) - d,
-                                 [im[c], c[0], c[1], a0, n0], full_output=True,
-                                 xtol=1e-14, ftol=1e-14, gtol=0.0)
+    v, cov, info, _, ier = leastsq(lambda v: moffat_model(v, P, Q) - d,
+                                   [im[c], c[0], c[1], a0, n0], full_output=True,
+                                   xtol=1e-14, ftol=1e-14, gtol=0.0)
     a, n = abs(v[3]), v[4]
-    fwhm = 2 * a * np.sqrt(2 ** (1 / n) - 1) * pixscale
+    s2 = 2 ** (1 / n) - 1
+    fwhm = 2 * a * np.sqrt(s2) * pixscale
     res = (v[0], v[1], v[2], fwhm, n)
+    chi2 = float(np.sum(info['fvec'] ** 2))
+    if errors:
+        dof = d.size - v.size
+        s = abs(chi2 / dof)
+        out = dict(peak=v[0], center=np.array([v[1], v[2]]), fwhm=fwhm, n=n, alpha=a, chi2=chi2, dof=dof,
+                   flux=v[0] * np.pi * a * a / (n - 1))
+        if cov is None:                 # singular J^T J (flat valley): mpdaf then reports no errors
+            out.update(err_peak=np.nan, err_center=np.full(2, np.nan), err_alpha=np.nan, err_n=np.nan,
+                       err_fwhm=np.nan, err_flux=np.nan)
+            return out
+        err = np.sqrt(np.abs(np.diag(cov)) * s)
+        # d fwhm / d(a, n), pixels
+        g = np.array([2 * np.sqrt(s2) * np.sign(v[3]),
+                      -a * 2 ** (1 / n) * np.log(2) / (n * n * np.sqrt(s2))])
+        var_fw = g @ cov[3:5, 3:5] @ g
+        with np.errstate(all='ignore'):
+            relf = np.sqrt((err[0] / v[0]) ** 2 + (2 * err[3] / a) ** 2 + (err[4] / (n - 1)) ** 2)
+        out.update(err_peak=err[0], err_center=err[1:3].copy(), err_alpha=err[3], err_n=err[4],
+                   err_fwhm=np.sqrt(abs(var_fw) * s) * pixscale, err_flux=abs(out['flux']) * relf)
+        return out
     if full:
-        return res, float(np.sum(info['fvec'] ** 2)), info['nfev']
+        return res, chi2, info['nfev']
     return res
 
 

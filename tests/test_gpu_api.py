@@ -210,6 +210,13 @@ def test_sparta_front_end_against_the_reference(api, golden, ref_masks, tag, mea
     assert np.abs(np.asarray(fr['peak']) / g[tag + '_rows_peak'] - 1).max() < 1e-4
     assert np.abs(np.asarray(fm['fwhm']) - g[tag + '_mean_fwhm']).max() < 1e-4
     assert np.abs(np.asarray(fm['n']) - g[tag + '_mean_n']).max() < 1e-4
+    # the columns psfrec.py:866-870 keeps besides (fwhm, n, center, peak): flux and the err_* of mpdaf's
+    # recipe (G7 holds them as the reference's own table carries them with the oracle's fit plugged in)
+    np.testing.assert_allclose(np.asarray(fr['flux']), g[tag + '_rows_flux'], rtol=1e-4)
+    np.testing.assert_allclose(np.asarray(fm['flux']), g[tag + '_mean_flux'], rtol=1e-4)
+    for c in ('err_center', 'err_flux', 'err_fwhm', 'err_n', 'err_peak'):
+        np.testing.assert_allclose(np.asarray(fr[c]), g['%s_rows_%s' % (tag, c)], rtol=2e-3, err_msg=c)
+        np.testing.assert_allclose(np.asarray(fm[c]), g['%s_mean_%s' % (tag, c)], rtol=2e-3, err_msg=c)
     hdr = res['FIT_MEAN'].header
     np.testing.assert_allclose([hdr['SEEING'], hdr['GL'], hdr['L0']], g[tag + '_mean_hdr'], rtol=1e-13)
     pm = np.asarray(res['PSF_MEAN'].data)
@@ -382,8 +389,6 @@ def test_large_table_in_asynchronous_parts_equals_one_call(api, monkeypatch):
         tbl.data['LGS%d_L0' % k][:] = l0
     tbl.data['LGS2_L0'][::7] = 150.0             # three-laser rows
     kw = dict(verbose=False, dim=256, pixscale=api.grid_pixscale(256), lmin=500, lmax=900, nl=5, mean_of_lgs=False)
-    if psfrec._astropy()[0] is not None:
-        pytest.skip('the part-wise assembly is the path without astropy')
     a = api.compute_psf_from_sparta(_hdul(tbl), **kw)
     monkeypatch.setattr(psfrec, 'PIPELINE_MIN_TASKS', 10 ** 9)
     b = api.compute_psf_from_sparta(_hdul(tbl), **kw)
@@ -412,3 +417,85 @@ def test_large_table_on_a_grid_too_small_raises_like_the_reference(api):
         api.compute_psf_from_sparta(_hdul(tbl), lmin=200, lmax=300, **kw)
     res = api.compute_psf_from_sparta(_hdul(tbl), lmin=500, lmax=900, **kw)
     assert len(res['FIT_ROWS'].data) == n * 3
+
+
+def _big_table(api, n):
+    see, gl, l0 = api.synthetic_rows(n)
+    tbl = api.create_sparta_table(nlines=n)
+    for k in range(1, 5):
+        tbl.data['LGS%d_SEEING' % k][:] = see
+        tbl.data['LGS%d_TUR_GND' % k][:] = gl
+        tbl.data['LGS%d_L0' % k][:] = l0
+    return tbl
+
+
+@pytest.mark.parametrize('exc', [RuntimeError, KeyboardInterrupt])
+def test_large_table_whose_later_part_fails_leaves_no_pending_arrays(api, monkeypatch, exc):
+    """a failure AFTER the first asynchronous parts have been queued (any exception, not only a
+    library error).  The queued parts are abandoned -- mpsfr_abandon: the GPU drains, the library forgets the
+    output arrays without writing to them -- so the cached context holds no pointer into freed memory, and the
+    next table through the same context is right."""
+    import gc
+    from muse_psfr_amd import psfrec
+    from muse_psfr_amd._lib import Context
+    tbl = _big_table(api, 520)                    # four parts
+    kw = dict(verbose=False, dim=128, pixscale=api.grid_pixscale(128), lmin=500, lmax=900, nl=3)
+    want = api.compute_psf_from_sparta(_hdul(tbl), **kw)
+    real, calls, seen = Context.reconstruct_async, [], []
+
+    def failing(self, *a, **k):
+        calls.append(1)
+        if len(calls) == 3:
+            seen.append((self, dict(self._pending)))
+            raise exc('part 3')
+        return real(self, *a, **k)
+    monkeypatch.setattr(Context, 'reconstruct_async', failing)
+    with pytest.raises(exc):
+        api.compute_psf_from_sparta(_hdul(tbl), **kw)
+    monkeypatch.setattr(Context, 'reconstruct_async', real)
+    ctx, held = seen[0]
+    assert len(held) == 2 and not ctx._pending and ctx._abandoned >= set(held)
+    # the two queued parts were never handed over: their arrays still hold what np.empty left (the library
+    # did not write them), and waiting for one of them now says so
+    gc.collect()
+    got = api.compute_psf_from_sparta(_hdul(tbl), **kw)
+    for name in want['FIT_ROWS'].data.dtype.names:
+        np.testing.assert_array_equal(want['FIT_ROWS'].data[name], got['FIT_ROWS'].data[name], err_msg=name)
+    np.testing.assert_array_equal(want['PSF_MEAN'].data, got['PSF_MEAN'].data)
+
+
+def test_dropped_pending_results_are_kept_alive_by_the_context(api):
+    """Context.reconstruct_async results that are dropped without wait().  The library holds raw
+    pointers to their arrays until the ticket is handed over (in a wait, a sync, or when the ring of four comes
+    round): the context keeps the arrays alive for exactly that long."""
+    import gc
+    import weakref
+    ps = api.grid_pixscale(128)
+    ctx = api.Context(dim=128, pixscale=ps, precision='mixed')
+    see, gl, l0 = api.synthetic_rows(6)
+    lb = np.array([500.0, 700.0, 900.0])
+    want = ctx.reconstruct(lb, see, gl, l0, None, H)
+    refs = []
+    for k in range(9):                               # more than twice round the ring, nobody waits
+        p = ctx.reconstruct_async(lb, see, gl, l0, None, H)
+        refs.append(weakref.ref(p._arrays['fit']))
+        del p
+        gc.collect()
+        assert len(ctx._pending) <= 4 and refs[-1]() is not None
+        if k >= 4:
+            assert refs[k - 4]() is None                 # handed over by the call four tickets later: released
+    last = ctx.reconstruct_async(lb, see, gl, l0, None, H)
+    r = last.wait()
+    assert not ctx._pending and all(w() is None for w in refs)
+    assert np.array_equal(r['fit'], want['fit']) and np.array_equal(r['psf'], want['psf'])
+    # abandon: the arrays of the calls in flight are never written
+    p = ctx.reconstruct_async(lb, see, gl, l0, None, H)
+    p._arrays['fit'][:] = -7.0
+    ctx.abandon()
+    ctx.sync()
+    assert np.all(p._arrays['fit'] == -7.0)
+    with pytest.raises(api.MpsfrError):
+        p.wait()
+    r = ctx.reconstruct_async(lb, see, gl, l0, None, H).wait()      # the context stays usable
+    assert np.array_equal(r['fit'], want['fit'])
+    ctx.close()

@@ -185,6 +185,41 @@ def test_fit_kernel_against_minpack_on_golden_stamps(api, golden):
     ctx.close()
 
 
+@pytest.mark.parametrize('prec', ['mixed', 'f64'])
+def test_fit_error_and_flux_columns_against_the_oracle(api, golden, prec):
+    """fit_out[8..13] and [15] (err_peak, err_center, err_alpha, err_n, err_fwhm, flux: the columns
+    psfrec.py:866-870 keeps from mpdaf's fit object) and the FIT_ROWS columns the host derives from them,
+    on the reference's own final stamps (G2), against the oracle's restatement of mpdaf's recipe
+    (MINPACK cov_x * chi2 / dof).  The library takes the covariance from the float normal matrix of the
+    last LM iteration, a point within ~1e-4 of the minimum: relative 1e-3."""
+    from muse_psfr_amd.psfrec import _fit_columns
+    g = golden('g2_native1280')
+    ctx = api.Context(dim=128, pixscale=0.2, precision=prec)
+    worst = {}
+    for k in range(len(g['meta'])):
+        fin = g['fin_%d' % k]
+        f = ctx.fit_stamps(fin)
+        cols = _fit_columns(np.arange(len(fin), dtype=float), f, 0.2)
+        for j in range(len(fin)):
+            o = O.moffat_fit(fin[j], 0.2, errors=True)
+            got = dict(err_peak=f[j, 8], err_center0=f[j, 9], err_center1=f[j, 10], err_alpha=f[j, 11],
+                       err_n=f[j, 12], err_fwhm=f[j, 13] * 0.2, flux=f[j, 15], chi2=f[j, 6],
+                       col_err_flux=cols['err_flux'][j], col_err_fwhm=cols['err_fwhm'][j, 1],
+                       col_err_center=cols['err_center'][j, 1], col_err_n=cols['err_n'][j],
+                       col_err_peak=cols['err_peak'][j], col_flux=cols['flux'][j])
+            want = dict(err_peak=o['err_peak'], err_center0=o['err_center'][0], err_center1=o['err_center'][1],
+                        err_alpha=o['err_alpha'], err_n=o['err_n'], err_fwhm=o['err_fwhm'], flux=o['flux'],
+                        chi2=o['chi2'], col_err_flux=o['err_flux'], col_err_fwhm=o['err_fwhm'],
+                        col_err_center=o['err_center'][1], col_err_n=o['err_n'], col_err_peak=o['err_peak'],
+                        col_flux=o['flux'])
+            for c in got:
+                worst[c] = max(worst.get(c, 0.0), abs(got[c] / want[c] - 1))
+    ctx.close()
+    record_margin('fit_error_columns_%s' % prec, **{'rel_' + c: v for c, v in worst.items()})
+    assert worst['flux'] < 1e-5 and worst['col_flux'] < 1e-5, worst
+    assert max(worst.values()) < 1e-3, worst
+
+
 def test_chunking_and_repeat_are_bitwise_invariant(api):
     see, gl, l0 = api.synthetic_rows(9)
     lb = np.linspace(465, 930, 5)

@@ -149,6 +149,46 @@ def test_sparta_golden_is_self_consistent(golden):
     np.testing.assert_allclose(O.fit_psf_cube(g['fin_row0'][[5]]), g['fit_rows'][0][[5]], rtol=1e-7)
 
 
+def test_fit_error_columns_follow_the_covariance_recipe(golden):
+    """The err_* / flux columns psfrec.py:866-870 keeps from mpdaf's fit object: the oracle's restatement
+    (MINPACK cov_x * chi2 / dof) against a covariance built here from a finite-difference Jacobian at the
+    solution, and against the FIT_MEAN rows the reference wrote into G7 through it."""
+    g = golden('g7_sparta_lgs')
+    for tag in ('mean', 'lgs'):
+        pm = g[tag + '_psf_mean']
+        for k in (0, 3):
+            f = O.moffat_fit(pm[k], 0.2, errors=True)
+            P, Q = (a.ravel().astype(float) for a in np.indices(pm[k].shape))
+            v = np.array([f['peak'], f['center'][0], f['center'][1], f['alpha'], f['n']])
+            J = np.empty((P.size, 5))
+            for i in range(5):
+                h = 1e-6 * max(abs(v[i]), 1.0)
+                vp, vm = v.copy(), v.copy()
+                vp[i] += h
+                vm[i] -= h
+                J[:, i] = (O.moffat_model(vp, P, Q) - O.moffat_model(vm, P, Q)) / (2 * h)
+            cov = np.linalg.inv(J.T @ J) * f['chi2'] / f['dof']
+            err = np.sqrt(np.diag(cov))
+            np.testing.assert_allclose([f['err_peak'], f['err_center'][0], f['err_center'][1], f['err_alpha'],
+                                        f['err_n']], err, rtol=1e-5)
+            # the FWHM's error = what a fit in (fwhm, n) reports: transform the Jacobian instead of the
+            # covariance (column of a at fixed fwhm) and invert again
+            s2 = 2 ** (1 / f['n']) - 1
+            dfw = np.array([2 * np.sqrt(s2), -f['alpha'] * 2 ** (1 / f['n']) * np.log(2) / (f['n'] ** 2 * np.sqrt(s2))])
+            Jw = J.copy()
+            Jw[:, 3] = J[:, 3] / dfw[0]                       # d/dfw at fixed n
+            Jw[:, 4] = J[:, 4] - J[:, 3] * dfw[1] / dfw[0]    # d/dn at fixed fw
+            covw = np.linalg.inv(Jw.T @ Jw) * f['chi2'] / f['dof']
+            np.testing.assert_allclose(f['err_fwhm'], np.sqrt(covw[3, 3]) * 0.2, rtol=1e-5)
+            np.testing.assert_allclose(f['flux'], f['peak'] * np.pi * f['alpha'] ** 2 / (f['n'] - 1), rtol=1e-14)
+            # ... and the reference's FIT_MEAN table (psfrec.py:1105) carries exactly these
+            for c, want in (('peak', f['peak']), ('flux', f['flux']), ('err_peak', f['err_peak']),
+                            ('err_n', f['err_n']), ('err_flux', f['err_flux'])):
+                np.testing.assert_allclose(g['%s_mean_%s' % (tag, c)][k], want, rtol=1e-6, err_msg=c)
+            np.testing.assert_allclose(g[tag + '_mean_err_fwhm'][k], [f['err_fwhm']] * 2, rtol=1e-6)
+            np.testing.assert_allclose(g[tag + '_mean_err_center'][k], f['err_center'], rtol=1e-6)
+
+
 def test_oracle_reproduces_the_reference_sparta_front_end(golden, ref_masks):
     """G7: the reference's own compute_psf_from_sparta (psfrec.py:981-1120, jittered LGS columns,
     mean_of_lgs True / False) -- the oracle's compute_psf on the task values the reference
