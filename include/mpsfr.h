@@ -72,15 +72,30 @@ const char* mpsfr_last_error(void);
  * 65536 stamps / 4 GiB of workspace, balanced passes beyond; a synchronous call -- host outputs --
  * of 8192 stamps or more: one pass per lane); "fast_exp" (mixed mode only,
  * default 1: hardware exp2 for the OTF); "fft_conv" (mixed mode only, default 1: the two 41x41
- * convolutions through 64-point FFTs instead of the direct form); "streams" (0 = automatic = 2,
+ * convolutions through 64-point FFTs instead of the direct form); "cu_partition" (default 0; 1: every lane's stream is created with a CU mask and owns
+ * 1/lanes of the compute units -- measured slower, profiles/r05_experiments.md); "streams" (0 = automatic = 2,
  * or 1..4 pipeline lanes: consecutive chunks -- of one call and of consecutive asynchronous
  * calls -- go to successive HIP streams with their own workspaces so that one chunk's tail
  * overlaps the next one's body; results are independent of it except for the summation order of
  * psf_sum_out in multi-chunk calls); "pipeline_calls" (default 1: asynchronous calls rotate over
  * the lanes; 0: every call starts on the first lane); "prune_eps" (mixed mode only, default 1e-9:
  * the parts of the OTF half plane -- trailing lines, and 16 x 32 blocks inside the lines kept --
- * that together weigh less than eps of the PSF peak are neither generated nor summed: no stamp
- * pixel changes by more than eps of the peak; 0 = everything); "otf_mfma" (mixed mode only,
+ * whose elements together weigh less than eps of OTF[0][0] (<= eps of the PSF peak, the sum of the OTF, whose
+ * elements are all >= 0) are neither generated nor summed; 0 = everything); "tier_eps" (mixed mode, matrix-core
+ * stage only, default 4e-6: the two precision tiers of that stage -- blocks whose largest element is below
+ * 2^-29 of OTF[0][0] are dropped, blocks below 2^-18 run without the low fp16 half of the OTF -- are applied,
+ * per task and wavelength, only as far as the OTF mass each of them leaves out stays below tier_eps / 2 of a
+ * lower bound of the PSF peak (the OTF summed exactly over its first four lines); where it would not, the
+ * thresholds of that (task, wavelength) are lowered until it does.  0 = no tiers; inf = tiers without a budget).
+ * WHAT THE TWO TOGETHER GUARANTEE, for every input: with eps = prune_eps + tier_eps no pixel of a stamp before
+ * the convolutions (psf_muse, psfrec.py:644-686) moves by more than eps of that stamp's peak -- up to the
+ * stamp's normalisation to unit sum (psfrec.py:685), which in the worst case (all 1600 pixels moved the same
+ * way) rescales the stamp by 1600 eps peak / sum; the Moffat fwhm, n and centre do not depend on the
+ * normalisation, and the two convolutions (non-negative kernels of unit sum) do not increase a difference.
+ * What the approximations really do on the workloads measured (tests/test_gpu_parity.py::
+ * test_precision_tiers_of_the_matrix_core_stage): <= 3e-7 of the peak, |d beta| <= 2e-6, and the budget
+ * is not reached (it is a guarantee for inputs nobody measured, e.g. an OTF whose coherent plateau sits just
+ * below the floor); "otf_mfma" (mixed mode only,
  * default 1: the per-wavelength stage as split-fp16 contractions on the matrix cores; 0: LDS
  * FFTs on the vector pipe); "profile" (0/1: bracket every kernel launch
  * with HIP events on the stream it is launched on -- the event packets cost ~8 % of a step);
@@ -96,12 +111,11 @@ const char* mpsfr_last_error(void);
  * waits once for the first lane's column transforms / per-wavelength preparation, so that the two
  * lanes do not start in step: +3 % in a sustained run of 100-row calls, -1 % on a burst of 20;
  * results do not depend on it).
- * Experiment switches of the matrix-core stage (results depend on them below 3e-7 of a stamp's
- * peak: the precision tiers are approximations of the size of the block pruning): "mf_kernel" (2 = thin-wave kernel with precision tiers
+ * Experiment switches of the matrix-core stage (results depend on them within the bound of "tier_eps"): "mf_kernel" (2 = thin-wave kernel with precision tiers
  * for one direction, 1 = the blocked kernel that several directions always use), "mf_permax"
  * (1..7 wavelengths per workgroup, default 6), "mf_floor" (default 1: blocks below the fp16
- * representation floor are skipped), "mf_mid_log2" (default -18.01: blocks below 2^this of the
- * OTF maximum run without the low half of the OTF), "mf_clock" (phase time stamps; builds with
+ * representation floor are skipped, within "tier_eps"), "mf_mid_log2" (default -18.01: blocks below 2^this of
+ * OTF[0][0] run without the low half of the OTF, within "tier_eps"), "mf_clock" (phase time stamps; builds with
  * -DMPSFR_MF_CLOCK=1 only), "prune_fixed" (a fixed number of lines for the FFT form). */
 int mpsfr_set_option(mpsfr_ctx* ctx, const char* key, double value);
 
@@ -121,6 +135,13 @@ int mpsfr_set_option(mpsfr_ctx* ctx, const char* key, double value);
  *                  [i_fx][j_fy] like the reference's arrays, or NULL for the exact rule
  *                  |k| >= 24 / |k| > 24 on the integer frequency grid.  (In the reference these
  *                  masks depend on last-bit libm rounding; see DESIGN.md "cut-off masks".)
+ *                  NOTE: NULL is NOT what the Python API passes by default.  muse_psfr_amd.compute_psf /
+ *                  compute_psf_from_sparta default to cutoff_masks='host' -- the masks as the caller's NumPy
+ *                  evaluates psfrec.py:257/:435, i.e. what the reference itself would compute on that
+ *                  machine -- which differs from the exact rule on 44-52 of the 160 boundary pixels and
+ *                  moves beta by up to 3e-3 (30x the parity tolerance).  A C caller that wants the results
+ *                  of the Python default (or of a given reference installation) passes that installation's
+ *                  masks; cutoff_masks='exact' in Python is this NULL.
  * psf_out        : [ntask][nl][dimpsf][dimpsf] final stamps (after both convolutions), or NULL
  * psf_sum_out    : [nl][dimpsf][dimpsf] sum over the ntask stamps (the caller divides by the
  *                  global task count to get PSF_MEAN, psfrec.py:1104), or NULL

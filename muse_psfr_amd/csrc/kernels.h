@@ -148,8 +148,11 @@ size_t mf2_part_bytes(int N, int ntask, int nl);
 void mf2_groups(int nl, int permax, int* per, int* ngr);
 // K_MF_PREP: block masks and the work lists of launch_otf_mfma2 from the block minima of launch_dmin
 // (d_dminb = nullptr: no pruning); d_sched[0..16] must be zero (launch_colfft_dphi does that)
+// thr: the eps rule; thr_floor / thr_mid: the precision tiers, applied per (task, wavelength) as far as the OTF
+// mass each leaves out stays below tier_half of a lower bound of the PSF peak (d_D0t, d_tl2; tier_half <= 0: no budget)
 void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const LamPar* d_lp,
-                    const float* d_dminb, const float* d_tlb, float thr, float thr_mid, void* d_own,
+                    const float* d_dminb, const float* d_tlb, float thr, float thr_floor, float thr_mid,
+                    float tier_half, const void* d_D0t, const float* d_tl2, void* d_own,
                     void* d_uni, void* d_sched, const float* d_dlin = nullptr);
 // (d_dlin: instead of d_dminb, the per-line block minima of launch_dphi_series -- the minimum over a
 // block's 16 lines is then taken by the kernel itself and launch_dmin16 is not needed)

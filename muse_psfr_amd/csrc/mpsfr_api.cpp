@@ -80,6 +80,7 @@ struct mpsfr_ctx {
     int mf_kernel = 2;           // 2: thin-wave kernel with precision tiers (otf_mfma2.hip, one direction); 1: otf_mfma.hip
     int mf_permax = 6;           // wavelengths per workgroup of the thin-wave kernel (6: 12 waves, 7: 14 waves)
     double mf_mid_log2 = -18.01; // blocks below 2^this need no low half of the OTF (see otf_mfma2.hip)
+    double tier_eps = 4.0e-6;    // budget of the two precision tiers, of the PSF peak (0: no tiers; inf: no budget)
     bool mf_clock = false;       // experiments: phase time stamps of the matrix-core kernel
     int stage_a = 1;             // stage A: 1 = automatic (the series + patch form of stage_a2.hip from 512^2 on, and at
                                  // 256^2 with several directions; the full-size transforms otherwise: one direction at
@@ -98,6 +99,7 @@ struct mpsfr_ctx {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;       // after the lane's last chunk of the most recent call
         bool busy = false;               // `done` has been recorded
+        int ncu = 0;                     // CUs the lane's stream may use (0: all of them)
         DevBuf C, s00, D0t, Tq, pre, fin, dmin, dblk, vkeep, dminb, order, mown, muni, msched, mpart;
         DevBuf pP, pT, psp, dlin;        // series form of stage A: patch, its row transforms, its sum; line minima
         // device outputs of its most recent calls: `done` is recorded behind every call of the lane,
@@ -110,6 +112,7 @@ struct mpsfr_ctx {
     static constexpr int MAX_LANES = 4;
     Lane lane[MAX_LANES];
     int nlanes = 0;              // 0 = automatic (two lanes)
+    int cu_partition = 0;        // 1: every lane's stream owns 1/lanes of the CUs (hipExtStreamCreateWithCUMask)
     bool pipeline_calls = true;  // successive asynchronous calls rotate over the lanes
     unsigned lane_rr = 0;        // lane of the next chunk
     hipEvent_t tables_ready = nullptr;
@@ -543,10 +546,27 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         c->chunk_tasks = (int)value;
     } else if (!strcmp(key, "fast_exp")) {
         c->fast_exp = value != 0.0;
-    } else if (!strcmp(key, "streams")) {
-        if (value < 0.0 || value > 4.0 || value != (int)value)
+    } else if (!strcmp(key, "streams") || !strcmp(key, "cu_partition")) {
+        const bool lanes = key[0] == 's';
+        if (lanes && (value < 0.0 || value > 4.0 || value != (int)value))
             return fail(MPSFR_E_INVALID, "streams must be 0 (automatic) or 1..4");
-        c->nlanes = (int)value;
+        if (!lanes && value != 0.0 && value != 1.0) return fail(MPSFR_E_INVALID, "cu_partition must be 0 or 1");
+        if (c->cu_partition || (!lanes && value != 0.0)) {
+            // the lanes' streams carry their CU masks: drain and drop them, the next call creates them anew
+            HIPCHK(hipSetDevice(c->device));
+            for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k) {
+                mpsfr_ctx::Lane& ln = c->lane[k];
+                if (!ln.stream) continue;
+                HIPCHK(hipStreamSynchronize(ln.stream));
+                HIPCHK(hipStreamDestroy(ln.stream));
+                ln.stream = nullptr;
+                ln.busy = false;
+                ln.ncu = 0;
+            }
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        if (lanes) c->nlanes = (int)value;
+        else c->cu_partition = (int)value;
     } else if (!strcmp(key, "prune_fixed")) {
         c->prune_fixed = (int)value;
     } else if (!strcmp(key, "prune_eps_f64")) {
@@ -567,6 +587,9 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
     } else if (!strcmp(key, "mf_permax")) {
         if (value != (int)value || value < 1.0 || value > 7.0) return fail(MPSFR_E_INVALID, "mf_permax must be 1..7");
         c->mf_permax = (int)value;
+    } else if (!strcmp(key, "tier_eps")) {
+        if (!(value >= 0.0)) return fail(MPSFR_E_INVALID, "tier_eps must be >= 0 (inf: tiers without a budget)");
+        c->tier_eps = value;
     } else if (!strcmp(key, "mf_mid_log2")) {
         c->mf_mid_log2 = value;
     } else if (!strcmp(key, "stage_a")) {
@@ -863,7 +886,21 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     auto lane_of = [&](int j) -> mpsfr_ctx::Lane& { return c->lane[(L0 + j) % NLmax]; };
     for (int j = 0; j < NL; ++j) {
         mpsfr_ctx::Lane& ln = lane_of(j);
-        if (!ln.stream) HIPCHK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        if (!ln.stream) {
+            const int li = (int)(&ln - c->lane);
+            if (c->cu_partition && NLmax > 1) {
+                // CU-mask bit i is CU i / 8 of XCD i % 8 (the driver deals the bits round the XCDs), so a
+                // contiguous range of bits is the same share of every XCD: each lane keeps all eight L2s
+                const int lo = c->ncu * li / NLmax, hi = c->ncu * (li + 1) / NLmax;
+                uint32_t mask[16] = {0};
+                for (int b = lo; b < hi && b < 512; ++b) mask[b >> 5] |= 1u << (b & 31);
+                HIPCHK(hipExtStreamCreateWithCUMask(&ln.stream, (uint32_t)((c->ncu + 31) / 32), mask));
+                ln.ncu = hi - lo;
+            } else {
+                HIPCHK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+                ln.ncu = 0;
+            }
+        }
         if (!ln.done) HIPCHK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
     }
     hipStream_t s0 = lane_of(0).stream;        // the call's tables are produced on its first lane
@@ -1056,11 +1093,27 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     const float thr_sum = prune ? (float)((mf ? 0.5 : 1.0) * eps_prune / (2.0 * N * ndir)) : 0.f;
     float thr_blk = (prune && mf)
         ? (float)std::log2(0.5 * eps_prune / (2.0 * ndir * 16 * 32 * mf_block_count(N))) : 0.f;
-    // Representation floor of the split-fp16 operands: the OTF is generated times 2^15, so an element
-    // below 2^-29 of OTF[0][0] has both fp16 halves in the subnormal range -- a block whose bound is below
-    // 2^-29.01 carries at most a few bits per element, and is dropped.  (An approximation of the size of the
-    // pruning itself, not a bit-neutral one: the matrix cores do not flush subnormals; option "mf_floor".)
-    if (prune && mf && c->mf_floor && thr_blk < kMfFloorLog2) thr_blk = kMfFloorLog2;
+    // Precision tiers of the matrix-core stage.  The OTF is generated times 2^15, so an element
+    // below 2^-29 of OTF[0][0] has both fp16 halves in the subnormal range: a block whose bound is below
+    // 2^-29.01 carries a few bits per element and is dropped ("floor"); a block below 2^-18.01 runs without
+    // the low half ("mid").  Both are approximations (the matrix cores do not flush subnormals), held to a
+    // budget: per (task, wavelength) the OTF mass each tier leaves out -- an upper bound from the block bounds --
+    // stays below tier_eps / 2 of a lower bound of the PSF peak; K_MF_PREP lowers the thresholds where it
+    // would not.  The kernel for several directions (otf_mfma.hip) has no such pass: its floor is the
+    // threshold that keeps the mass below tier_eps / 2 of OTF[0][0] <= the peak whatever the input.
+    const float thr_eps = thr_blk;
+    float thr_floor = -1.0e30f;
+    const bool tiers = prune && mf && c->tier_eps > 0.0;
+    if (tiers && c->mf_floor) {
+        thr_floor = kMfFloorLog2;
+        if (!mf2) {
+            const float uni = (float)std::log2(0.5 * c->tier_eps / (2.0 * ndir * 16 * 32 * mf_block_count(N)));
+            if (thr_floor > uni) thr_floor = uni;
+        }
+        if (thr_blk < thr_floor) thr_blk = thr_floor;       // (what the kernel for several directions drops)
+    }
+    const float thr_mid = (tiers && c->mf_floor) ? (float)c->mf_mid_log2 : -1.0e30f;
+    const float tier_half = std::isfinite(c->tier_eps) ? (float)(0.5 * c->tier_eps) : 0.f;
     for (int j = 0; j < NL; ++j) {
         mpsfr_ctx::Lane& ln = lane_of(j);
         if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * (c->f64 ? 8 : 4)))) return rc;
@@ -1178,7 +1231,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             ProfScope ps(c, K_DPHI_SERIES, ls);
             launch_dphi_series(ls, N, ntd, ndir, d_tp + t0, ln.pT.p, (const double*)ln.psp.p, c->scoef.p,
                                c->stwk.p, scale2, ln.D0t.p, prune ? (float*)ln.dlin.p : nullptr, c->f64,
-                               mf2 ? (int*)ln.msched.p : nullptr, c->ncu);
+                               mf2 ? (int*)ln.msched.p : nullptr, ln.ncu ? ln.ncu : c->ncu);
         } else {
             {
                 ProfScope ps(c, K_PSD_ROWFFT, ls);
@@ -1210,7 +1263,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             const bool from_lines = prune && series && !io.psd_in;
             if (prune && !from_lines) launch_dmin(ls, N, ntd, ln.D0t.p, (float*)ln.dmin.p, (float*)ln.dblk.p);
             launch_mf_prep(ls, N, tc, nl, c->mf_permax, d_lp, (prune && !from_lines) ? (const float*)ln.dblk.p : nullptr,
-                           (const float*)c->tlb.p, thr_blk, (prune && c->mf_floor) ? (float)c->mf_mid_log2 : -1.0e30f,
+                           (const float*)c->tlb.p, thr_eps, thr_floor, thr_mid, tier_half, ln.D0t.p, (const float*)c->tl2.p,
                            ln.mown.p, ln.muni.p, ln.msched.p, from_lines ? (const float*)ln.dlin.p : nullptr);
         } else if (prune) {
             ProfScope ps(c, mf ? K_MF_PREP : K_VKEEP, ls);
@@ -1227,7 +1280,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             // (nothing)
         } else if (mf2) {
             ProfScope ps(c, K_OTF_MFMA, ls);
-            launch_otf_mfma2(ls, N, tc, nl, c->mf_permax, c->ncu, ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
+            launch_otf_mfma2(ls, N, tc, nl, c->mf_permax, ln.ncu ? ln.ncu : c->ncu, ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
                              c->gtab.p, ln.mown.p, ln.muni.p, ln.msched.p, ln.mpart.p, ln.pre.p,
                              c->mf_clock ? c->mfclk.p : nullptr);
         } else if (mf) {

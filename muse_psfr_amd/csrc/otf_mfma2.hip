@@ -87,7 +87,15 @@ struct MaskArgs {
     const float* dlin;       // instead of dminb: [ntask][N/2+1][nks] minima per LINE and block of 32 columns
                              // (K_DPHI_SERIES); the minimum over a block's 16 lines is taken here
     const float* tlb;        // [nmt][nks]
-    float thr, thr_mid;
+    float thr, thr_mid;      // thr: the eps rule (blocks below are dropped whatever the tiers do)
+    // Precision tiers under a budget: blocks with a bound in (thr, thr_floor] are dropped and
+    // blocks in (thr_floor, thr_mid] run without the low fp16 half of the OTF -- as far as the OTF mass each of
+    // the two leaves out stays below tier_half of a lower bound of the PSF peak, the OTF summed exactly over
+    // the first kPeakLines lines of the half plane (D0t, tl2).  Where it would not, the wave lowers the
+    // threshold for its (task, wavelength) until it does.  tier_half <= 0 or D0t == nullptr: no budget.
+    float thr_floor, tier_half;
+    const float* D0t;        // [ntask][N/2+1][N]
+    const float* tl2;        // [nmt 16][N] log2 of the telescope OTF
     u64* own;
     u64* uni;
     u64* ksum;
@@ -99,6 +107,14 @@ struct MaskArgs {
 };
 
 constexpr int kMaxNmt = 1280 / 2 / MTL + 1, kMaxNks = 1280 / KBL;      // 41, 40
+
+constexpr int kPeakLines = 4;      // lines of the half plane summed for the lower bound of the peak
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 
 // one workgroup per (wavelength group, task): wave = wavelength slot of the group, lane = k-step
 __global__ void __launch_bounds__(64 * 8) k_mf_prep(const MaskArgs a) {
@@ -130,12 +146,64 @@ __global__ void __launch_bounds__(64 * 8) k_mf_prep(const MaskArgs a) {
     const float c2 = lv ? (float)a.lp[l].c * 1.44269504088896340736f : 0.f;
     __syncthreads();
     const int kk = min(lane, nks - 1);
+    const bool nopr = a.dminb == nullptr && a.dlin == nullptr;
+    float thr_keep = fmaxf(a.thr, a.thr_floor), thr_mid = a.thr_mid;
+    if (!nopr && lv && a.tier_half > 0.f && a.D0t != nullptr && thr_mid > a.thr) {
+        // mass of the blocks with a bound in (lo, hi]: 2 half planes x 512 elements x the bound each
+        auto mass = [&](float lo, float hi) {
+            float m = 0.f;
+            for (int mt = 0; mt < nmt; ++mt) {
+                const float e = fmaf(c2, s_dm[mt * nks + kk], s_tb[mt * nks + kk]);
+                m += (lane < nks && e > lo && e <= hi) ? __builtin_amdgcn_exp2f(e) : 0.f;
+            }
+            return 1024.f * wave_sum_f(m);
+        };
+        // both tiers at their nominal thresholds in one pass (the usual case needs no other)
+        float mf = 0.f, mm = 0.f;
+        for (int mt = 0; mt < nmt; ++mt) {
+            const float e = fmaf(c2, s_dm[mt * nks + kk], s_tb[mt * nks + kk]);
+            const float x = (lane < nks && e > a.thr && e <= thr_mid) ? __builtin_amdgcn_exp2f(e) : 0.f;
+            mf += e <= thr_keep ? x : 0.f;
+            mm += e <= thr_keep ? 0.f : x;
+        }
+        mf = 1024.f * wave_sum_f(mf);
+        mm = 1024.f * wave_sum_f(mm);
+        if (mf > 0.f || mm > 0.f) {          // (wave-uniform)
+            // lower bound of the PSF peak = sum of the OTF: its first lines, exactly (every element is >= 0)
+            const int H1 = N / 2 + 1;
+            const float4* d4 = reinterpret_cast<const float4*>(a.D0t + (size_t)task * H1 * N);
+            const float4* t4 = reinterpret_cast<const float4*>(a.tl2);
+            float S = 0.f;
+            const int n4 = kPeakLines * N / 4;            // a multiple of 128
+            for (int i0 = lane; i0 < n4; i0 += 128) {     // four loads in flight
+                const float4 da = d4[i0], ta = t4[i0], db = d4[i0 + 64], tb = t4[i0 + 64];
+                const float xa = (__builtin_amdgcn_exp2f(fmaf(c2, fmaxf(da.x, 0.f), ta.x)) + __builtin_amdgcn_exp2f(fmaf(c2, fmaxf(da.y, 0.f), ta.y))) +
+                                 (__builtin_amdgcn_exp2f(fmaf(c2, fmaxf(da.z, 0.f), ta.z)) + __builtin_amdgcn_exp2f(fmaf(c2, fmaxf(da.w, 0.f), ta.w)));
+                const float xb = (__builtin_amdgcn_exp2f(fmaf(c2, fmaxf(db.x, 0.f), tb.x)) + __builtin_amdgcn_exp2f(fmaf(c2, fmaxf(db.y, 0.f), tb.y))) +
+                                 (__builtin_amdgcn_exp2f(fmaf(c2, fmaxf(db.z, 0.f), tb.z)) + __builtin_amdgcn_exp2f(fmaf(c2, fmaxf(db.w, 0.f), tb.w)));
+                // line 0 once, the others stand for both half planes
+                S += (i0 < N / 4 ? xa : 2.f * xa) + (i0 + 64 < N / 4 ? xb : 2.f * xb);
+            }
+            const float budget = a.tier_half * wave_sum_f(S);
+            if (mf > budget) {
+                do {
+                    thr_keep -= 2.f;
+                    if (thr_keep <= a.thr) { thr_keep = a.thr; break; }
+                } while (mass(a.thr, thr_keep) > budget);
+                mm = mass(thr_keep, thr_mid);
+            }
+            // a mid block loses the low half of every element: 2^-11 of it at most (round to nearest fp16)
+            while (thr_mid > thr_keep && mm * (1.f / 2048.f) > budget) {
+                thr_mid -= 2.f;
+                mm = mass(thr_keep, thr_mid);
+            }
+        }
+    }
     u64 myf = 0, mym = 0;                    // lane mt keeps the two words of m-tile mt
     for (int mt = 0; mt < nmt; ++mt) {
         const float e = fmaf(c2, s_dm[mt * nks + kk], s_tb[mt * nks + kk]);
-        const bool nopr = a.dminb == nullptr && a.dlin == nullptr;
-        const bool keep = lv && lane < nks && (nopr || e > a.thr);
-        const bool full = keep && (nopr || e > a.thr_mid);
+        const bool keep = lv && lane < nks && (nopr || e > thr_keep);
+        const bool full = keep && (nopr || e > thr_mid);
         const u64 bf = __ballot(full), bm = __ballot(keep && !full);
         if (lane == mt) { myf = bf; mym = bm; }
     }
@@ -720,10 +788,13 @@ SchedPtrs sched_ptrs(void* d_sched, int ntask, int nl) {
 // masks of every (task, wavelength) and the work lists (d_sched[0..16] must be zero: launch_colfft_dphi
 // does that).  d_dminb = nullptr: no pruning.
 void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const LamPar* d_lp,
-                    const float* d_dminb, const float* d_tlb, float thr, float thr_mid, void* d_own,
+                    const float* d_dminb, const float* d_tlb, float thr, float thr_floor, float thr_mid,
+                    float tier_half, const void* d_D0t, const float* d_tl2, void* d_own,
                     void* d_uni, void* d_sched, const float* d_dlin) {
     MaskArgs a;
     a.dlin = d_dlin;
+    a.thr_floor = thr_floor; a.tier_half = tier_half;
+    a.D0t = (const float*)d_D0t; a.tl2 = d_tl2;
     a.N = N; a.nl = nl;
     mf2_groups(nl, permax, &a.per, &a.ngr);
     a.lp = d_lp; a.dminb = d_dminb; a.tlb = d_tlb;

@@ -783,40 +783,91 @@ def test_series_form_of_stage_a_against_the_full_size_transforms(api, dim, npl, 
                       beta=float(np.abs(rb['fit'][:, :, 4] - ra['fit'][:, :, 4])[well].max(initial=0)))
 
 
-def test_precision_tiers_of_the_matrix_core_stage(api):
-    """The matrix-core stage skips blocks below 2^-29 of OTF[0][0] ("mf_floor") and runs blocks below
-    2^-18 without the low half of the OTF ("mf_mid_log2"), where the fp16 halves it leaves out are
-    subnormal (otf_mfma2.hip).  Round 3 documented that as bit-neutral ("the
-    matrix cores flush fp16 subnormals"); this test showed it is not -- the gfx950 matrix cores keep
-    subnormal fp16 inputs -- so the tiers are approximations like the pruning, and what is asserted is
-    their size: no stamp pixel moves by more than 3e-7 of its stamp's peak (the bound the block pruning
-    is held to), the fits far inside the parity tolerance."""
-    see, gl, l0 = api.synthetic_rows(10)
-    see[0], gl[0], l0[0] = 0.4, 0.95, 29.0
-    see[1], gl[1], l0[1] = 1.6, 0.30, 9.0
-    lb = np.linspace(465, 930, 9)
-    ps = api.grid_pixscale(512)
+TIER_EPS, PRUNE_EPS = 4.0e-6, 1.0e-9        # the library's defaults (include/mpsfr.h)
+
+
+def _tier_runs(api, dim, ps, lb, see, gl, l0, variants):
     out = {}
-    for key, opts in (('default', {}), ('no_floor', {'mf_floor': 0}), ('no_mid', {'mf_mid_log2': -1e30})):
-        ctx = api.Context(dim=512, pixscale=ps, precision='mixed')
+    for key, opts in variants:
+        ctx = api.Context(dim=dim, pixscale=ps, precision='mixed')
         for k, v in opts.items():
             ctx.set_option(k, v)
         out[key] = ctx.reconstruct(lb, see, gl, l0, None, H)
+        out[key + '_pre'] = ctx.debug_fetch('pre', (len(see), len(lb), 40, 40))
         out[key + '_work'] = ctx.debug_fetch('mf_work', (5,))
         ctx.close()
-    # the tiers are in use on this workload (else the test says nothing)
-    assert out['default_work'][4] > 0 and out['no_mid_work'][4] == 0
-    assert out['no_floor_work'][0] > out['default_work'][0]
-    a = out['default']
-    peak = a['psf'].max(axis=(2, 3), keepdims=True)
-    well = a['fit'][:, :, 4] < 10
-    for key in ('no_mid', 'no_floor'):
-        b = out[key]
-        dst = float((np.abs(b['psf'] - a['psf']) / peak).max())
-        dfw = float(np.abs(b['fit'][:, :, 5] - a['fit'][:, :, 5])[well].max(initial=0) * ps)
-        dbe = float(np.abs(b['fit'][:, :, 4] - a['fit'][:, :, 4])[well].max(initial=0))
-        record_margin('precision_tiers_' + key, stamp=dst, fwhm_arcsec=dfw, beta=dbe)
-        assert dst < 3e-7 and dfw < 2e-6 and dbe < 2e-5, (key, dst, dfw, dbe)
+    return out
+
+
+def _tier_bound(pre, eps):
+    """What include/mpsfr.h promises for a stamp before the convolutions: every pixel within eps of the stamp's
+    peak, plus the stamp's normalisation to unit sum (psfrec.py:685) in the worst case that all 1600 pixels moved
+    the same way: eps (1 + 1600 peak / sum), per stamp."""
+    peak = pre.max(axis=(2, 3))
+    return eps * (1 + 1600 * peak / pre.sum(axis=(2, 3)))
+
+
+@pytest.mark.parametrize('case', ['bench512', 'sharp1280', 'plateau512'])
+def test_precision_tiers_of_the_matrix_core_stage(api, case):
+    """The matrix-core stage drops blocks below 2^-29 of OTF[0][0] ("mf_floor") and runs blocks below 2^-18
+    without the low half of the OTF ("mf_mid_log2"), where the fp16 halves left out are subnormal (otf_mfma2.hip,
+    DESIGN.md 2.9).  These are approximations (gfx950's matrix cores keep subnormal fp16 inputs), held to a budget
+    per (task, wavelength): the OTF mass a tier leaves out is below tier_eps / 2 of a lower bound of the PSF peak,
+    and K_MF_PREP lowers the thresholds where it would not be ("tier_eps", default 4e-6).  Asserted here: (1) the
+    documented bound, per stamp, of the default path against the path without tiers -- on the bench rows, on the
+    sharpest PSF the SPARTA filter admits at the native 1280^2 grid (seeing 0.3", GL 0.98, 930 nm: VERDICT r4 #3),
+    and on rows whose OTF has its coherent plateau just below the floor; (2) the size the approximations really
+    have on these workloads (3e-7 of the peak, fits far inside the parity tolerance); (3) that the budget acts:
+    a small tier_eps executes more blocks and lands closer to the path without tiers."""
+    if case == 'bench512':
+        dim, ps = 512, api.grid_pixscale(512)
+        see, gl, l0 = api.synthetic_rows(10)
+        see[0], gl[0], l0[0] = 0.4, 0.95, 29.0
+        see[1], gl[1], l0[1] = 1.6, 0.30, 9.0
+        lb = np.linspace(465, 930, 9)
+    elif case == 'sharp1280':
+        dim, ps = 1280, 0.2
+        see = np.array([0.3, 0.3, 0.35, 0.5])
+        gl = np.array([0.98, 0.98, 0.9, 0.98])
+        l0 = np.array([29.9, 8.1, 20.0, 15.0])
+        lb = np.array([490.0, 600.0, 700.0, 800.0, 930.0])
+    else:
+        dim, ps = 512, api.grid_pixscale(512)
+        see = np.array([0.6, 0.5, 0.3, 0.9, 0.4])
+        gl = np.array([0.5, 0.9, 0.5, 0.9, 0.95])
+        l0 = np.array([15.0, 20.0, 29.0, 11.0, 29.0])
+        lb = np.linspace(465, 930, 7)
+    out = _tier_runs(api, dim, ps, lb, see, gl, l0,
+                     (('default', {}), ('no_tiers', {'tier_eps': 0}), ('no_floor', {'mf_floor': 0}),
+                      ('no_mid', {'mf_mid_log2': -1e30}), ('tight', {'tier_eps': 1e-8}),
+                      ('no_budget', {'tier_eps': float('inf')})))
+    a, ref = out['default'], out['no_tiers']
+    # (3) the switches do what they say
+    assert out['no_tiers_work'][4] == 0 and out['no_mid_work'][4] == 0
+    assert out['no_tiers_work'][0] >= out['tight_work'][0] >= out['default_work'][0] >= out['no_budget_work'][0]
+    if case != 'sharp1280':
+        assert out['default_work'][4] > 0 and out['no_floor_work'][0] > out['default_work'][0]
+    # (1) the documented bound of the default path, per stamp, before the convolutions ...
+    peak = out['no_tiers_pre'].max(axis=(2, 3))
+    err = np.abs(out['default_pre'] - out['no_tiers_pre']).max(axis=(2, 3)) / peak
+    bound = _tier_bound(out['no_tiers_pre'], TIER_EPS)
+    assert np.all(err <= bound + 2e-7), (case, float((err / bound).max()))      # (+ the fp32 rounding of two runs)
+    errt = np.abs(out['tight_pre'] - out['no_tiers_pre']).max(axis=(2, 3)) / peak
+    assert np.all(errt <= _tier_bound(out['no_tiers_pre'], 1e-8) + 2e-7), (case, float(errt.max()))
+    # ... and after them (non-negative kernels of unit sum: contractions in the maximum norm)
+    fpeak = ref['psf'].max(axis=(2, 3))
+    ferr = np.abs(a['psf'] - ref['psf']).max(axis=(2, 3)) / fpeak
+    assert np.all(ferr <= bound * peak / fpeak * 1.0 + 4e-7), (case, float(ferr.max()))
+    # (2) their real size
+    well = ref['fit'][:, :, 4] < 10
+    dst = float(ferr.max())
+    dfw = float(np.abs(a['fit'][:, :, 5] - ref['fit'][:, :, 5])[well].max(initial=0) * ps)
+    dbe = float(np.abs(a['fit'][:, :, 4] - ref['fit'][:, :, 4])[well].max(initial=0))
+    record_margin('precision_tiers_' + case, stamp=dst, stamp_pre=float(err.max()), fwhm_arcsec=dfw, beta=dbe,
+                  bound_used_fraction=float((err / bound).max()),
+                  blocks_default=out['default_work'][0], blocks_no_tiers=out['no_tiers_work'][0],
+                  blocks_no_budget=out['no_budget_work'][0])
+    assert dst < 3e-7 and dfw < 2e-6 and dbe < 2e-5, (case, dst, dfw, dbe)
 
 
 @pytest.mark.parametrize('dim,npl', [(512, 1), (128, 1), (256, 2), (256, 5), (512, 3), (1280, 1)])
