@@ -186,6 +186,48 @@ def rehearse(a, rank, world, bounds, total_rows, strong):
     return 0 if ok else 1
 
 
+def e2e_sparta_leg(ncalls):
+    """compute_psf_from_sparta (psfrec.py:981-1120) end to end on synthetic SPARTA tables held in memory: 1000 rows
+    x 35 wavelengths on the 512^2 grid (configs[2] on one GPU) and 100 rows on the reference's own 1280^2 grid.
+    A call = HDUList in -> HDUList out (row filter, tasks, the GPU batch, FIT_ROWS / FIT_MEAN / PSF_MEAN).
+    Median of `ncalls` calls after three warm ones; `value` is the 512^2 figure."""
+    import muse_psfr_amd as M
+    from muse_psfr_amd import _minifits as mf
+    from muse_psfr_amd.psfrec import _astropy
+    fits, _ = _astropy()
+
+    def run(nrows, dim_, ncall):
+        see_, gl_, l0_ = M.synthetic_rows(nrows)
+        tbl = M.create_sparta_table(nlines=nrows)
+        for k in range(1, 5):
+            tbl.data['LGS%d_SEEING' % k][:] = see_
+            tbl.data['LGS%d_TUR_GND' % k][:] = gl_
+            tbl.data['LGS%d_L0' % k][:] = l0_
+        mk = (lambda: fits.HDUList([fits.PrimaryHDU(), tbl])) if fits is not None else \
+             (lambda: mf.HDUList([mf.PrimaryHDU(), tbl]))
+        kw = dict(verbose=False, cutoff_masks='exact')
+        if dim_ != 1280:
+            kw.update(dim=dim_, pixscale=M.grid_pixscale(dim_), lmin=465, lmax=930)
+        for _ in range(3):
+            res = M.compute_psf_from_sparta(mk(), **kw)
+        ts = []
+        for _ in range(ncall):
+            t0 = time.perf_counter()
+            res = M.compute_psf_from_sparta(mk(), **kw)
+            ts.append(time.perf_counter() - t0)
+        med = float(np.median(ts))
+        assert len(res['FIT_ROWS'].data) == nrows * 35
+        return {'rows': nrows, 'dim': dim_, 'nl': 35, 'calls': ncall, 'ms_per_call_median': round(med * 1e3, 4),
+                'ms_per_call_min': round(min(ts) * 1e3, 4), 'value': round(nrows * 35 / med, 1)}
+    a512 = run(1000, 512, ncalls)
+    a1280 = run(100, 1280, ncalls)
+    return {'value': a512['value'], 'unit': 'PSFs/sec', 'table_1000_rows_512': a512, 'table_100_rows_native1280': a1280,
+            'astropy': fits is not None,
+            'what': 'compute_psf_from_sparta(HDUList) -> HDUList with FIT_ROWS, FIT_MEAN, PSF_MEAN (psfrec.py:981-1120): '
+                    'host logic, asynchronous host-output parts, table assembly and the FIT_MEAN refit included; '
+                    'median wall time per call'}
+
+
 def series_flops_per_line(dim):
     """Algorithmic fp64 flops of one line (td, y) of K_DPHI_SERIES: the fold of the 80
     complex inputs with the lanes' twiddles (80 complex multiply-adds x L lanes) and the Q-point in-lane
@@ -233,6 +275,8 @@ def main():
     ap.add_argument('--host-steps', type=int, default=-1,
                     help='steps of the host-output leg (synchronous call, fit table + stamp sum copied to the '
                          'host; -1: 50, 0: skip)')
+    ap.add_argument('--e2e-steps', type=int, default=-1,
+                    help='calls of the end-to-end leg through compute_psf_from_sparta (-1: 20, 0: skip)')
     ap.add_argument('--native-steps', type=int, default=-1,
                     help='steps of the native-grid leg (1280^2, pixscale 0.2, 490-930 nm: what the reference\'s '
                          'compute_psf runs; -1: 60 at the default workload, 0: skip)')
@@ -344,7 +388,7 @@ def main():
                 c.set_option('prune_eps', prune_eps)
             if os.environ.get('MPSFR_OTF_MFMA') and precision == 'mixed':     # experiments: 0 = FFT path
                 c.set_option('otf_mfma', int(os.environ['MPSFR_OTF_MFMA']))
-            for key in ('mf_floor', 'mf_kernel', 'mf_permax', 'mf_mid_log2', 'cold_stagger', 'stage_a', 'cu_partition'):      # experiments
+            for key in ('mf_floor', 'mf_kernel', 'mf_permax', 'mf_mid_log2', 'mf_floor_log2', 'tier_eps', 'cold_stagger', 'stage_a', 'cu_partition'):      # experiments
                 if os.environ.get('MPSFR_' + key.upper()) and (precision == 'mixed' or key == 'stage_a'):
                     c.set_option(key, float(os.environ['MPSFR_' + key.upper()]))
             if os.environ.get('MPSFR_PRUNE_FIXED') and precision == 'mixed':
@@ -444,11 +488,54 @@ def main():
 
         def rank_times():
             return state.get('rank_dt')
+
+        def exchange_times(nsteps):
+            """ms per step of the two collectives alone (all-gather of the fit tables + reduce of the stamp
+            sums), measured in an UNTIMED pass: HIP events on torch's stream around the exchange of every
+            step (gloo rehearsal: host clock), the steps otherwise as in the timed region.  Every rank's
+            mean travels to rank 0.  None without an exchange."""
+            if not xchg:
+                return None
+            fence()
+            evs, host_s = [], 0.0
+            for _ in range(nsteps):
+                k = state['i'] % nctx
+                b = state['i'] % nset
+                state['i'] += 1
+                fit_b, psum_b = fits[b], psums[b]
+                if state['ev'][b] is not None:
+                    ctxs[k].wait_event(state['ev'][b].cuda_event)
+                ctxs[k].reconstruct_device(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin,
+                                           None, None, psum_b.data_ptr(), fit_b.data_ptr())
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(lib_streams[k])
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                th = time.perf_counter()
+                if packed:
+                    exch[b].exchange_packed()
+                elif backend == 'nccl':
+                    exch[b].gather(fit_b)
+                    exch[b].reduce(psum_b, dst=0)
+                else:
+                    exch[b].gather(fit_b.cpu())
+                    exch[b].reduce(psum_b.cpu(), dst=0)
+                host_s += time.perf_counter() - th
+                e1.record(cur)
+                evs.append((e0, e1))
+                state['ev'][b] = e1
+            fence()
+            ms = (sum(a_.elapsed_time(b_) for a_, b_ in evs) if backend == 'nccl' else host_s * 1e3) / max(1, nsteps)
+            tt = torch.tensor([ms], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+            allt = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(allt, tt)
+            return [float(t.item()) for t in allt]
+
         def host_lib():
             tot = [c.host_time() for c in ctxs]
             return sum(t[0] for t in tot) / max(1, sum(t[1] for t in tot))
         return dict(ctxs=ctxs, step=step, fence=fence, timed=timed, profile_sum=profile_sum,
-                    fits=fits, close=close, host_lib=host_lib, rank_times=rank_times)
+                    fits=fits, close=close, host_lib=host_lib, rank_times=rank_times, exchange_times=exchange_times)
 
     def parity_block(fitg, n):
         return {'rows_checked': n,
@@ -587,6 +674,8 @@ def main():
         prof_all = R['profile_sum']()
     for c in ctxs:
         c.set_option('profile', 0)
+    # N > 1: what the two collectives of a step cost on their own (untimed pass, events around them)
+    exch_ms = R['exchange_times'](min(a.steps, 40))
     fitg = R['fits'][0].cpu().numpy()
     # line pruning: lines of the OTF half plane transformed per (row, wavelength pair) in the last
     # call (every call of the loop has the same inputs)
@@ -681,6 +770,13 @@ def main():
                                   'max_abs_err_fwhm_arcsec': float(np.abs(rh['fit'][:n, :, 5] * ps - cpu_fits[:, :, 3]).max()),
                                   'max_abs_err_beta': float(np.abs(rh['fit'][:n, :, 4] - cpu_fits[:, :, 4]).max()),
                                   'tolerance': 1e-4}
+
+    # ---- the drop-in API end to end (psfrec.py:981-1120): FITS table in memory -> compute_psf_from_sparta -> HDUList
+    # (FIT_ROWS, FIT_MEAN, PSF_MEAN), host logic, PCIe and table assembly included -- never `value`
+    e2e = None
+    ne2e = (20 if a.e2e_steps < 0 else a.e2e_steps) if (world == 1 and a.precision == 'mixed' and dim == 512 and a.npsflin == 1) else 0
+    if ne2e > 0:
+        e2e = e2e_sparta_leg(ne2e)
 
     # ---- the reference's own grid (compute_psf hard-codes dim = 1280, pixscale 0.2: psfrec.py:954-955, 659)
     native = None
@@ -965,6 +1061,18 @@ def main():
         }
         if rank_dt:
             out['rank_ms_per_step'] = rank_times_block(rank_dt, a.steps)
+        if exch_ms:
+            out['exchange_ms_per_step'] = round(max(exch_ms), 4)
+            out['exchange'] = {'ms_per_step_by_rank': [round(v, 4) for v in exch_ms],
+                               'share_of_step': round(max(exch_ms) / (dt / a.steps * 1e3), 4),
+                               'collectives': 'all-gather of the fit tables [rows][nl][16] f64 + sum-reduce of the stamp '
+                                              'sums [nl][40][40] f64 to rank 0 (SURVEY.md 8(e))',
+                               'how': 'separate untimed pass of %d steps, HIP events on the stream of the collectives '
+                                      'around the two calls of every step (they overlap the next call of the library in the '
+                                      'timed region: this is their cost, not their share of the critical path)' % min(a.steps, 40)}
+        if e2e is not None:
+            out['value_e2e_sparta'] = e2e['value']
+            out['e2e_sparta'] = e2e
         if len(rep_dt) > 1:
             vals = [npsf / d for d in rep_dt]
             out['timed_region_repeats'] = {'count': len(rep_dt), 'seconds_each': round(dt, 4),

@@ -175,6 +175,21 @@ int mpsfr_reconstruct_multi(mpsfr_ctx* const* ctxs, int nctx, int ntask, const d
                             const uint8_t* mask_res, double* psf_out, double* psf_sum_out,
                             double* fit_out);
 
+/* The same without waiting for the GPUs: every context takes its shard as an asynchronous host-output call
+ * (on_device = 2 of mpsfr_reconstruct: no host thread, the call returns once the shards are queued), and
+ * mpsfr_wait_multi(ctxs, nctx) -- same contexts, same order -- blocks until all of them have finished, hands
+ * the per-row outputs to the caller's arrays and adds the shards' stamp sums in context order into the
+ * psf_sum_out of the call.  One such call may be pending per ctxs[0]; the output arrays must stay allocated
+ * until mpsfr_wait_multi returns (or mpsfr_abandon on every context gives them up).  Several tables -- or the
+ * parts of one -- can so be kept in flight on several devices, like on_device = 2 does on one. */
+int mpsfr_reconstruct_multi_async(mpsfr_ctx* const* ctxs, int nctx, int ntask, const double* seeing,
+                            const double* gl, const double* l0, const uint8_t* three_lgs,
+                            const double h[2], double wind_speed, int npsflin, int nl,
+                            const double* lbda_nm, const uint8_t* mask_rec,
+                            const uint8_t* mask_res, double* psf_out, double* psf_sum_out,
+                            double* fit_out);
+int mpsfr_wait_multi(mpsfr_ctx* const* ctxs, int nctx);
+
 /* Replacement of fit_psf_cube (psfrec.py:861-871) on caller-provided stamps, e.g. the mean PSF
  * (psfrec.py:1105).  stamps: [nstamp][dimpsf][dimpsf] float64; fit_out: [nstamp][MPSFR_NFIT]. */
 int mpsfr_fit_stamps(mpsfr_ctx* ctx, int nstamp, const double* stamps, double* fit_out,
@@ -199,6 +214,14 @@ int mpsfr_psf_from_psd(mpsfr_ctx* ctx, int ndir, const double* psd, int nl, cons
                        double* psf_out);
 int mpsfr_convolve_stamps(mpsfr_ctx* ctx, int ntask, const double* seeing, const double* gl, const double* l0,
                           int nl, const double* lbda_nm, const double* psf_in, double* psf_out);
+
+/* FIT_ROWS assembly on the host (pure C, no GPU): the columns fit_psf_cube keeps from the fit object
+ * (psfrec.py:866-870) -- center[2], flux, fwhm[2] (arcsec), n, peak, err_center[2], err_flux, err_fwhm[2] (arcsec),
+ * err_n, err_peak: 14 doubles -- of `n` fit rows ([n][MPSFR_NFIT], as mpsfr_reconstruct writes them) into
+ * out[r * stride + 0..13].  `stride` (in doubles, >= 14) lets the caller write straight into the records of a
+ * table that carries further columns (compute_psf_from_sparta's FIT_ROWS: lbda in front, SEEING, GL, L0, row_idx,
+ * lgs_idx behind, psfrec.py:1086-1101).  err_flux: the relative errors of peak, alpha^2 and (n - 1) in quadrature. */
+int mpsfr_fit_rows(const double* fit, long n, double pixscale, double* out, long stride);
 
 /* Block until every call made so far has finished (and hand over the results of every
  * asynchronous host-output call). */

@@ -67,6 +67,10 @@ def load():
     lib.mpsfr_reconstruct_multi.argtypes = [C.POINTER(p), C.c_int, C.c_int, dp, dp, dp, u8p, dp, C.c_double,
                                             C.c_int, C.c_int, dp, u8p, u8p, p, p, p]
     lib.mpsfr_reconstruct_multi.restype = C.c_int
+    lib.mpsfr_reconstruct_multi_async.argtypes = lib.mpsfr_reconstruct_multi.argtypes
+    lib.mpsfr_reconstruct_multi_async.restype = C.c_int
+    lib.mpsfr_wait_multi.argtypes = [C.POINTER(p), C.c_int]
+    lib.mpsfr_wait_multi.restype = C.c_int
     lib.mpsfr_fit_stamps.argtypes = [p, C.c_int, p, p, C.c_int]
     lib.mpsfr_fit_stamps.restype = C.c_int
     lib.mpsfr_simul_psd.argtypes = [p, C.c_double, C.c_double, C.c_double, C.c_int, dp, C.c_double, C.c_int, u8p, u8p, dp]
@@ -75,6 +79,8 @@ def load():
     lib.mpsfr_psf_from_psd.restype = C.c_int
     lib.mpsfr_convolve_stamps.argtypes = [p, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp]
     lib.mpsfr_convolve_stamps.restype = C.c_int
+    lib.mpsfr_fit_rows.argtypes = [dp, C.c_long, C.c_double, dp, C.c_long]
+    lib.mpsfr_fit_rows.restype = C.c_int
     lib.mpsfr_sync.argtypes = [p]
     lib.mpsfr_sync.restype = C.c_int
     lib.mpsfr_last_ticket.argtypes = [p]
@@ -110,12 +116,21 @@ def load():
 
 
 EXPORTS = ['mpsfr_create', 'mpsfr_destroy', 'mpsfr_last_error', 'mpsfr_set_option',
-           'mpsfr_reconstruct', 'mpsfr_reconstruct_multi', 'mpsfr_fit_stamps', 'mpsfr_simul_psd', 'mpsfr_psf_from_psd',
-           'mpsfr_convolve_stamps', 'mpsfr_sync', 'mpsfr_last_ticket', 'mpsfr_wait', 'mpsfr_abandon',
+           'mpsfr_reconstruct', 'mpsfr_reconstruct_multi', 'mpsfr_reconstruct_multi_async', 'mpsfr_wait_multi', 'mpsfr_fit_stamps', 'mpsfr_simul_psd', 'mpsfr_psf_from_psd',
+           'mpsfr_convolve_stamps', 'mpsfr_fit_rows', 'mpsfr_sync', 'mpsfr_last_ticket', 'mpsfr_wait', 'mpsfr_abandon',
            'mpsfr_stream', 'mpsfr_wait_event',
            'mpsfr_host_time', 'mpsfr_debug_fetch',
            'mpsfr_profile_count', 'mpsfr_profile_name', 'mpsfr_profile_get',
            'mpsfr_profile_reset', 'mpsfr_version', 'mpsfr_build_id', 'mpsfr_device_count']
+
+
+def fit_rows(fit, pixscale, out):
+    """mpsfr_fit_rows: the 14 fit columns of FIT_ROWS from library fit rows `fit` (n, NFIT) into `out`, a C-contiguous
+    float64 (n, stride >= 14) block whose first 14 columns receive them."""
+    f = np.ascontiguousarray(fit, dtype=np.float64).reshape(-1, NFIT)
+    assert out.dtype == np.float64 and out.ndim == 2 and out.shape[0] == f.shape[0] and out.strides[1] == 8
+    _check(load().mpsfr_fit_rows(_dptr(f), f.shape[0], float(pixscale), out.ctypes.data_as(C.POINTER(C.c_double)),
+                                 out.strides[0] // 8))
 
 
 def device_count():
@@ -177,11 +192,11 @@ class Context:
         try:
             _check(self.lib.mpsfr_abandon(self._h))
         finally:
-            self._abandoned.update(self._pending)
+            self._abandoned.update(t for t in self._pending if not isinstance(t, tuple))
             self._pending.clear()
 
     def _handed_over(self, upto):
-        for t in [t for t in self._pending if t <= upto]:
+        for t in [t for t in self._pending if (t[1] if isinstance(t, tuple) else t) <= upto]:
             del self._pending[t]
 
     def wait_event(self, hip_event):
@@ -243,8 +258,15 @@ class Context:
         return dict(psf=psf, psf_sum=psum, fit=fit)
 
     @staticmethod
+    def reconstruct_multi_async(ctxs, *args, **kwargs):
+        """`reconstruct_multi` without waiting for the GPUs (mpsfr_reconstruct_multi_async): every context takes its
+        shard as an asynchronous host-output call; returns a PendingMulti whose .wait() (mpsfr_wait_multi) returns the
+        same dict.  One such call may be pending per ctxs[0]."""
+        return Context.reconstruct_multi(ctxs, *args, _async=True, **kwargs)
+
+    @staticmethod
     def reconstruct_multi(ctxs, lbda, seeing, gl, l0, three_lgs=None, h=(100, 10000), wind_speed=None,
-                          npsflin=1, masks=None, want_psf=True, want_sum=True, want_fit=True):
+                          npsflin=1, masks=None, want_psf=True, want_sum=True, want_fit=True, _async=False):
         """`reconstruct` with the rows in contiguous shards over several contexts (one per device,
         one host thread each inside the library: mpsfr_reconstruct_multi) -- the reference's joblib
         fan-out (psfrec.py:1082-1083).  Same outputs as the single-context call."""
@@ -272,11 +294,26 @@ class Context:
         fit = np.empty((nt, nl, NFIT)) if want_fit else None
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
         handles = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
-        _check(ctxs[0].lib.mpsfr_reconstruct_multi(
-            handles, len(ctxs), nt, _dptr(seeing), _dptr(gl), _dptr(l0), _u8ptr(three), _dptr(hh),
-            float(wind_speed), int(npsflin), nl, _dptr(lbda), _u8ptr(mrec), _u8ptr(mres),
-            vp(psf), vp(psum), vp(fit)))
-        return dict(psf=psf, psf_sum=psum, fit=fit)
+        fn = ctxs[0].lib.mpsfr_reconstruct_multi_async if _async else ctxs[0].lib.mpsfr_reconstruct_multi
+        arrays = dict(psf=psf, psf_sum=psum, fit=fit)
+        try:
+            _check(fn(handles, len(ctxs), nt, _dptr(seeing), _dptr(gl), _dptr(l0), _u8ptr(three), _dptr(hh),
+                      float(wind_speed), int(npsflin), nl, _dptr(lbda), _u8ptr(mrec), _u8ptr(mres),
+                      vp(psf), vp(psum), vp(fit)))
+        except MpsfrError:
+            if _async:                      # (the library has abandoned the shards it had queued)
+                for c in ctxs:
+                    c._pending.clear()
+            raise
+        if _async:
+            # the library holds pointers into `arrays` until mpsfr_wait_multi: every context keeps them alive
+            # under the ticket of its shard
+            for c in ctxs:
+                t = int(c.lib.mpsfr_last_ticket(c._h))
+                if t >= 0:
+                    c._pending[('multi', t)] = arrays
+            return PendingMulti(ctxs, handles, arrays)
+        return arrays
 
     def reconstruct_device(self, lbda, seeing, gl, l0, three_lgs, h, wind_speed, npsflin, masks,
                            psf_ptr, sum_ptr, fit_ptr):
@@ -384,6 +421,24 @@ class PendingResult:
                 self.ctx._handed_over(self.ticket)
             elif self.ticket in self.ctx._abandoned:
                 raise MpsfrError(-1, 'ticket %d was abandoned (Context.abandon): its results were dropped' % self.ticket)
+            self._done = True
+        return self._arrays
+
+
+class PendingMulti:
+    """An asynchronous multi-context call (Context.reconstruct_multi_async)."""
+
+    def __init__(self, ctxs, handles, arrays):
+        self.ctxs, self._handles, self._arrays, self._done = list(ctxs), handles, arrays, False
+
+    def wait(self):
+        if not self._done:
+            try:
+                _check(self.ctxs[0].lib.mpsfr_wait_multi(self._handles, len(self.ctxs)))
+            finally:
+                for c in self.ctxs:
+                    for t in [t for t in c._pending if isinstance(t, tuple) and c._pending[t] is self._arrays]:
+                        del c._pending[t]
             self._done = True
         return self._arrays
 

@@ -80,6 +80,7 @@ struct mpsfr_ctx {
     int mf_kernel = 2;           // 2: thin-wave kernel with precision tiers (otf_mfma2.hip, one direction); 1: otf_mfma.hip
     int mf_permax = 6;           // wavelengths per workgroup of the thin-wave kernel (6: 12 waves, 7: 14 waves)
     double mf_mid_log2 = -18.01; // blocks below 2^this need no low half of the OTF (see otf_mfma2.hip)
+    double mf_floor_log2 = kMfFloorLog2;   // blocks below 2^this are dropped
     double tier_eps = 4.0e-6;    // budget of the two precision tiers, of the PSF peak (0: no tiers; inf: no budget)
     bool mf_clock = false;       // experiments: phase time stamps of the matrix-core kernel
     int stage_a = 1;             // stage A: 1 = automatic (the series + patch form of stage_a2.hip from 512^2 on, and at
@@ -159,6 +160,15 @@ struct mpsfr_ctx {
     };
     static constexpr int NTICKET = 4;
     Ticket ticket[NTICKET];
+    // mpsfr_reconstruct_multi_async (held by ctxs[0]): the shards' stamp sums until mpsfr_wait_multi adds them
+    struct Multi {
+        bool pending = false;
+        int nctx = 0;
+        size_t n = 0;                    // nl * 1600
+        std::vector<double> sums;        // [nctx][n]
+        std::vector<long> tickets;       // per context (-1: no shard)
+        double* user_sum = nullptr;
+    } multi;
     long ticket_next = 0;                // id of the next asynchronous host-output call
     double host_seconds = 0.0;           // wall time spent inside mpsfr_reconstruct
     long host_calls = 0;
@@ -590,6 +600,8 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
     } else if (!strcmp(key, "tier_eps")) {
         if (!(value >= 0.0)) return fail(MPSFR_E_INVALID, "tier_eps must be >= 0 (inf: tiers without a budget)");
         c->tier_eps = value;
+    } else if (!strcmp(key, "mf_floor_log2")) {
+        c->mf_floor_log2 = value;
     } else if (!strcmp(key, "mf_mid_log2")) {
         c->mf_mid_log2 = value;
     } else if (!strcmp(key, "stage_a")) {
@@ -647,6 +659,8 @@ int mpsfr_abandon(mpsfr_ctx* c) {
         tk.pending = false;
         tk.u_psf = tk.u_sum = tk.u_fit = nullptr;
     }
+    c->multi.pending = false;
+    c->multi.user_sum = nullptr;
     if (rc != MPSFR_OK) return fail(rc, "a stream failed while the pending calls were drained");
     return MPSFR_OK;
 }
@@ -1105,7 +1119,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     float thr_floor = -1.0e30f;
     const bool tiers = prune && mf && c->tier_eps > 0.0;
     if (tiers && c->mf_floor) {
-        thr_floor = kMfFloorLog2;
+        thr_floor = (float)c->mf_floor_log2;
         if (!mf2) {
             const float uni = (float)std::log2(0.5 * c->tier_eps / (2.0 * ndir * 16 * 32 * mf_block_count(N)));
             if (thr_floor > uni) thr_floor = uni;
@@ -1452,6 +1466,97 @@ int mpsfr_reconstruct_multi(mpsfr_ctx* const* ctxs, int nctx, int ntask, const d
             for (int k = 1; k < nctx; ++k) t += sums[k][e];
             psf_sum_out[e] = t;
         }
+    return MPSFR_OK;
+}
+
+int mpsfr_reconstruct_multi_async(mpsfr_ctx* const* ctxs, int nctx, int ntask, const double* seeing,
+                                  const double* gl, const double* l0, const uint8_t* three_lgs,
+                                  const double h[2], double wind_speed, int npsflin, int nl,
+                                  const double* lbda_nm, const uint8_t* mask_rec, const uint8_t* mask_res,
+                                  double* psf_out, double* psf_sum_out, double* fit_out) {
+    if (!ctxs || nctx < 1) return fail(MPSFR_E_INVALID, "need at least one context");
+    for (int k = 0; k < nctx; ++k)
+        if (!ctxs[k]) return fail(MPSFR_E_INVALID, "context %d is NULL", k);
+    if (ntask < 1 || nl < 1) return fail(MPSFR_E_INVALID, "ntask and nl must be positive");
+    mpsfr_ctx::Multi& m = ctxs[0]->multi;
+    if (m.pending) return fail(MPSFR_E_INVALID, "a multi-context call is pending on this context: mpsfr_wait_multi first");
+    for (int k = 1; k < nctx; ++k)
+        if (ctxs[k]->dimpsf != ctxs[0]->dimpsf || ctxs[k]->N != ctxs[0]->N || ctxs[k]->prec != ctxs[0]->prec ||
+            ctxs[k]->pixscale != ctxs[0]->pixscale)
+            return fail(MPSFR_E_INVALID, "the contexts must share dim, dimpsf, pixscale and precision "
+                                         "(context %d differs from context 0)", k);
+    const size_t per_stamp = (size_t)ctxs[0]->dimpsf * ctxs[0]->dimpsf;
+    const int used = ntask < nctx ? 1 : nctx;            // (like the blocking form: too few rows go to context 0)
+    std::vector<int> start(nctx + 1, 0);
+    for (int k = 0; k < nctx; ++k)
+        start[k + 1] = used == 1 ? ntask : start[k] + ntask / nctx + (k < ntask % nctx ? 1 : 0);
+    m.nctx = nctx;
+    m.n = (size_t)nl * per_stamp;
+    m.user_sum = psf_sum_out;
+    m.sums.assign(psf_sum_out ? (size_t)nctx * m.n : 0, 0.0);
+    m.tickets.assign(nctx, -1);
+    for (int k = 0; k < used; ++k) {
+        const int a = start[k], n = start[k + 1] - a;
+        const int rc = mpsfr_reconstruct(ctxs[k], n, seeing + a, gl + a, l0 + a, three_lgs ? three_lgs + a : nullptr, h,
+                                         wind_speed, npsflin, nl, lbda_nm, mask_rec, mask_res,
+                                         psf_out ? psf_out + (size_t)a * nl * per_stamp : nullptr,
+                                         psf_sum_out ? m.sums.data() + (size_t)k * m.n : nullptr,
+                                         fit_out ? fit_out + (size_t)a * nl * NFIT : nullptr, 2);
+        if (rc != MPSFR_OK) {
+            // the shards already queued still point at the caller's arrays and at m.sums: give them up
+            const std::string msg = g_err;
+            for (int q = 0; q < k; ++q) (void)mpsfr_abandon(ctxs[q]);
+            return fail(rc, "context %d: %s", k, msg.c_str());
+        }
+        m.tickets[k] = mpsfr_last_ticket(ctxs[k]);
+    }
+    m.pending = true;
+    return MPSFR_OK;
+}
+
+int mpsfr_wait_multi(mpsfr_ctx* const* ctxs, int nctx) {
+    if (!ctxs || nctx < 1 || !ctxs[0]) return fail(MPSFR_E_INVALID, "need at least one context");
+    mpsfr_ctx::Multi& m = ctxs[0]->multi;
+    if (!m.pending) return MPSFR_OK;
+    if (nctx != m.nctx) return fail(MPSFR_E_INVALID, "mpsfr_wait_multi: %d contexts, the pending call had %d", nctx, m.nctx);
+    int rc = MPSFR_OK;
+    std::string msg;
+    for (int k = 0; k < nctx; ++k) {
+        if (m.tickets[k] < 0) continue;
+        const int r = mpsfr_wait(ctxs[k], m.tickets[k]);
+        if (r != MPSFR_OK && rc == MPSFR_OK) { rc = r; msg = g_err; }
+    }
+    m.pending = false;
+    if (rc != MPSFR_OK) return fail(rc, "%s", msg.c_str());
+    if (m.user_sum)          // in context order: the result does not depend on which shard finished first
+        for (size_t e = 0; e < m.n; ++e) {
+            double t = m.sums[e];
+            for (int k = 1; k < nctx; ++k)
+                if (m.tickets[k] >= 0) t += m.sums[(size_t)k * m.n + e];
+            m.user_sum[e] = t;
+        }
+    return MPSFR_OK;
+}
+
+int mpsfr_fit_rows(const double* fit, long n, double pixscale, double* out, long stride) {
+    if (!fit || !out || n < 0 || stride < 14) return fail(MPSFR_E_INVALID, "mpsfr_fit_rows: bad argument");
+    for (long r = 0; r < n; ++r) {
+        const double* f = fit + (size_t)r * NFIT;
+        double* o = out + (size_t)r * stride;
+        o[0] = f[1];                     // center
+        o[1] = f[2];
+        o[2] = f[15];                    // flux
+        o[3] = o[4] = f[5] * pixscale;   // fwhm
+        o[5] = f[4];                     // n
+        o[6] = f[0];                     // peak
+        o[7] = f[9];                     // err_center
+        o[8] = f[10];
+        const double a = f[8] / f[0], b = 2.0 * f[11] / f[3], d = f[12] / (f[4] - 1.0);
+        o[9] = std::fabs(f[15]) * std::sqrt(a * a + b * b + d * d);      // err_flux
+        o[10] = o[11] = f[13] * pixscale;                                // err_fwhm
+        o[12] = f[12];                   // err_n
+        o[13] = f[8];                    // err_peak
+    }
     return MPSFR_OK;
 }
 

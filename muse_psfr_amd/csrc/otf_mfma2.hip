@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64 * 8) k_mf_prep(const MaskArgs a) {
     const int kk = min(lane, nks - 1);
     const bool nopr = a.dminb == nullptr && a.dlin == nullptr;
     float thr_keep = fmaxf(a.thr, a.thr_floor), thr_mid = a.thr_mid;
-    if (!nopr && lv && a.tier_half > 0.f && a.D0t != nullptr && thr_mid > a.thr) {
+    if (!nopr && lv && a.tier_half > 0.f && a.D0t != nullptr && fmaxf(thr_mid, thr_keep) > a.thr) {
         // mass of the blocks with a bound in (lo, hi]: 2 half planes x 512 elements x the bound each
         auto mass = [&](float lo, float hi) {
             float m = 0.f;
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(64 * 8) k_mf_prep(const MaskArgs a) {
         float mf = 0.f, mm = 0.f;
         for (int mt = 0; mt < nmt; ++mt) {
             const float e = fmaf(c2, s_dm[mt * nks + kk], s_tb[mt * nks + kk]);
-            const float x = (lane < nks && e > a.thr && e <= thr_mid) ? __builtin_amdgcn_exp2f(e) : 0.f;
+            const float x = (lane < nks && e > a.thr && e <= fmaxf(thr_mid, thr_keep)) ? __builtin_amdgcn_exp2f(e) : 0.f;
             mf += e <= thr_keep ? x : 0.f;
             mm += e <= thr_keep ? 0.f : x;
         }
@@ -184,7 +184,8 @@ __global__ void __launch_bounds__(64 * 8) k_mf_prep(const MaskArgs a) {
                 // line 0 once, the others stand for both half planes
                 S += (i0 < N / 4 ? xa : 2.f * xa) + (i0 + 64 < N / 4 ? xb : 2.f * xb);
             }
-            const float budget = a.tier_half * wave_sum_f(S);
+            // (tl2 carries the 2^kShift of the fp16 scaling: mf_common.h)
+            const float budget = a.tier_half * wave_sum_f(S) * __builtin_amdgcn_exp2f(-kShift);
             if (mf > budget) {
                 do {
                     thr_keep -= 2.f;

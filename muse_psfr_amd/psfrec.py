@@ -21,7 +21,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from . import _minifits
+from . import _lib, _minifits
 from ._lib import Context, MpsfrError, E_GRID
 
 MIN_L0 = 8    # minimum L0 in m (psfrec.py:30)
@@ -202,15 +202,18 @@ def _reconstruct(lbda, tasks, npsflin, h, dim, dimpsf, pixscale, precision, cuto
         raise
 
 
-PIPELINE_MIN_TASKS = 125      # rows per asynchronous part of a large single-device table
+PIPELINE_MIN_TASKS = 125      # a single-device table of at least twice as many tasks goes through asynchronous parts
+PIPELINE_PARTS = 2            # one part per pipeline lane (with the FIT_ROWS columns written in C -- mpsfr_fit_rows --
+                              # the parts' host work no longer pays for more: 1000 rows x 35 lambda at 512^2 take
+                              # 2.41 / 2.49 / 2.62 / 2.64 ms in 2 / 3 / 4 / 5 parts)
 
 
 def _reconstruct_pipelined(lbda, stats, three, laser_idx, npsflin, h, dim, dimpsf, pixscale, precision,
                            cutoff_masks, dev):
-    """compute_psf_from_sparta's batch as 2-4 asynchronous parts on one context, the FIT_ROWS records of a
+    """compute_psf_from_sparta's batch as asynchronous parts (PIPELINE_PARTS) on one context, the FIT_ROWS records of a
     part assembled while the next parts are on the GPU.  Returns (dict(psf_sum, devices, rec), records)."""
     ntask, nlam = len(stats), lbda.size
-    nparts = max(2, min(4, ntask // PIPELINE_MIN_TASKS))
+    nparts = max(2, min(PIPELINE_PARTS, ntask // PIPELINE_MIN_TASKS))
     bounds = [ntask * k // nparts for k in range(nparts + 1)]
     masks = _resolve_masks(cutoff_masks)
     ctx = get_context(dim, pixscale, dimpsf, precision, dev, 0)
@@ -288,15 +291,10 @@ def _fit_rows_template(lbda, stats, laser_idx):
 
 def _fit_rows_fill(blk, fit, pixscale):
     """The fit columns of FIT_ROWS (the values of _fit_columns) into the rows `blk` ((n, 20) view of the
-    records) from the library's fit rows `fit` (.., NFIT): one row-wise gather (np.take: 4x faster than
-    fancy indexing on both sides) instead of column-by-column copies."""
-    f = fit.reshape(-1, fit.shape[-1])
-    blk[:, 1:15] = np.take(f, [1, 2, 15, 5, 5, 4, 0, 9, 10, 0, 13, 13, 12, 8], axis=1)
-    blk[:, 4:6] *= pixscale
-    blk[:, 11:13] *= pixscale
-    with np.errstate(all='ignore'):
-        rel = np.sqrt((f[:, 8] / f[:, 0]) ** 2 + (2 * f[:, 11] / f[:, 3]) ** 2 + (f[:, 12] / (f[:, 4] - 1)) ** 2)
-    blk[:, 10] = np.abs(f[:, 15]) * rel
+    records) from the library's fit rows `fit` (.., NFIT): one pass in C (mpsfr_fit_rows), straight into the
+    records -- the NumPy form (a row-wise gather + six strided column operations) took 0.28 ms per 8750 rows,
+    a third of the host's critical path behind the last part of a large table."""
+    _lib.fit_rows(fit, pixscale, blk[:, 1:15])
 
 
 def _fit_rows_records(lbda, fit, pixscale, stats, laser_idx):

@@ -287,6 +287,39 @@ def test_reconstruct_multi_in_the_library(api):
             c.close()
 
 
+def test_asynchronous_multi_context_call(api):
+    """mpsfr_reconstruct_multi_async / mpsfr_wait_multi: the shards of a table as asynchronous host-output calls on
+    several contexts (here three on the one GPU), no host thread, the caller free until it waits -- against the
+    blocking multi-context call bit for bit; one call pending per ctxs[0]; a failing shard leaves the contexts
+    usable and the arrays of the shards already queued unwritten."""
+    from muse_psfr_amd._lib import Context, MpsfrError
+    see, gl, l0 = api.synthetic_rows(23)
+    three = (np.arange(23) % 4 == 0).astype(np.uint8)
+    lb = np.linspace(500, 900, 5)
+    ps = api.grid_pixscale(256)
+    ctxs = [Context(dim=256, pixscale=ps, precision='mixed', device=0) for _ in range(3)]
+    try:
+        want = Context.reconstruct_multi(ctxs, lb, see, gl, l0, three, (100, 10000))
+        for _ in range(2):
+            p = Context.reconstruct_multi_async(ctxs, lb, see, gl, l0, three, (100, 10000))
+            with pytest.raises(MpsfrError):            # one pending call per ctxs[0]
+                Context.reconstruct_multi_async(ctxs, lb, see, gl, l0, three, (100, 10000))
+            got = p.wait()
+            for k in ('psf', 'fit', 'psf_sum'):
+                np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+            assert all(not c._pending for c in ctxs)
+        few = Context.reconstruct_multi_async(ctxs, lb, see[:2], gl[:2], l0[:2], three[:2], (100, 10000)).wait()
+        np.testing.assert_array_equal(few['fit'], want['fit'][:2])
+        with pytest.raises(MpsfrError) as e:           # 100 nm: the first shard already fails
+            Context.reconstruct_multi_async(ctxs, np.array([100.0, 700.0]), see, gl, l0, three, (100, 10000))
+        assert 'context 0' in str(e.value)
+        again = Context.reconstruct_multi_async(ctxs, lb, see, gl, l0, three, (100, 10000)).wait()
+        np.testing.assert_array_equal(again['fit'], want['fit'])
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_asynchronous_host_outputs_equal_the_blocking_call(api):
     """on_device = 2 (Context.reconstruct_async): several calls in flight -- more than the ring of four
     staging sets holds, so that the library hands the oldest over by itself -- give, bit for bit, what
@@ -438,6 +471,7 @@ def test_large_table_whose_later_part_fails_leaves_no_pending_arrays(api, monkey
     import gc
     from muse_psfr_amd import psfrec
     from muse_psfr_amd._lib import Context
+    monkeypatch.setattr(psfrec, 'PIPELINE_PARTS', 4)
     tbl = _big_table(api, 520)                    # four parts
     kw = dict(verbose=False, dim=128, pixscale=api.grid_pixscale(128), lmin=500, lmax=900, nl=3)
     want = api.compute_psf_from_sparta(_hdul(tbl), **kw)

@@ -711,6 +711,7 @@ def test_line_pruning_changes_nothing_above_its_bound(api, dim, npl):
     out = {}
     for key, eps in (('all', 0.0), ('pruned', None), ('loose', 1e-6)):
         ctx = api.Context(dim=dim, pixscale=ps, precision='mixed')
+        ctx.set_option('tier_eps', 0)          # the eps rule alone (the precision tiers have their own test)
         if eps is not None:
             ctx.set_option('prune_eps', eps)
         out[key] = ctx.reconstruct(lb, see, gl, l0, three, H, npsflin=npl)
