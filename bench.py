@@ -958,6 +958,30 @@ def main():
                 traffic = per_unit * units_per_launch
             traffic_step = sum((v.get('fetch_kib', 0) + v.get('write_kib', 0)) * 1024.0
                                for v in tj['kernels'].values())
+        # step-level utilisation: what the kernels of ONE call keep busy, summed over the call
+        # (PMC passes with one call in flight, profiles/<round>_kernel_util.json), over the pipelined step time
+        step_util = None
+        if util and (dim, nl, rows, a.npsflin, mixed) == (512, 35, 100, 1, True):
+            ks = {k: v for k, v in util.items() if isinstance(v, dict) and 'avg_us' in v}
+            tot_us = sum(v['avg_us'] for v in ks.values())
+            step_us = dt / a.steps * 1e6
+            busy = {key: sum(v['avg_us'] * (v.get(src) or 0.0) for v in ks.values())
+                    for key, src in (('valu_issue', 'valu_issue'), ('mfma_busy', 'mfma_busy'), ('lds_busy', 'lds_array_busy'))}
+            pipelined = {k: v[0] / max(nprof, 1) for k, v in prof_all.items() if v[1]}
+            big = max(pipelined, key=pipelined.get) if pipelined else None
+            step_util = {'kernel_us_per_call_one_in_flight': round(tot_us, 1), 'step_us': round(step_us, 1),
+                         'lane_overlap': round(tot_us / step_us, 3),
+                         'valu_issue_us': round(busy['valu_issue'], 1), 'mfma_busy_us': round(busy['mfma_busy'], 1),
+                         'lds_busy_us': round(busy['lds_busy'], 1),
+                         'valu_issue_frac': round(busy['valu_issue'] / step_us, 4),
+                         'mfma_busy_frac': round(busy['mfma_busy'] / step_us, 4),
+                         'lds_busy_frac': round(busy['lds_busy'] / step_us, 4),
+                         'largest_pipelined_share': big and {'kernel': big, 'ms_per_step': round(pipelined[big], 4),
+                                                            'share_of_kernel_time': round(pipelined[big] / sum(pipelined.values()), 4)},
+                         'note': 'sum over the kernels of a call of (duration x share of cycles the unit is busy) / time per '
+                                 'step of the two-lane pipeline: no unit of the chip is busy for more than this fraction of a '
+                                 'step -- the path is bound by latency and occupancy (registers, LDS), not by a pipe or by HBM',
+                         'source': 'profiles/%s' % util_name}
         series = 'dphi_series' in prof_all or ('dphi_series' in prof)
         model = hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac, has_tq=mf_work is None,
                                 series=series or (not prof_all and series_form(dim, a.npsflin)))
@@ -1014,6 +1038,7 @@ def main():
                          'mfma_busy': u and u.get('mfma_busy'),
                          'lds_busy': u and u.get('lds_array_busy'),
                          'pmc_source': u and 'profiles/%s (scripts/prof_table.sh, one step in flight)' % util_name,
+                         'step': step_util,
                          # the whole step against HBM (the pipe north_star names): algorithmic bytes of the
                          # pipeline as built over the step time; `alone_frac`: the kernel with nothing beside it
                          'hbm_frac': round(model_step / step_s / 1e9 / PEAK_HBM_GBPS, 4),

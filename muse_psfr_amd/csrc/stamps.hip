@@ -1053,20 +1053,25 @@ __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][
 template <typename RE>
 constexpr int fit_min_waves() { return sizeof(RE) == 4 ? MPSFR_FIT_WAVES : 2; }
 
+// Stamps (= waves) per workgroup.  The waves of a workgroup share nothing, but a workgroup's slots are
+// released together: with four stamps per workgroup a slot waits for the slowest of four fits.
+#ifndef MPSFR_FIT_WG
+#define MPSFR_FIT_WG 1
+#endif
 template <typename RE, typename TS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fit_min_waves<RE>())))
+__global__ void __launch_bounds__(64 * MPSFR_FIT_WG) __attribute__((amdgpu_waves_per_eu(fit_min_waves<RE>())))
 k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit, double polish_tol) {
     constexpr int NPX = NS * NS / 64;                     // 25 pixels per lane
     static_assert(NPX * 64 == NS * NS, "the lane map assumes 1600 pixels");
     using S = RE;                                         // type of the LM state
     const int lane = threadIdx.x & 63;
-    const int st = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int st = blockIdx.x * MPSFR_FIT_WG + (threadIdx.x >> 6);
     if (st >= nstamp) return;                             // the whole wave exits together
     const TS* src = stamps + (size_t)st * NS * NS;
     // the stamp in the evaluation type, LDS-resident for the LM evaluations (25 fewer VGPRs than
     // register-resident pixels: with the gradient-only polish this reaches 4 waves per SIMD, so
     // all 3500 stamps of the bench step are resident at once instead of in two rounds)
-    __shared__ RE spix[4][NS * NS];
+    __shared__ RE spix[MPSFR_FIT_WG][NS * NS];
     RE* sp = spix[threadIdx.x >> 6];
     // comparisons in the type the stamp is stored in (exact; in double they were a conversion and
     // a two-register select per pixel for float stamps)
@@ -1086,22 +1091,71 @@ k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit, doubl
         const int oo = __shfl_xor(besto, o, 64);
         if (ob > best || (ob == best && oo < besto)) { best = ob; besto = oo; }
     }
+    // Start values.  The LM phase costs one pass over the stamp per iteration, so a start inside the
+    // basin of quadratic convergence is worth a few hundred instructions of setup.  Moments of the
+    // stamp over the largest disc around the brightest pixel that fits the stamp, R = (distance to the
+    // nearest edge) + 1/2: for a Moffat sampled at its centre
+    //     S1 = sum d   = I pi a^2 / (n - 1)  T1,   T1 = 1 - (1 + R^2/a^2)^(1 - n)
+    //     S2 = sum d^2 = I^2 pi a^2 / (2n - 1) T2,  T2 = 1 - (1 + R^2/a^2)^(1 - 2n)
+    // so (S2/T2) / (I S1/T1) = (n - 1)/(2n - 1) gives n and then a; the truncation factors T1, T2 by
+    // fixed-point iteration from T = 1 (five rounds: eta to ~0.01, FWHM to 1 % on the bench stamps, which
+    // are Moffat-like but not Moffats).  Mean LM passes per stamp 3.07 -> 2.34 on the bench workload,
+    // 3.69 -> 2.86 on the native-grid goldens (NumPy study with the iteration rules of this kernel); a
+    // brightest pixel within six pixels of an edge (caller stamps) falls back to the half-maximum area
+    // and n = 2.5.  The least-squares minimum is unique: the start only sets the
+    // iteration count.
+    const int p0i = besto / NS, q0i = besto % NS;
+    const int rm = min(min(p0i, NS - 1 - p0i), min(q0i, NS - 1 - q0i));
     int cnt = 0;
     const TS half = (TS)0.5 * best;
+    float ms1 = 0.f, ms2 = 0.f;
+    {
+        const float r2 = ((float)rm + 0.5f) * ((float)rm + 0.5f);
+        const float lrf = (float)((lane >> 3) - p0i), lcf = (float)((lane & 7) - q0i);   // pixel map: moffat_accumulate
+        const RE* pl = sp + (lane >> 3) * NS + (lane & 7);
 #pragma unroll
-    for (int m = 0; m < NPX; ++m) cnt += (TS)sp[lane + m * 64] > half ? 1 : 0;
+        for (int mo = 0; mo < 5; ++mo) {
+            const float dp = (float)(8 * mo) + lrf, dp2 = dp * dp;
+#pragma unroll
+            for (int mi = 0; mi < 5; ++mi) {
+                const float dq = (float)(8 * mi) + lcf;
+                const float d = (float)pl[mo * 8 * NS + mi * 8];
+                cnt += (TS)pl[mo * 8 * NS + mi * 8] > half ? 1 : 0;
+                const float din = fmaf(dq, dq, dp2) <= r2 ? d : 0.f;
+                ms1 += din;
+                ms2 = fmaf(din, din, ms2);
+            }
+        }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    // start values: peak and its position, FWHM from the area above half maximum, n = 2.5.
-    // (The least-squares minimum is unique -- SURVEY.md 8(c) -- so the start only sets the
-    // iteration count; the oracle starts from fwhm = 4 px, n = 2.  A start from two points of
-    // the radial profile saved 0.3 iterations on average and cost more than it saved.)
+    ms1 = wave_total(ms1);
+    ms2 = wave_total(ms2);
     double fw0 = 2.0 * sqrt((double)cnt / kPi);
     fw0 = fmin(fmax(fw0, 1.5), (double)NS);
+    float eta0 = 0.4f;
+    if (rm >= 6 && ms1 > 0.f && (float)best > 0.f) {
+        const float bf = (float)best, r2 = ((float)rm + 0.5f) * ((float)rm + 0.5f);
+        float t1 = 1.f, t2 = 1.f, nn = 2.5f, a2 = 1.f;
+#pragma unroll 1
+        for (int k = 0; k < 6; ++k) {
+            float rho = (ms2 * t1) * __builtin_amdgcn_rcpf(bf * ms1 * t2);
+            rho = fminf(fmaxf(rho, 0.05f), 0.47f);
+            nn = (1.f - rho) * __builtin_amdgcn_rcpf(1.f - 2.f * rho);
+            nn = fminf(fmaxf(nn, 1.1f), 15.f);
+            a2 = ms1 * (nn - 1.f) * __builtin_amdgcn_rcpf(t1 * bf * 3.14159265f);
+            const float lx = __builtin_amdgcn_logf(1.f + r2 * __builtin_amdgcn_rcpf(a2));
+            t1 = 1.f - __builtin_amdgcn_exp2f((1.f - nn) * lx);
+            t2 = 1.f - __builtin_amdgcn_exp2f((1.f - 2.f * nn) * lx);
+        }
+        eta0 = __builtin_amdgcn_rcpf(nn);
+        const float w = 2.f * __builtin_amdgcn_sqrtf(a2 * (__builtin_amdgcn_exp2f(eta0) - 1.f));
+        if (w == w) fw0 = fmin(fmax((double)w, 1.5), (double)NS);
+    }
     // LM variables (I, p0, q0, w = FWHM, eta = 1/n): towards broad, Gaussian-like profiles the
     // model is nearly linear in 1/n, and the valley that n -> large opens in (w, n) stays short --
     // at most 4 iterations where the fit in n took up to 29
-    S v[5] = {(S)best, (S)(besto / NS), (S)(besto % NS), (S)fw0, (S)0.4};
+    S v[5] = {(S)best, (S)p0i, (S)q0i, (S)fw0, (S)eta0};
     // float evaluation only has to reach the basin of quadratic convergence: the fp64 polish
     // below finishes the job.  Every lane carries the same LM state (the totals of
     // moffat_accumulate are wave-uniform), so the control flow is uniform.
@@ -1351,10 +1405,12 @@ void launch_conv_fft(hipStream_t s, int ntask, int nl, const void* d_pre, const 
 void launch_fit(hipStream_t s, int nstamp, const void* d_stamps, bool stamps_f32, double* d_fit,
                 bool f64) {
     if (nstamp <= 0) return;
-    // One wavefront per stamp, four stamps per workgroup.  (A whole workgroup per stamp with the
-    // wave sums meeting in LDS measured 1.8x slower at 3500 stamps: every wave repeats the 5x5
-    // solves and the iterations serialise on barriers.)
-    const dim3 grid((nstamp + 3) / 4);
+    // One wavefront per stamp and one stamp per workgroup: the waves share nothing, and a workgroup of
+    // four gave its slots back only when the slowest of its four fits was done (alone, bracketed:
+    // 56.1 us with one stamp per workgroup, 57.9 with two, 58.0 with four).  (A whole workgroup per
+    // stamp with the wave sums meeting in LDS measured 1.8x slower at 3500 stamps: every wave repeats
+    // the 5x5 solves and the iterations serialise on barriers.)
+    const dim3 grid((nstamp + MPSFR_FIT_WG - 1) / MPSFR_FIT_WG), blk(64 * MPSFR_FIT_WG);
     // f64 mode: the same float Levenberg-Marquardt iterations find the basin (they cost a third of
     // fp64 ones), and the polish on the fp64 stamps runs on until its steps are below 1e-8 (or
     // MPSFR_POLISH_MAX passes).  Only the residual of that pass is fp64: moffat_gradient rounds it to
@@ -1366,13 +1422,13 @@ void launch_fit(hipStream_t s, int nstamp, const void* d_stamps, bool stamps_f32
 #define MPSFR_FIT_F64_LM 0
 #endif
     if (f64 && MPSFR_FIT_F64_LM)
-        hipLaunchKernelGGL((k_fit<double, double>), grid, dim3(256), 0, s, nstamp,
+        hipLaunchKernelGGL((k_fit<double, double>), grid, blk, 0, s, nstamp,
                            (const double*)d_stamps, d_fit, 0.0);
     else if (stamps_f32)
-        hipLaunchKernelGGL((k_fit<float, float>), grid, dim3(256), 0, s, nstamp, (const float*)d_stamps,
+        hipLaunchKernelGGL((k_fit<float, float>), grid, blk, 0, s, nstamp, (const float*)d_stamps,
                            d_fit, (double)MPSFR_POLISH_TOL);
     else
-        hipLaunchKernelGGL((k_fit<float, double>), grid, dim3(256), 0, s, nstamp,
+        hipLaunchKernelGGL((k_fit<float, double>), grid, blk, 0, s, nstamp,
                            (const double*)d_stamps, d_fit, f64 ? 1.0e-8 : (double)MPSFR_POLISH_TOL);
 }
 

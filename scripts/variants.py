@@ -41,12 +41,13 @@ def run(args):
         d = json.loads(line[0])
         par = d.get('parity') or {}
         k = d['kernel_ms_per_step']
+        ka = d.get('kernel_ms_one_call_in_flight') or {}
         print('%-14s %.3f M/s  step %.4f ms | otf %.4f prep %.4f fit %.4f colpass %.4f conv %.4f psd %.4f colfft %.4f'
-              ' | dbeta %.1e dfwhm %.1e | it %s' % (
+              ' | alone: fit %.4f conv %.4f otf %.4f | dbeta %.1e dfwhm %.1e | it %s' % (
                   lib or 'default', d['value'] / 1e6, d['ms_per_step'], k.get('otf_mfma', 0) + k.get('otf_rowfft', 0),
                   k.get('mf_prep', 0) + k.get('vkeep', 0),
                   k.get('fit', 0), k.get('colpass', 0), k.get('conv', 0), k.get('psd_rowfft', 0),
-                  k.get('colfft_dphi', 0), par.get('max_abs_err_beta', float('nan')),
+                  k.get('colfft_dphi', 0), ka.get('fit', 0), ka.get('conv', 0), ka.get('otf_mfma', 0), par.get('max_abs_err_beta', float('nan')),
                   par.get('max_abs_err_fwhm_arcsec', float('nan')), d['fit_iterations']), flush=True)
 
 

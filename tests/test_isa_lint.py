@@ -55,6 +55,9 @@ def test_rules_on_handwritten_snippets():
     assert _rules(['v_exp_f32_e32 v4, v5', 'v_fma_mix_f32 v6, v7, -1.0, v4 op_sel_hi:[1,0,0]', 's_endpgm']) == ['R4']
     assert _rules(['v_exp_f32_e32 v4, v5', 'v_exp_f32_e32 v8, v9',
                    'v_fma_mix_f32 v6, v7, -1.0, v4 op_sel_hi:[1,0,0]', 's_endpgm']) == []
+    # a dependent chain of transcendentals stays in their own pipe: no hazard (hipcc emits these back to back)
+    assert _rules(['v_rcp_f32_e32 v4, v9', 'v_exp_f32_e32 v0, v4', 's_nop 0', 'v_add_f32_e32 v1, v0, v0', 's_endpgm']) == []
+    assert _rules(['v_rcp_f32_e32 v4, v9', 'v_exp_f32_e32 v0, v4', 'v_add_f32_e32 v1, v0, v0', 's_endpgm']) == ['R4']
     # a barrier behind an LDS-DMA load without the vmcnt(0) wait
     assert _rules(DMA_OK + ['s_waitcnt lgkmcnt(0)', 's_barrier', 's_endpgm']) == ['R5']
     assert _rules(DMA_OK + ['s_waitcnt vmcnt(0) lgkmcnt(0)', 's_barrier', 's_endpgm']) == []

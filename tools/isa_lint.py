@@ -21,7 +21,10 @@ instruction of every kernel (it cannot tell compiler instructions from asm ones,
   R3  a VGPR written by a (non-MFMA) vector instruction is not read by a v_mfma_* as A, B or C
       within 2 wait states;
   R4  a VGPR written by a transcendental instruction (v_exp, v_log, v_rcp, v_rsq, v_sqrt, v_sin,
-      v_cos) is not read by the next vector instruction (1 wait state);
+      v_cos) is not read by the next vector instruction (1 wait state) -- unless that instruction is
+      itself transcendental: the hazard is the forwarding from the transcendental unit to the main
+      vector pipe (LLVM's GCNHazardRecognizer checks exactly this for gfx940+: a dependent chain of
+      transcendentals stays in their in-order pipe, and hipcc emits such chains back to back);
   R5  in a kernel that issues LDS-DMA loads, every s_barrier is preceded, on every path, by an
       s_waitcnt vmcnt(0) with no LDS-DMA load in between (a barrier does not drain the DMA, and the
       waves behind it read what the DMA wrote).
@@ -236,7 +239,7 @@ def lint_kernel(name, code):
                     return True
                 return False
             walk_back(code, preds, i, 2, v3)
-        if ins.is_valu() or ins.is_mfma():
+        if (ins.is_valu() and not ins.is_trans()) or ins.is_mfma():
             vsrc = {r for r in ins.src_regs() if r[0] == 'v'}
             def v4(j, between, vsrc=vsrc, i=i):
                 pj = code[j]
