@@ -34,7 +34,7 @@ PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector / fp32 matrix peak (MI355X_MIC
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak (same guide)
 PEAK_HBM_GBPS = 8000.0
 PEAK_FP64_TFLOPS = 78.6        # fp64 vector (= fp64 matrix) peak (same guide)
-PROFILE_ROUND = 'r04'          # profiles/<round>_kernel_util.json, _traffic.json, _parity_margins.json
+PROFILE_ROUND = 'r05'          # profiles/<round>_kernel_util.json, _traffic.json, _parity_margins.json
 PIPELINE_HAS_TQ = True       # FFT form of the per-wavelength stage: the sampled first-pass lines go through HBM
 sys.path.insert(0, ROOT)
 

@@ -4,7 +4,7 @@
 set -e
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-COMMON="--gpus 1 --steps 200 --warmup 5 --cpu-rows 0 --f64-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --profile-steps 0"
+COMMON="--gpus 1 --steps 200 --warmup 5 --cpu-rows 0 --f64-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --e2e-steps 0 --profile-steps 0"
 for rows in 125 500; do
   python3 bench.py $COMMON --rows $rows > gpurun_out/x_none_$rows.json
   for mode in packed two; do

@@ -2,7 +2,7 @@
 # f64 mode: single-lane kernel table
 export TMPDIR=/tmp
 OUT=gpurun_out/trace_f64; mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --precision f64 --steps 10 --warmup 2 --cpu-rows 0 --f64-steps 0 --profile-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --prime 64 --streams 1 > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --precision f64 --steps 10 --warmup 2 --cpu-rows 0 --f64-steps 0 --profile-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --e2e-steps 0 --prime 64 --streams 1 > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }
 cp $(ls $OUT/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 python3 - <<'PY'
 import csv,re

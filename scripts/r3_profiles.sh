@@ -11,7 +11,7 @@ python3 scripts/traffic_json.py gpurun_out/prof_r03 > gpurun_out/prof_r03/traffi
 echo "two-lane done"
 # native 1280 grid: kernel trace (single lane) and a PMC pass
 OUT=gpurun_out/prof_1280; mkdir -p $OUT/trace
-NAT="--dim 1280 --rows 100 --nl 35 --cpu-rows 0 --f64-steps 0 --profile-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --prime 64 --streams 1"
+NAT="--dim 1280 --rows 100 --nl 35 --cpu-rows 0 --f64-steps 0 --profile-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --e2e-steps 0 --prime 64 --streams 1"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $NAT --steps 10 --warmup 2 > $OUT/trace.log 2>&1 || { echo native trace failed; tail -5 $OUT/trace.log; exit 1; }
 cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 grep '^{' $OUT/trace.log > $OUT/bench.json

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/pmcb_$1; shift
 rm -rf $OUT; mkdir -p $OUT/trace
-B="--cpu-rows 0 --f64-steps 0 --profile-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --prime 64 --streams 1"
+B="--cpu-rows 0 --f64-steps 0 --profile-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --e2e-steps 0 --prime 64 --streams 1"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 2 $B "$@" > $OUT/trace.log 2>&1 || exit 1
 i=0
 while read -r P; do

@@ -2,7 +2,7 @@
 # CU-partitioned lanes: lanes x cu_partition at configs[1] (100 rows) and configs[2] on one GPU (1000 rows)
 out=gpurun_out/r5_lanes.txt
 : > $out
-Q="--f64-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --cpu-rows 0 --profile-steps 0 --steps 300 --warmup 10"
+Q="--f64-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --e2e-steps 0 --cpu-rows 0 --profile-steps 0 --steps 300 --warmup 10"
 for rows in 100 1000; do
 for st in 2 3 4; do
 for cp in 0 1; do

@@ -2,7 +2,7 @@
 # potential of higher tier thresholds (no budget): floor / mid sweeps at configs[1]
 out=gpurun_out/r5_tiers.txt
 : > $out
-Q="--f64-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --cpu-rows 12 --steps 300 --warmup 10"
+Q="--f64-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --e2e-steps 0 --cpu-rows 12 --steps 300 --warmup 10"
 for cfg in "-29.01 -18.01" "-26 -18.01" "-23 -18.01" "-20 -18.01" "-29.01 -14" "-29.01 -10" "-23 -12" "-20 -10" "-18 -8"; do
   set -- $cfg
   MPSFR_TIER_EPS=inf MPSFR_MF_FLOOR_LOG2=$1 MPSFR_MF_MID_LOG2=$2 python bench.py $Q > gpurun_out/_l.json 2> gpurun_out/_l.err || { echo "FAILED $cfg" >> $out; tail -3 gpurun_out/_l.err >> $out; continue; }

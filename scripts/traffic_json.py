@@ -19,7 +19,7 @@ for blk in re.split(r'\n(?=\S)', txt):
 print(json.dumps({
     'round': 4,
     'command': 'scripts/prof_all.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes, no tracing) '
-               '-- python3 bench.py --steps 3 --warmup 1 --cpu-rows 0 --f64-steps 0 --profile-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0',
+               '-- python3 bench.py --steps 3 --warmup 1 --cpu-rows 0 --f64-steps 0 --profile-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --e2e-steps 0',
     'workload': '100 rows x 35 lambda x 512^2, mixed precision, one context with two lanes, one launch of '
                 '100 rows per step',
     'units': 'FETCH_SIZE/WRITE_SIZE in KiB per launch (rocprofv3), mean over launches; FETCH_SIZE is not '
