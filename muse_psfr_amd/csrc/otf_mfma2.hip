@@ -91,7 +91,7 @@ struct MaskArgs {
     // Precision tiers under a budget: blocks with a bound in (thr, thr_floor] are dropped and
     // blocks in (thr_floor, thr_mid] run without the low fp16 half of the OTF -- as far as the OTF mass each of
     // the two leaves out stays below tier_half of a lower bound of the PSF peak, the OTF summed exactly over
-    // the first kPeakLines lines of the half plane (D0t, tl2).  Where it would not, the wave lowers the
+    // the first peak_lines(N) lines of the half plane (D0t, tl2).  Where it would not, the wave lowers the
     // threshold for its (task, wavelength) until it does.  tier_half <= 0 or D0t == nullptr: no budget.
     float thr_floor, tier_half;
     const float* D0t;        // [ntask][N/2+1][N]
@@ -108,7 +108,8 @@ struct MaskArgs {
 
 constexpr int kMaxNmt = 1280 / 2 / MTL + 1, kMaxNks = 1280 / KBL;      // 41, 40
 
-constexpr int kPeakLines = 4;      // lines of the half plane summed for the lower bound of the peak
+// lines of the half plane summed for the lower bound of the peak (two on the large grids: as many elements)
+__host__ __device__ constexpr int peak_lines(int N) { return N > 512 ? 2 : 4; }
 
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(64 * 8) k_mf_prep(const MaskArgs a) {
             const float4* d4 = reinterpret_cast<const float4*>(a.D0t + (size_t)task * H1 * N);
             const float4* t4 = reinterpret_cast<const float4*>(a.tl2);
             float S = 0.f;
-            const int n4 = kPeakLines * N / 4;            // a multiple of 128
+            const int n4 = peak_lines(N) * N / 4;         // a multiple of 128
             for (int i0 = lane; i0 < n4; i0 += 128) {     // four loads in flight
                 const float4 da = d4[i0], ta = t4[i0], db = d4[i0 + 64], tb = t4[i0 + 64];
                 const float xa = (__builtin_amdgcn_exp2f(fmaf(c2, fmaxf(da.x, 0.f), ta.x)) + __builtin_amdgcn_exp2f(fmaf(c2, fmaxf(da.y, 0.f), ta.y))) +
