@@ -186,9 +186,14 @@ void launch_khat(hipStream_t s, int nker, const double* d_gamma, const double* d
 // f64: double stamps in and out, fp64 transforms, khat tables of complex double
 void launch_conv_fft(hipStream_t s, int ntask, int nl, const void* d_pre, const void* d_khat_tt,
                      const void* d_khat_muse, void* d_fin, bool fin_f32, bool f64 = false);
+// (sum_*: the deterministic sum of the stamps over the sum_ntask tasks of the chunk -- [sum_nl][40][40] into d_sum,
+// added to it if sum_accumulate -- as the first workgroups of the same launch; d_sum = nullptr: none)
 void launch_fit(hipStream_t s, int nstamp, const void* d_stamps, bool stamps_f32, double* d_fit,
-                bool f64);
+                bool f64, int sum_ntask = 0, int sum_nl = 0, double* d_sum = nullptr, int sum_accumulate = 0);
 void launch_stamp_sum(hipStream_t s, int ntask, int nl, const void* d_fin, bool fin_f32, double* d_sum,
                       int accumulate);
+// the call's parameter blob from pinned host memory into device memory, as a kernel of the call's own queue
+// (bytes: a multiple of 16)
+void launch_param_copy(hipStream_t s, void* d_dst, const void* h_src_pinned, size_t bytes);
 
 }  // namespace mpsfr

@@ -114,6 +114,7 @@ struct mpsfr_ctx {
     Lane lane[MAX_LANES];
     int nlanes = 0;              // 0 = automatic (two lanes)
     int cu_partition = 0;        // 1: every lane's stream owns 1/lanes of the CUs (hipExtStreamCreateWithCUMask)
+    bool param_copy_kernel = true;   // the parameter blob of a call is fetched by a kernel (else hipMemcpyAsync)
     bool pipeline_calls = true;  // successive asynchronous calls rotate over the lanes
     unsigned lane_rr = 0;        // lane of the next chunk
     hipEvent_t tables_ready = nullptr;
@@ -597,6 +598,8 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
     } else if (!strcmp(key, "mf_permax")) {
         if (value != (int)value || value < 1.0 || value > 7.0) return fail(MPSFR_E_INVALID, "mf_permax must be 1..7");
         c->mf_permax = (int)value;
+    } else if (!strcmp(key, "param_copy")) {
+        c->param_copy_kernel = value != 0.0;
     } else if (!strcmp(key, "tier_eps")) {
         if (!(value >= 0.0)) return fail(MPSFR_E_INVALID, "tier_eps must be >= 0 (inf: tiers without a budget)");
         c->tier_eps = value;
@@ -1002,7 +1005,11 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     }
     c->wait_next = nullptr;
     sl.call_pending = false;
-    HIPCHK(hipMemcpyAsync(sl.params.p, hb, blob, hipMemcpyHostToDevice, s0));
+    // The blob travels as a KERNEL of the call's own queue that reads the pinned host memory: a
+    // hipMemcpyAsync of these ~20 KB is a hand-over to a copy engine and back, and sat at the head of every
+    // call ("param_copy" = 0 brings it back).
+    if (c->param_copy_kernel) launch_param_copy(s0, sl.params.p, hb, blob);
+    else HIPCHK(hipMemcpyAsync(sl.params.p, hb, blob, hipMemcpyHostToDevice, s0));
     HIPCHK(hipEventRecord(sl.staged, s0));
     sl.staged_pending = true;
     const char* db = (const char*)sl.params.p;
@@ -1345,14 +1352,14 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
                 launch_conv(ls, tc, nl, ln.pre.p, (const char*)sl.ktt.p + koff,
                             c->kmuse.p, (double*)d_fin, c->f64);
         }
-        if (fit_out) {
+        // per-lane partial stamp sums in chunk order; combined below in lane order (deterministic)
+        double* lsum = NL > 1 ? (double*)c->lsum.p + (size_t)j * nl * per_stamp : d_sum;
+        if (fit_out) {             // (with the chunk's stamp sum as the first workgroups of the same launch)
             ProfScope ps(c, K_FIT, ls);
-            launch_fit(ls, tc * nl, d_fin, fin_f32, d_fit_all + (size_t)t0 * nl * NFIT, c->f64);
-        }
-        if (psf_sum_out) {
-            // per-lane partial sums in chunk order; combined below in lane order (deterministic)
+            launch_fit(ls, tc * nl, d_fin, fin_f32, d_fit_all + (size_t)t0 * nl * NFIT, c->f64,
+                       psf_sum_out ? tc : 0, nl, psf_sum_out ? lsum : nullptr, nchunk_lane[j] > 0 ? 1 : 0);
+        } else if (psf_sum_out) {
             ProfScope ps(c, K_STAMP_SUM, ls);
-            double* lsum = NL > 1 ? (double*)c->lsum.p + (size_t)j * nl * per_stamp : d_sum;
             launch_stamp_sum(ls, tc, nl, d_fin, fin_f32, lsum, nchunk_lane[j] > 0 ? 1 : 0);
         }
         HIPCHK(hipGetLastError());

@@ -1053,6 +1053,12 @@ __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][
 template <typename RE>
 constexpr int fit_min_waves() { return sizeof(RE) == 4 ? MPSFR_FIT_WAVES : 2; }
 
+// the stamp sum riding in the fit's launch (nwg = 0: none)
+struct SumArgs {
+    int nwg, ntask, nl, accumulate;
+    double* sum;
+};
+
 // Stamps (= waves) per workgroup.  The waves of a workgroup share nothing, but a workgroup's slots are
 // released together: with four stamps per workgroup a slot waits for the slowest of four fits.
 #ifndef MPSFR_FIT_WG
@@ -1060,12 +1066,33 @@ constexpr int fit_min_waves() { return sizeof(RE) == 4 ? MPSFR_FIT_WAVES : 2; }
 #endif
 template <typename RE, typename TS>
 __global__ void __launch_bounds__(64 * MPSFR_FIT_WG) __attribute__((amdgpu_waves_per_eu(fit_min_waves<RE>())))
-k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit, double polish_tol) {
+k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit, double polish_tol, SumArgs sa) {
     constexpr int NPX = NS * NS / 64;                     // 25 pixels per lane
     static_assert(NPX * 64 == NS * NS, "the lane map assumes 1600 pixels");
     using S = RE;                                         // type of the LM state
     const int lane = threadIdx.x & 63;
-    const int st = blockIdx.x * MPSFR_FIT_WG + (threadIdx.x >> 6);
+    if ((int)blockIdx.x < sa.nwg) {
+        // The stamp sum of the chunk (K_STAMP_SUM's job: PSF_MEAN numerator, psfrec.py:1104) as the first
+        // workgroups of the fit's launch: it reads the same stamps, is independent of the fits, and as a
+        // launch of its own it was 5 us of a queue that runs one kernel at a time (one lane 12.13 -> 12.38 M
+        // PSFs/s).  A wave adds the tasks of 64 outputs in task order (eight loads in flight): deterministic.
+        const size_t per = (size_t)sa.nl * NS * NS;
+        const size_t e = ((size_t)blockIdx.x * MPSFR_FIT_WG + (threadIdx.x >> 6)) * 64 + lane;
+        if (e >= per) return;
+        double acc = 0.0;
+        int t = 0;
+        for (; t + 8 <= sa.ntask; t += 8) {
+            TS v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = stamps[(size_t)(t + k) * per + e];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += (double)v[k];
+        }
+        for (; t < sa.ntask; ++t) acc += (double)stamps[(size_t)t * per + e];
+        sa.sum[e] = sa.accumulate ? sa.sum[e] + acc : acc;
+        return;
+    }
+    const int st = ((int)blockIdx.x - sa.nwg) * MPSFR_FIT_WG + (threadIdx.x >> 6);
     if (st >= nstamp) return;                             // the whole wave exits together
     const TS* src = stamps + (size_t)st * NS * NS;
     // the stamp in the evaluation type, LDS-resident for the LM evaluations (25 fewer VGPRs than
@@ -1335,7 +1362,20 @@ __global__ void __launch_bounds__(256) k_stamp_sum(int ntask, int nl, const TF* 
     }
 }
 
+// K_PARAM_COPY: see launch_param_copy
+__global__ void __launch_bounds__(256) k_param_copy(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 }  // namespace
+
+void launch_param_copy(hipStream_t s, void* d_dst, const void* h_src_pinned, size_t bytes) {
+    const int n16 = (int)(bytes / 16);
+    if (n16 <= 0) return;
+    int nwg = (n16 + 255) / 256;
+    if (nwg > 16) nwg = 16;
+    hipLaunchKernelGGL(k_param_copy, dim3(nwg), dim3(256), 0, s, (uint4*)d_dst, (const uint4*)h_src_pinned, n16);
+}
 
 void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
                            void* d_out, bool f64) {
@@ -1403,14 +1443,19 @@ void launch_conv_fft(hipStream_t s, int ntask, int nl, const void* d_pre, const 
 }
 
 void launch_fit(hipStream_t s, int nstamp, const void* d_stamps, bool stamps_f32, double* d_fit,
-                bool f64) {
+                bool f64, int sum_ntask, int sum_nl, double* d_sum, int sum_accumulate) {
     if (nstamp <= 0) return;
+    SumArgs sa = {0, sum_ntask, sum_nl, sum_accumulate, d_sum};
+    if (d_sum != nullptr && sum_ntask > 0) {
+        const size_t per = (size_t)sum_nl * NS * NS;
+        sa.nwg = (int)((per + 64 * MPSFR_FIT_WG - 1) / (64 * MPSFR_FIT_WG));
+    }
     // One wavefront per stamp and one stamp per workgroup: the waves share nothing, and a workgroup of
     // four gave its slots back only when the slowest of its four fits was done (alone, bracketed:
     // 56.1 us with one stamp per workgroup, 57.9 with two, 58.0 with four).  (A whole workgroup per
     // stamp with the wave sums meeting in LDS measured 1.8x slower at 3500 stamps: every wave repeats
     // the 5x5 solves and the iterations serialise on barriers.)
-    const dim3 grid((nstamp + MPSFR_FIT_WG - 1) / MPSFR_FIT_WG), blk(64 * MPSFR_FIT_WG);
+    const dim3 grid(sa.nwg + (nstamp + MPSFR_FIT_WG - 1) / MPSFR_FIT_WG), blk(64 * MPSFR_FIT_WG);
     // f64 mode: the same float Levenberg-Marquardt iterations find the basin (they cost a third of
     // fp64 ones), and the polish on the fp64 stamps runs on until its steps are below 1e-8 (or
     // MPSFR_POLISH_MAX passes).  Only the residual of that pass is fp64: moffat_gradient rounds it to
@@ -1423,13 +1468,13 @@ void launch_fit(hipStream_t s, int nstamp, const void* d_stamps, bool stamps_f32
 #endif
     if (f64 && MPSFR_FIT_F64_LM)
         hipLaunchKernelGGL((k_fit<double, double>), grid, blk, 0, s, nstamp,
-                           (const double*)d_stamps, d_fit, 0.0);
+                           (const double*)d_stamps, d_fit, 0.0, sa);
     else if (stamps_f32)
         hipLaunchKernelGGL((k_fit<float, float>), grid, blk, 0, s, nstamp, (const float*)d_stamps,
-                           d_fit, (double)MPSFR_POLISH_TOL);
+                           d_fit, (double)MPSFR_POLISH_TOL, sa);
     else
         hipLaunchKernelGGL((k_fit<float, double>), grid, blk, 0, s, nstamp,
-                           (const double*)d_stamps, d_fit, f64 ? 1.0e-8 : (double)MPSFR_POLISH_TOL);
+                           (const double*)d_stamps, d_fit, f64 ? 1.0e-8 : (double)MPSFR_POLISH_TOL, sa);
 }
 
 void launch_stamp_sum(hipStream_t s, int ntask, int nl, const void* d_fin, bool fin_f32, double* d_sum,
