@@ -190,7 +190,7 @@ def e2e_sparta_leg(ncalls):
     """compute_psf_from_sparta (psfrec.py:981-1120) end to end on synthetic SPARTA tables held in memory: 1000 rows
     x 35 wavelengths on the 512^2 grid (configs[2] on one GPU) and 100 rows on the reference's own 1280^2 grid.
     A call = HDUList in -> HDUList out (row filter, tasks, the GPU batch, FIT_ROWS / FIT_MEAN / PSF_MEAN).
-    Median of `ncalls` calls after three warm ones; `value` is the 512^2 figure."""
+    Median of `ncalls` calls after ten warm ones; `value` is the 512^2 figure."""
     import muse_psfr_amd as M
     from muse_psfr_amd import _minifits as mf
     from muse_psfr_amd.psfrec import _astropy
@@ -208,7 +208,7 @@ def e2e_sparta_leg(ncalls):
         kw = dict(verbose=False, cutoff_masks='exact')
         if dim_ != 1280:
             kw.update(dim=dim_, pixscale=M.grid_pixscale(dim_), lmin=465, lmax=930)
-        for _ in range(3):
+        for _ in range(10):                  # (context, tables, and the GPU's clocks)
             res = M.compute_psf_from_sparta(mk(), **kw)
         ts = []
         for _ in range(ncall):
@@ -418,7 +418,9 @@ def main():
         # step): torch's stream waits for the context's stream (which is ordered after every call
         # made so far) before the exchange, and the call that next overwrites a buffer set waits
         # for the exchange that last read it (mpsfr_wait_event).
-        lib_streams = [torch.cuda.ExternalStream(c.stream_handle(), device=dev) for c in ctxs]
+        # (only a run with an exchange orders its own stream behind the library's: asking for the stream makes the
+        # library join its lanes into it on every call)
+        lib_streams = [torch.cuda.ExternalStream(c.stream_handle(), device=dev) for c in ctxs] if xchg else None
 
         def step():
             k = state['i'] % nctx

@@ -86,7 +86,9 @@ const char* mpsfr_last_error(void);
  * 2^-29 of OTF[0][0] are dropped, blocks below 2^-18 run without the low fp16 half of the OTF -- are applied,
  * per task and wavelength, only as far as the OTF mass each of them leaves out stays below tier_eps / 2 of a
  * lower bound of the PSF peak (the OTF summed exactly over its first four lines; two on grids above 512^2); where it would not, the
- * thresholds of that (task, wavelength) are lowered until it does.  0 = no tiers; inf = tiers without a budget).
+ * thresholds of that (task, wavelength) are lowered until it does; the kernel for several directions has the floor
+ * tier only and takes one floor per task, from the OTF of the task's shortest wavelength and the number of blocks.
+ * 0 = no tiers; inf = tiers without a budget).
  * WHAT THE TWO TOGETHER GUARANTEE, for every input: with eps = prune_eps + tier_eps no pixel of a stamp before
  * the convolutions (psf_muse, psfrec.py:644-686) moves by more than eps of that stamp's peak -- up to the
  * stamp's normalisation to unit sum (psfrec.py:685), which in the worst case (all 1600 pixels moved the same

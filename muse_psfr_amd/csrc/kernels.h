@@ -134,10 +134,13 @@ void launch_mf_tables(hipStream_t s, int N, int nl, const LamPar* d_lp, const vo
 void launch_mf_tel(hipStream_t s, int N, const void* d_tel, float* d_tl2, float* d_tlb);
 // d_vkeep / d_dminb: nullptr = no line / block pruning; thr: log2 of the block threshold;
 // d_order: dispatch order of the tasks (or nullptr)
+// K_PEAK_FLOOR: per-task floor of launch_otf_mfma's block rule under the tier budget (d_thrf [ntask])
+void launch_peak_floor(hipStream_t s, int N, int ntask, int ndir, const void* d_D0t, const float* d_tl2, float c2min,
+                       float tier_half, float floor_nominal, float* d_thrf);
 void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
                      const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,
                      const int* d_vkeep, const float* d_dminb, const float* d_tlb, float thr,
-                     void* d_pre, const int* d_order = nullptr, void* d_clk = nullptr);
+                     void* d_pre, const int* d_order = nullptr, void* d_clk = nullptr, const float* d_thrf = nullptr);
 // Second generation of the matrix-core stage (otf_mfma2.hip, one direction): block masks per
 // (task, wavelength) in two precision tiers, then the thin-wave kernel.  permax: wavelengths per
 // workgroup (7: 14 waves of 128 registers; 6: 12 waves of 168).

@@ -103,6 +103,7 @@ struct mpsfr_ctx {
         int ncu = 0;                     // CUs the lane's stream may use (0: all of them)
         DevBuf C, s00, D0t, Tq, pre, fin, dmin, dblk, vkeep, dminb, order, mown, muni, msched, mpart;
         DevBuf pP, pT, psp, dlin;        // series form of stage A: patch, its row transforms, its sum; line minima
+        DevBuf thrf;                     // [tasks] floor of the kernel for several directions (K_PEAK_FLOOR)
         // device outputs of its most recent calls: `done` is recorded behind every call of the lane,
         // so waiting for it covers all of them (a caller that rotates more buffer sets than lanes
         // must still get the calls that share a buffer in order)
@@ -115,6 +116,7 @@ struct mpsfr_ctx {
     int nlanes = 0;              // 0 = automatic (two lanes)
     int cu_partition = 0;        // 1: every lane's stream owns 1/lanes of the CUs (hipExtStreamCreateWithCUMask)
     bool param_copy_kernel = true;   // the parameter blob of a call is fetched by a kernel (else hipMemcpyAsync)
+    bool stream_exported = false;    // mpsfr_stream() has been called: every call joins its lanes into `stream`
     bool pipeline_calls = true;  // successive asynchronous calls rotate over the lanes
     unsigned lane_rr = 0;        // lane of the next chunk
     hipEvent_t tables_ready = nullptr;
@@ -189,6 +191,7 @@ struct mpsfr_ctx {
     int last_ndir = 0, last_nl = 0, last_chunk_tasks = 0, last_lane = 0;
     bool last_mf = false, last_pruned = false, last_mf2 = false;
     float last_thr_blk = 0.f;
+    bool last_floor_per_task = false;
     std::vector<double> last_lpc;        // c of every wavelength of the last call
     // profiling
     double prof_ms[K_COUNT] = {0};
@@ -523,7 +526,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
         if (ln.done) (void)hipEventDestroy(ln.done);
         DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.dmin, &ln.dblk, &ln.vkeep, &ln.dminb, &ln.order, &ln.mown, &ln.muni, &ln.msched, &ln.mpart,
-                         &ln.pP, &ln.pT, &ln.psp, &ln.dlin};
+                         &ln.pP, &ln.pT, &ln.psp, &ln.dlin, &ln.thrf};
         for (auto b : lb) release(*b);
     }
     for (int k = 0; k < mpsfr_ctx::NSTAGE; ++k) {
@@ -988,9 +991,11 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     const void* outs[3] = {dev_out ? (const void*)psf_out : nullptr,
                            dev_out ? (const void*)psf_sum_out : nullptr,
                            dev_out ? (const void*)fit_out : nullptr};
+    // (the call that used this slot NSTAGE calls ago has usually finished: then no lane waits for it)
+    const bool slot_done = sl.call_pending && hipEventQuery(sl.call_done) == hipSuccess;
     for (int j = 0; j < NL; ++j) {
         hipStream_t ls = lane_of(j).stream;
-        if (sl.call_pending) HIPCHK(hipStreamWaitEvent(ls, sl.call_done, 0));
+        if (sl.call_pending && !slot_done) HIPCHK(hipStreamWaitEvent(ls, sl.call_done, 0));
         if (c->wait_next) HIPCHK(hipStreamWaitEvent(ls, c->wait_next, 0));
         if (c->lsum_busy && NL > 1) HIPCHK(hipStreamWaitEvent(ls, c->lsum_done, 0));
         for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k) {
@@ -1091,7 +1096,10 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         HIPCHK(hipEventRecord(c->cache_ready, s0));
         c->cache_ready_valid = true;
     } else if (c->cache_ready_valid) {
-        HIPCHK(hipStreamWaitEvent(s0, c->cache_ready, 0));
+        // (once the tables are known to be complete no call has to wait for them any more: a wait on a
+        // finished event is still a barrier packet at the head of the call's queue)
+        if (hipEventQuery(c->cache_ready) == hipSuccess) c->cache_ready_valid = false;
+        else HIPCHK(hipStreamWaitEvent(s0, c->cache_ready, 0));
     }
     {   // Tip-tilt kernels of this call's tasks (psfrec.py:879-917).  (Measured: moving this small
         // launch to a side stream, off the head of the call's chain, and folding the DC sum into
@@ -1121,18 +1129,18 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     // budget: per (task, wavelength) the OTF mass each tier leaves out -- an upper bound from the block bounds --
     // stays below tier_eps / 2 of a lower bound of the PSF peak; K_MF_PREP lowers the thresholds where it
     // would not.  The kernel for several directions (otf_mfma.hip) has no such pass: its floor is the
-    // threshold that keeps the mass below tier_eps / 2 of OTF[0][0] <= the peak whatever the input.
+    // per-task floor from K_PEAK_FLOOR (the same budget against the OTF of the shortest wavelength, blocks counted).
     const float thr_eps = thr_blk;
     float thr_floor = -1.0e30f;
     const bool tiers = prune && mf && c->tier_eps > 0.0;
+    // (the kernel for several directions takes a per-task floor under the same budget from K_PEAK_FLOOR)
+    const bool floor_per_task = tiers && c->mf_floor && !mf2 && std::isfinite(c->tier_eps);
     if (tiers && c->mf_floor) {
         thr_floor = (float)c->mf_floor_log2;
-        if (!mf2) {
-            const float uni = (float)std::log2(0.5 * c->tier_eps / (2.0 * ndir * 16 * 32 * mf_block_count(N)));
-            if (thr_floor > uni) thr_floor = uni;
-        }
-        if (thr_blk < thr_floor) thr_blk = thr_floor;       // (what the kernel for several directions drops)
+        if (!mf2 && !floor_per_task && thr_blk < thr_floor) thr_blk = thr_floor;     // tier_eps = inf: the plain floor
     }
+    float c2min = 0.f;             // log2-scaled exponent factor of the shortest wavelength (the most negative)
+    for (int l = 0; l < nl; ++l) c2min = std::fmin(c2min, (float)(lp[l].c * 1.44269504088896340736));
     const float thr_mid = (tiers && c->mf_floor) ? (float)c->mf_mid_log2 : -1.0e30f;
     const float tier_half = std::isfinite(c->tier_eps) ? (float)(0.5 * c->tier_eps) : 0.f;
     for (int j = 0; j < NL; ++j) {
@@ -1169,6 +1177,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             if ((rc = ensure(c, ln.dblk, (size_t)ndir * mf_dminb_bytes(N, TC)))) return rc;
             if (mf && (rc = ensure(c, ln.dminb, mf_dminb_bytes(N, TC)))) return rc;
             if (mf && (rc = ensure(c, ln.order, (size_t)TC * sizeof(int)))) return rc;
+            if (mf && (rc = ensure(c, ln.thrf, (size_t)TC * sizeof(float)))) return rc;
             if ((rc = ensure(c, ln.vkeep, (size_t)TC * ((nl + 1) / 2) * sizeof(int)))) return rc;
         }
     }
@@ -1306,10 +1315,14 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
                              c->mf_clock ? c->mfclk.p : nullptr);
         } else if (mf) {
             ProfScope ps(c, K_OTF_MFMA, ls);
+            if (floor_per_task)
+                launch_peak_floor(ls, N, tc, ndir, ln.D0t.p, (const float*)c->tl2.p, c2min, tier_half, thr_floor,
+                                  (float*)ln.thrf.p);
             launch_otf_mfma(ls, N, tc, ndir, nl, ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
                             c->gtab.p, d_vkeep, prune ? (const float*)ln.dminb.p : nullptr,
                             (const float*)c->tlb.p, thr_blk, ln.pre.p,
-                            prune ? (const int*)ln.order.p : nullptr, c->mf_clock ? c->mfclk.p : nullptr);
+                            prune ? (const int*)ln.order.p : nullptr, c->mf_clock ? c->mfclk.p : nullptr,
+                            floor_per_task ? (const float*)ln.thrf.p : nullptr);
         } else {
             {
                 ProfScope ps(c, K_OTF_ROWFFT, ls);
@@ -1372,15 +1385,20 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         c->last_chunk_tasks = tc;
         c->last_lane = (L0 + j) % NLmax;
     }
-    // join: everything queued on the lanes becomes a dependency of the context's stream
+    // join: everything queued on the lanes becomes a dependency of the context's stream -- if anybody uses that
+    // stream: a caller that asked for it (mpsfr_stream), the copies of host outputs, the sum over several lanes.
+    // A device-output call on one lane of a context whose stream was never asked for stays on its lane: this GPU
+    // runs two active queues well and a third one at a loss (profiles/r05_experiments.md), and the join was a
+    // barrier and a signal on a third queue per call.
     hipStream_t s = c->stream;
+    const bool join = c->stream_exported || tk != nullptr || !dev_out || NL > 1 || !c->pipeline_calls;
     for (int j = 0; j < NL; ++j) {
         mpsfr_ctx::Lane& ln = lane_of(j);
         HIPCHK(hipEventRecord(ln.done, ln.stream));
         ln.busy = true;
         for (int a = 0; a < 3; ++a) ln.outs[ln.nouts % mpsfr_ctx::Lane::NHIST][a] = outs[a];
         ln.nouts += 1;
-        HIPCHK(hipStreamWaitEvent(s, ln.done, 0));
+        if (join) HIPCHK(hipStreamWaitEvent(s, ln.done, 0));
     }
     if (psf_sum_out && NL > 1) {       // add the per-lane sums in lane order
         {
@@ -1391,7 +1409,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         HIPCHK(hipEventRecord(c->lsum_done, s));
         c->lsum_busy = true;
     }
-    HIPCHK(hipEventRecord(sl.call_done, s));
+    HIPCHK(hipEventRecord(sl.call_done, join ? s : lane_of(0).stream));
     sl.call_pending = true;
     c->last_ndir = ndir;
     c->last_nl = nl;
@@ -1399,6 +1417,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     c->last_mf2 = mf2;
     c->last_pruned = prune;
     c->last_thr_blk = thr_blk;
+    c->last_floor_per_task = floor_per_task;
     c->last_lpc.resize(nl);
     for (int l = 0; l < nl; ++l) c->last_lpc[l] = lp[l].c;
     if (tk) {
@@ -1681,15 +1700,19 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
             }
             steps = steps_full + steps_mid;
         } else {
+        std::vector<float> thrf((size_t)tc, -1.0e30f);
+        if (c->last_pruned && c->last_floor_per_task)
+            HIPCHK(hipMemcpy(thrf.data(), ln.thrf.p, thrf.size() * sizeof(float), hipMemcpyDeviceToHost));
         for (int t = 0; t < tc; ++t)
             for (int l = 0; l < nl; ++l) {
                 const float c2 = (float)c->last_lpc[l] * 1.44269504088896340736f;
+                const float thr_t = std::fmax(c->last_thr_blk, thrf[t]);
                 const int nv = c->last_pruned ? vk[(size_t)t * npair + (l >> 1)] : H1;
                 for (int mt = 0; mt < (nv + 15) / 16; ++mt) {
                     int n = 0;
                     for (int ks = 0; ks < nks; ++ks)
                         n += !c->last_pruned ||
-                             std::fmaf(c2, dm[((size_t)t * nmt + mt) * nks + ks], tb[mt * nks + ks]) > c->last_thr_blk;
+                             std::fmaf(c2, dm[((size_t)t * nmt + mt) * nks + ks], tb[mt * nks + ks]) > thr_t;
                     steps += n;
                     tiles += n > 0;
                 }
@@ -1735,7 +1758,17 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
     return (long)n;
 }
 
-void* mpsfr_stream(mpsfr_ctx* c) { return c ? (void*)c->stream : nullptr; }
+void* mpsfr_stream(mpsfr_ctx* c) {
+    if (!c) return nullptr;
+    if (!c->stream_exported) {
+        // from now on every call joins its lanes into the stream; what is already queued joins here
+        c->stream_exported = true;
+        (void)hipSetDevice(c->device);
+        for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
+            if (c->lane[k].busy) (void)hipStreamWaitEvent(c->stream, c->lane[k].done, 0);
+    }
+    return (void*)c->stream;
+}
 
 int mpsfr_profile_count(void) { return K_COUNT; }
 

@@ -162,7 +162,8 @@ struct MfArgs {
     const int* vkeep;        // [ntask][(nl+1)/2] or nullptr
     const float* dminb;      // [ntask][nmt][nks] or nullptr
     const float* tlb;        // [nmt][nks]
-    float thr;               // log2 of the block threshold
+    float thr;               // log2 of the block threshold (the eps rule)
+    const float* thrf;       // [ntask] floor of the task (K_PEAK_FLOOR: the precision tier under its budget), or nullptr
     float tq_scale;          // 2^-ceil(log2 N): first-pass sums back into the fp16 range
     float* pre;              // [ntask][nl][40][40]
     const int* order;        // [ntask] dispatch order of the tasks, or nullptr
@@ -284,6 +285,7 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
     // the last m-tile read the zeroed padding behind D (log2 tel = -inf there).
     const unsigned voff = (unsigned)(((size_t)lr * N + 8 * lk) * sizeof(float)), voff16 = voff + 16;
     const unsigned voffb = (unsigned)lane * 16;
+    const float thr_t = a.thrf != nullptr ? fmaxf(a.thr, a.thrf[task]) : a.thr;
     const char* dtask = reinterpret_cast<const char*>(a.D0t + (size_t)task * ndir * H1 * N);
     const size_t dstride = (size_t)H1 * N * sizeof(float);       // one direction of D
     float dirshift = 0.f;                      // several directions: their sum <= 2^dirshift
@@ -313,8 +315,8 @@ k_otf_mfma1(const MfArgs a, int per, int ngr, int tpg) {
             const int mt = g0 + g;
             bool ou = g < tpg && mt < nmtu && lane < nks, oo = g < tpg && mt < nmt && lane < nks;
             if (a.dminb != nullptr) {
-                ou = ou && fmaf(c2u, dm[g], tb[g]) > a.thr;
-                oo = oo && fmaf(c2, dm[g], tb[g]) > a.thr;
+                ou = ou && fmaf(c2u, dm[g], tb[g]) > thr_t;
+                oo = oo && fmaf(c2, dm[g], tb[g]) > thr_t;
             }
             uni[g] = __ballot(ou);
             own[g] = __ballot(oo) & uni[g];
@@ -572,6 +574,43 @@ void launch_mf_tables(hipStream_t s, int N, int nl, const LamPar* d_lp, const vo
                        (const cx<double>*)d_tw64, (h8*)d_E, (h4*)d_G);
 }
 
+// K_PEAK_FLOOR: the floor tier of the kernel for several directions under its budget.  Per task:
+// S = the OTF of the SHORTEST wavelength (the smallest) summed exactly over the first `nlines` lines of the half
+// plane and over the directions -- a lower bound of the PSF peak of every wavelength of the task -- and
+//   thrf[task] = min(floor, log2(tier_half S / (2 x 512 x ndir x blocks))):
+// every element of a dropped block is below 2^thrf in every direction, so all dropped blocks together weigh less than
+// tier_half of S.  (One threshold per task, counted not summed: coarser than K_MF_PREP's per-wavelength masses.)
+__global__ void __launch_bounds__(256) k_peak_floor(int N, int ndir, int nlines, const float* __restrict__ D0t,
+                                                    const float* __restrict__ tl2, float c2min, float tier_half,
+                                                    float floor_nominal, int nblocks, float* __restrict__ thrf) {
+    __shared__ float part[4];
+    const int task = blockIdx.x, H1 = N / 2 + 1;
+    float s = 0.f;
+    const int per = nlines * N, tot = per * ndir;          // (direction, element) pairs: independent loads
+    const float* dt = D0t + (size_t)task * ndir * H1 * N;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < tot; i += 256) {
+        const int d = i / per, e = i - d * per;
+        const float x = __builtin_amdgcn_exp2f(fmaf(c2min, fmaxf(dt[(size_t)d * H1 * N + e], 0.f), tl2[e]));
+        s += e < N ? x : 2.f * x;             // line 0 once, the others stand for both half planes
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float S = ((part[0] + part[1]) + (part[2] + part[3])) * __builtin_amdgcn_exp2f(-kShift);   // (tl2 carries 2^kShift)
+        const float lim = __builtin_amdgcn_logf(tier_half * S / (1024.f * (float)ndir * (float)nblocks));
+        thrf[task] = fminf(floor_nominal, lim);
+    }
+}
+
+void launch_peak_floor(hipStream_t s, int N, int ntask, int ndir, const void* d_D0t, const float* d_tl2, float c2min,
+                       float tier_half, float floor_nominal, float* d_thrf) {
+    hipLaunchKernelGGL(k_peak_floor, dim3(ntask), dim3(256), 0, s, N, ndir, N > 512 ? 2 : 4, (const float*)d_D0t, d_tl2,
+                       c2min, tier_half, floor_nominal, mf_nmt(N) * mf_nks(N), d_thrf);
+}
+
 void launch_mf_tel(hipStream_t s, int N, const void* d_tel, float* d_tl2, float* d_tlb) {
     hipLaunchKernelGGL(k_mf_tel, dim3(mf_nmt(N)), dim3(256), 0, s, N, (const float*)d_tel, d_tl2, d_tlb);
 }
@@ -579,8 +618,9 @@ void launch_mf_tel(hipStream_t s, int N, const void* d_tel, float* d_tl2, float*
 void launch_otf_mfma(hipStream_t s, int N, int ntask, int ndir, int nl, const void* d_D0t,
                      const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,
                      const int* d_vkeep, const float* d_dminb, const float* d_tlb, float thr,
-                     void* d_pre, const int* d_order, void* d_clk) {
+                     void* d_pre, const int* d_order, void* d_clk, const float* d_thrf) {
     MfArgs a;
+    a.thrf = d_thrf;
     a.N = N; a.ntask = ntask; a.ndir = ndir; a.nl = nl;
     a.D0t = (const float*)d_D0t; a.tl2 = d_tl2; a.lp = d_lp;
     a.E = (const h8*)d_E; a.G = (const h4*)d_G;

@@ -1053,6 +1053,9 @@ __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][
 template <typename RE>
 constexpr int fit_min_waves() { return sizeof(RE) == 4 ? MPSFR_FIT_WAVES : 2; }
 
+#ifndef MPSFR_FIT_MOMENT_START
+#define MPSFR_FIT_MOMENT_START 1
+#endif
 // the stamp sum riding in the fit's launch (nwg = 0: none)
 struct SumArgs {
     int nwg, ntask, nl, accumulate;
@@ -1161,7 +1164,7 @@ k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit, doubl
     double fw0 = 2.0 * sqrt((double)cnt / kPi);
     fw0 = fmin(fmax(fw0, 1.5), (double)NS);
     float eta0 = 0.4f;
-    if (rm >= 6 && ms1 > 0.f && (float)best > 0.f) {
+    if (MPSFR_FIT_MOMENT_START && rm >= 6 && ms1 > 0.f && (float)best > 0.f) {
         const float bf = (float)best, r2 = ((float)rm + 0.5f) * ((float)rm + 0.5f);
         float t1 = 1.f, t2 = 1.f, nn = 2.5f, a2 = 1.f;
 #pragma unroll 1

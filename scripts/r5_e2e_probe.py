@@ -63,4 +63,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(10):
     M.compute_psf_from_sparta(mk(), **kw)
 pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(22); print(s.getvalue()[:5000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(45); print(s.getvalue()[:9000])
