@@ -3,6 +3,7 @@ declares (no compute calls -- there is no GPU here)."""
 import os
 import re
 
+import numpy as np
 import pytest
 
 from conftest import ROOT
@@ -89,3 +90,24 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert 'created' in r.stdout or 'rc=-' in r.stdout
+
+
+def test_fit_rows_helper_is_the_numpy_formula():
+    """mpsfr_fit_rows (pure host C, no GPU): the 14 fit columns of FIT_ROWS (psfrec.py:866-870) from library fit rows,
+    against the NumPy column builder of the drop-in package, bit for bit, written into records with a stride."""
+    from muse_psfr_amd import _lib
+    from muse_psfr_amd.psfrec import _fit_columns
+    rng = np.random.default_rng(5)
+    n = 37
+    fit = rng.uniform(0.5, 3.0, (n, _lib.NFIT))
+    fit[3, 4] = 1.0                               # n = 1: the flux error divides by n - 1
+    fit[5, 0] = 0.0                               # peak = 0
+    out = np.full((n, 20), -1.0)
+    with np.errstate(all='ignore'):
+        _lib.fit_rows(fit, 0.2, out[:, 1:15])
+        cols = _fit_columns(np.zeros(n), fit, 0.2)
+    want = np.column_stack([cols['center'], cols['flux'], cols['fwhm'], cols['n'], cols['peak'], cols['err_center'],
+                            cols['err_flux'], cols['err_fwhm'], cols['err_n'], cols['err_peak']])
+    assert want.shape == (n, 14)
+    np.testing.assert_array_equal(out[:, 1:15], want)
+    assert np.all(out[:, 0] == -1.0) and np.all(out[:, 15:] == -1.0)        # nothing outside the 14 columns

@@ -291,14 +291,22 @@ def test_pipeline_lanes_and_kernel_variants_agree(api):
     res = {}
     for key, opts in (('base', {'streams': 2}), ('one_lane', {'streams': 1}), ('auto', {}),
                       ('direct_conv', {'fft_conv': 0}),
-                      ('expf', {'fast_exp': 0})):
+                      ('expf', {'fast_exp': 0}),
+                      ('cu_masks', {'streams': 2, 'cu_partition': 1}),       # lanes on CU-masked streams
+                      ('memcpy_params', {'param_copy': 0})):                 # the parameter blob by hipMemcpyAsync
         ctx = api.Context(dim=128, pixscale=ps, precision='mixed')
         for k, v in opts.items():
             ctx.set_option(k, v)
         res[key] = ctx.reconstruct(lb, see, gl, l0, three, H)      # 2240 stamps: split over 2 lanes
+        if key == 'cu_masks':
+            ctx.set_option('cu_partition', 0)                      # (the lanes' streams are created anew)
+            again = ctx.reconstruct(lb, see, gl, l0, three, H)
+            assert np.array_equal(again['fit'], res[key]['fit'])
         ctx.close()
     a, b = res['base'], res['one_lane']
     assert np.array_equal(a['psf'], b['psf']) and np.array_equal(a['fit'], b['fit'])
+    for key in ('cu_masks', 'memcpy_params'):                      # where and how the work is queued changes no bit
+        assert np.array_equal(res[key]['psf'], a['psf']) and np.array_equal(res[key]['fit'], a['fit']), key
     assert np.array_equal(res['auto']['fit'], b['fit'])      # one chunk: automatic = one lane
     np.testing.assert_allclose(a['psf_sum'], b['psf_sum'], rtol=1e-13)
     for key in ('direct_conv', 'expf'):
