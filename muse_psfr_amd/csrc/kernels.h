@@ -163,7 +163,7 @@ void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const L
 void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int ncu, const void* d_D0t,
                       const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,
                       const void* d_own, const void* d_uni, void* d_sched, void* d_part, void* d_pre,
-                      void* d_clk = nullptr);
+                      void* d_clk = nullptr, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void* d_tw64,
                    int* d_samp_p, void* d_samp_a, void* d_G, bool f64);
 void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,

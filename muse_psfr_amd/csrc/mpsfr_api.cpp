@@ -98,8 +98,10 @@ struct mpsfr_ctx {
     // `stream` is only the join stream: it waits for the lanes at the end of every call.
     struct Lane {
         hipStream_t stream = nullptr;
-        hipEvent_t done = nullptr;       // after the lane's last chunk of the most recent call
-        bool busy = false;               // `done` has been recorded
+        hipEvent_t done = nullptr;       // after the lane's last chunk of the most recent call (calls that join)
+        hipEvent_t done_ev = nullptr;    // the event that marks the end of the lane's most recent call: `done`, or
+                                         // the slot event of a call that queued a single marker (see "lean" below)
+        bool busy = false;               // `done_ev` has been recorded
         int ncu = 0;                     // CUs the lane's stream may use (0: all of them)
         DevBuf C, s00, D0t, Tq, pre, fin, dmin, dblk, vkeep, dminb, order, mown, muni, msched, mpart;
         DevBuf pP, pT, psp, dlin;        // series form of stage A: patch, its row transforms, its sum; line minima
@@ -140,9 +142,11 @@ struct mpsfr_ctx {
         void* host = nullptr;
         size_t host_cap = 0;
         hipEvent_t staged = nullptr;     // after the H2D copy (the pinned blob may be refilled)
+        hipEvent_t staged_ev = nullptr;  // what the host waits for before it refills the blob: `staged` or `call_done`
         bool staged_pending = false;
-        hipEvent_t call_done = nullptr;  // on the join stream, after the call that used the slot
+        hipEvent_t call_done = nullptr;  // after the call that used the slot (join stream, or the call's lane)
         bool call_pending = false;
+        int last_lane = -1;              // lane of a single-marker call (stream order covers the slot's reuse there)
         DevBuf params, ktt;
     };
     Slot slot[NSTAGE];
@@ -258,8 +262,9 @@ struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t st;
     bool on = false;
-    ProfScope(mpsfr_ctx* ctx, int kid, hipStream_t stream = nullptr)
-        : c(ctx), id(kid), st(stream ? stream : ctx->stream) {
+    bool markers;              // false: the launch itself carries the events (hipExtLaunchKernelGGL)
+    ProfScope(mpsfr_ctx* ctx, int kid, hipStream_t stream = nullptr, bool use_markers = true)
+        : c(ctx), id(kid), st(stream ? stream : ctx->stream), markers(use_markers) {
         on = c->profile && (c->prof_only < 0 || c->prof_only == kid);
         if (on) {
             a = get_event(c);
@@ -267,15 +272,16 @@ struct ProfScope {
             if (!a || !b) {          // out of events: this launch goes untimed
                 if (a) c->pool.push_back(a);
                 if (b) c->pool.push_back(b);
+                a = b = nullptr;
                 on = false;
-            } else {
+            } else if (markers) {
                 (void)hipEventRecord(a, st);
             }
         }
     }
     ~ProfScope() {
         if (on) {
-            (void)hipEventRecord(b, st);
+            if (markers) (void)hipEventRecord(b, st);
             c->pending.push_back({id, a, b});
             // a caller that never reads the profile must not grow the event list without bound
             if (c->pending.size() >= 8192) (void)resolve_profile(c);
@@ -900,6 +906,12 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     // unwritten, and the final sum over lanes would read stale memory
     const int NL = NLmax < nchunks ? NLmax : nchunks;
     const bool dev_out = on_device != 0;
+    // join: everything queued on the lanes becomes a dependency of the context's stream -- if anybody uses that
+    // stream: a caller that asked for it (mpsfr_stream), the copies of host outputs, the sum over several lanes.
+    // A device-output call on one lane of a context whose stream was never asked for stays on its lane: this GPU
+    // runs two active queues well and a third one at a loss (profiles/r05_experiments.md).
+    const bool join = c->stream_exported || tk != nullptr || !dev_out || NL > 1 || !c->pipeline_calls;
+    const bool lean = !join;
     if (!(c->pipeline_calls && dev_out)) c->lane_rr = 0;       // synchronous calls: nothing to overlap
     const int L0 = (int)(c->lane_rr % (unsigned)NLmax);
     c->lane_rr += (unsigned)nchunks;
@@ -939,7 +951,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     if (stagger && NLmax > 1) {
         cold_first = true;
         for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
-            if (c->lane[k].busy && hipEventQuery(c->lane[k].done) != hipSuccess) cold_first = false;
+            if (c->lane[k].busy && hipEventQuery(c->lane[k].done_ev) != hipSuccess) cold_first = false;
         if (!c->stagger_ev) HIPCHK(hipEventCreateWithFlags(&c->stagger_ev, hipEventDisableTiming));
     }
 
@@ -956,7 +968,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     double t_blocked = 0.0;
     if (sl.staged_pending) {        // the copy that last used the pinned blob must have left it
         const auto tb = std::chrono::steady_clock::now();
-        HIPCHK(hipEventSynchronize(sl.staged));      // only blocks once the host is NSTAGE calls ahead
+        HIPCHK(hipEventSynchronize(sl.staged_ev));   // only blocks once the host is NSTAGE calls ahead
         t_blocked = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count();
         sl.staged_pending = false;
     }
@@ -995,7 +1007,9 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     const bool slot_done = sl.call_pending && hipEventQuery(sl.call_done) == hipSuccess;
     for (int j = 0; j < NL; ++j) {
         hipStream_t ls = lane_of(j).stream;
-        if (sl.call_pending && !slot_done) HIPCHK(hipStreamWaitEvent(ls, sl.call_done, 0));
+        // (a single-marker call recorded the slot's event on its own lane: on that lane stream order suffices)
+        if (sl.call_pending && !slot_done && sl.last_lane != (int)(&lane_of(j) - c->lane))
+            HIPCHK(hipStreamWaitEvent(ls, sl.call_done, 0));
         if (c->wait_next) HIPCHK(hipStreamWaitEvent(ls, c->wait_next, 0));
         if (c->lsum_busy && NL > 1) HIPCHK(hipStreamWaitEvent(ls, c->lsum_done, 0));
         for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k) {
@@ -1005,7 +1019,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             for (int hsl = 0; hsl < mpsfr_ctx::Lane::NHIST; ++hsl)
                 for (int a = 0; a < 3; ++a)
                     for (int b = 0; b < 3; ++b) same = same || (outs[a] && outs[a] == o.outs[hsl][b]);
-            if (same) HIPCHK(hipStreamWaitEvent(ls, o.done, 0));
+            if (same) HIPCHK(hipStreamWaitEvent(ls, o.done_ev, 0));
         }
     }
     c->wait_next = nullptr;
@@ -1015,7 +1029,16 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     // call ("param_copy" = 0 brings it back).
     if (c->param_copy_kernel) launch_param_copy(s0, sl.params.p, hb, blob);
     else HIPCHK(hipMemcpyAsync(sl.params.p, hb, blob, hipMemcpyHostToDevice, s0));
-    HIPCHK(hipEventRecord(sl.staged, s0));
+    // "lean" calls -- device outputs on one lane of a context whose stream nobody uses -- queue ONE marker: the
+    // slot's event at the end of the lane's chain is the end of the call for the slot, for the lane and for the
+    // pinned blob.  A marker is a packet the queue stops at (~7 us in the kernel trace: the three of a call --
+    // behind the parameter copy, the lane's, the slot's -- were a tenth of a 100-row call).
+    if (lean) {
+        sl.staged_ev = sl.call_done;
+    } else {
+        HIPCHK(hipEventRecord(sl.staged, s0));
+        sl.staged_ev = sl.staged;
+    }
     sl.staged_pending = true;
     const char* db = (const char*)sl.params.p;
     const LamPar* d_lp = (const LamPar*)(db + o_lp);
@@ -1063,7 +1086,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     if (!ao_cached || !lam_cached) {
         for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
             if (c->lane[k].busy && c->lane[k].stream != s0)
-                HIPCHK(hipStreamWaitEvent(s0, c->lane[k].done, 0));
+                HIPCHK(hipStreamWaitEvent(s0, c->lane[k].done_ev, 0));
         if (!ao_cached) {
             ProfScope ps(c, K_AO_TABLES, s0);
             launch_ao_tables(s0, g, d_mrec, d_mres, (double*)c->aotab.p);
@@ -1309,10 +1332,12 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         if (io.pre_in) {
             // (nothing)
         } else if (mf2) {
-            ProfScope ps(c, K_OTF_MFMA, ls);
+            // (timed through the dispatch packet of K_OTF_MFMA2 itself: the persistent kernel alone, without
+            // K_MF_FINISH and without marker packets round it)
+            ProfScope ps(c, K_OTF_MFMA, ls, false);
             launch_otf_mfma2(ls, N, tc, nl, c->mf_permax, ln.ncu ? ln.ncu : c->ncu, ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
                              c->gtab.p, ln.mown.p, ln.muni.p, ln.msched.p, ln.mpart.p, ln.pre.p,
-                             c->mf_clock ? c->mfclk.p : nullptr);
+                             c->mf_clock ? c->mfclk.p : nullptr, ps.a, ps.b);
         } else if (mf) {
             ProfScope ps(c, K_OTF_MFMA, ls);
             if (floor_per_task)
@@ -1385,20 +1410,20 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         c->last_chunk_tasks = tc;
         c->last_lane = (L0 + j) % NLmax;
     }
-    // join: everything queued on the lanes becomes a dependency of the context's stream -- if anybody uses that
-    // stream: a caller that asked for it (mpsfr_stream), the copies of host outputs, the sum over several lanes.
-    // A device-output call on one lane of a context whose stream was never asked for stays on its lane: this GPU
-    // runs two active queues well and a third one at a loss (profiles/r05_experiments.md), and the join was a
-    // barrier and a signal on a third queue per call.
     hipStream_t s = c->stream;
-    const bool join = c->stream_exported || tk != nullptr || !dev_out || NL > 1 || !c->pipeline_calls;
     for (int j = 0; j < NL; ++j) {
         mpsfr_ctx::Lane& ln = lane_of(j);
-        HIPCHK(hipEventRecord(ln.done, ln.stream));
+        if (lean) {
+            HIPCHK(hipEventRecord(sl.call_done, ln.stream));
+            ln.done_ev = sl.call_done;
+        } else {
+            HIPCHK(hipEventRecord(ln.done, ln.stream));
+            ln.done_ev = ln.done;
+            HIPCHK(hipStreamWaitEvent(s, ln.done, 0));
+        }
         ln.busy = true;
         for (int a = 0; a < 3; ++a) ln.outs[ln.nouts % mpsfr_ctx::Lane::NHIST][a] = outs[a];
         ln.nouts += 1;
-        if (join) HIPCHK(hipStreamWaitEvent(s, ln.done, 0));
     }
     if (psf_sum_out && NL > 1) {       // add the per-lane sums in lane order
         {
@@ -1409,8 +1434,9 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         HIPCHK(hipEventRecord(c->lsum_done, s));
         c->lsum_busy = true;
     }
-    HIPCHK(hipEventRecord(sl.call_done, join ? s : lane_of(0).stream));
+    if (!lean) HIPCHK(hipEventRecord(sl.call_done, s));
     sl.call_pending = true;
+    sl.last_lane = lean ? (int)(&lane_of(0) - c->lane) : -1;
     c->last_ndir = ndir;
     c->last_nl = nl;
     c->last_mf = mf;
@@ -1765,7 +1791,7 @@ void* mpsfr_stream(mpsfr_ctx* c) {
         c->stream_exported = true;
         (void)hipSetDevice(c->device);
         for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
-            if (c->lane[k].busy) (void)hipStreamWaitEvent(c->stream, c->lane[k].done, 0);
+            if (c->lane[k].busy) (void)hipStreamWaitEvent(c->stream, c->lane[k].done_ev, 0);
     }
     return (void*)c->stream;
 }

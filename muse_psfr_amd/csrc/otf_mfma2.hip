@@ -43,6 +43,7 @@
 //    need no K_MF_FINISH and balance so much worse that the launch is 20 % longer: DESIGN.md.)
 //  * The queue runs a little ahead: the next item's number is drawn during the last k-step, its
 //    descriptor and masks are loaded behind the second pass and the epilogue.
+#include <hip/hip_ext.h>
 #include "mf_common.h"
 
 namespace mpsfr {
@@ -813,7 +814,7 @@ void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const L
 void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int ncu, const void* d_D0t,
                       const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,
                       const void* d_own, const void* d_uni, void* d_sched, void* d_part, void* d_pre,
-                      void* d_clk) {
+                      void* d_clk, hipEvent_t ev_start, hipEvent_t ev_stop) {
     Mf2Args a;
     a.N = N; a.ntask = ntask; a.nl = nl;
     mf2_groups(nl, permax, &a.per, &a.ngr);
@@ -835,12 +836,20 @@ void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int n
     const int maxitems = ntask * a.ngr * (int)mf2_nsw(N);
     const int nwg = ncu < maxitems ? ncu : maxitems;
     const size_t sm = 2 * (size_t)kStage2 + 2 * (size_t)a.per * kSlab + 64;     // + the queue word
+    // (ev_start / ev_stop: the kernel's own start and end time stamps through the dispatch packet -- no marker
+    // packets before and behind it, which cost the queue ~7 us each)
     if (permax > 6) {
         allow_smem(k_otf_mfma2<4>, 2 * (size_t)kStage2 + 2 * (size_t)7 * kSlab + 64);
-        hipLaunchKernelGGL(k_otf_mfma2<4>, dim3(nwg), dim3(128 * a.per), sm, s, a);
+        if (ev_start != nullptr)
+            hipExtLaunchKernelGGL(k_otf_mfma2<4>, dim3(nwg), dim3(128 * a.per), (unsigned)sm, s, ev_start, ev_stop, 0, a);
+        else
+            hipLaunchKernelGGL(k_otf_mfma2<4>, dim3(nwg), dim3(128 * a.per), sm, s, a);
     } else {
         allow_smem(k_otf_mfma2<3>, 2 * (size_t)kStage2 + 2 * (size_t)6 * kSlab + 64);
-        hipLaunchKernelGGL(k_otf_mfma2<3>, dim3(nwg), dim3(128 * a.per), sm, s, a);
+        if (ev_start != nullptr)
+            hipExtLaunchKernelGGL(k_otf_mfma2<3>, dim3(nwg), dim3(128 * a.per), (unsigned)sm, s, ev_start, ev_stop, 0, a);
+        else
+            hipLaunchKernelGGL(k_otf_mfma2<3>, dim3(nwg), dim3(128 * a.per), sm, s, a);
     }
     hipLaunchKernelGGL(k_mf_finish, dim3(nl, ntask), dim3(64), 0, s, N, nl, a.per, a.ngr, (const int*)p.gsw,
                        (const f4*)a.part, a.pre);
