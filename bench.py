@@ -283,6 +283,8 @@ def main():
     ap.add_argument('--min-seconds', type=float, default=0.2,
                     help='if the timed region is shorter, repeat it (value stays the first, value_min/max '
                          'report the spread)')
+    ap.add_argument('--profile-every', type=int, default=4,
+                    help='HIP events on every n-th launch of the dominant kernel in the timed region')
     ap.add_argument('--profile-steps', type=int, default=-1,
                     help='steps of the untimed per-kernel event pass (-1: min(steps, 40), 0: skip)')
     a = ap.parse_args()
@@ -550,6 +552,7 @@ def main():
         stream it is launched on), over `nsteps` untimed steps of the runner."""
         for c in Rx['ctxs']:
             c.set_option('profile_only', -1)
+            c.set_option('profile_every', 1)
             c.set_option('profile', 1)
             c.profile_reset()
         for _ in range(nsteps):
@@ -634,13 +637,17 @@ def main():
     # which form of the per-wavelength stage runs: one probing step with every slot timed
     for c in ctxs:
         c.set_option('profile_only', -1)
+        c.set_option('profile_every', 1)
         c.set_option('profile', 1)
         c.profile_reset()
     R['step']()
     R['fence']()
     dominant = 'otf_mfma' if R['profile_sum']().get('otf_mfma', (0, 0))[1] > 0 else DOMINANT
+    # (every fourth launch of it: a timed launch stops its queue in front of and behind the kernel, ~12 us in the
+    # kernel trace -- profiles/r05_experiments.md; `roofline.launches` says how many were timed)
     for c in ctxs:
         c.set_option('profile_only', c.profile_names().index(dominant))
+        c.set_option('profile_every', a.profile_every)
         c.set_option('profile', 1)
     # The library's pool of HIP events for the bracketed kernel must hold a whole timed region's worth
     # before that region starts (an event created inside it costs ~10 us of host time: with K = 20 and
@@ -669,6 +676,7 @@ def main():
     if nprof > 0:
         for c in ctxs:
             c.set_option('profile_only', -1)
+            c.set_option('profile_every', 1)
             c.profile_reset()
         for _ in range(nprof):
             R['step']()
@@ -906,8 +914,14 @@ def main():
         ndir = a.npsflin ** 2
         ms, nlaunch = prof[dominant]
         chunk = a.chunk or 'auto'
-        units_per_launch = rows * nl * ndir * a.steps / max(nlaunch, 1)
-        tasks_per_launch = rows * a.steps / max(nlaunch, 1)
+        # launches of the kernel per step (one per pipeline pass): from the all-kernel pass, where every launch is
+        # timed; in the timed region only every `--profile-every`-th launch carries events
+        if prof_all.get(dominant, (0, 0))[1] and nprof:
+            launches_per_step = prof_all[dominant][1] / nprof
+        else:
+            launches_per_step = max(1.0, round(nlaunch * a.profile_every / a.steps))
+        units_per_launch = rows * nl * ndir / launches_per_step
+        tasks_per_launch = rows / launches_per_step
         avg_s = ms / max(nlaunch, 1) * 1e-3
         ntrans_all = tasks_per_launch * (dim // 2 + 1) * ((nl + 1) // 2)
         kept_frac = float(lines_kept.mean() / (dim // 2 + 1)) if lines_kept is not None else 1.0
@@ -1017,7 +1031,7 @@ def main():
             'roofline': {'bound': bound, 'kernel': kernel_name,
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4), 'traffic': traffic,
-                         'avg_launch_ms': round(avg_s * 1e3, 4), 'launches': nlaunch,
+                         'avg_launch_ms': round(avg_s * 1e3, 4), 'launches': nlaunch, 'launches_timed_every': a.profile_every,
                          'one_call_in_flight': alone_ms and {
                              'avg_launch_ms': round(alone_ms, 4),
                              'achieved': round(flops / (alone_ms * 1e-3) / 1e12, 2),

@@ -71,6 +71,8 @@ struct mpsfr_ctx {
     bool fast_exp = true;    // mixed mode: exp(x) = v_exp_f32(x log2 e)
     bool profile = false;
     int prof_only = -1;          // >= 0: time only this kernel id
+    int prof_every = 1;          // time every n-th launch of a slot (a timed launch stops its queue twice)
+    unsigned prof_count[64] = {};
     bool fft_conv = true;   // mixed mode: convolutions through 64-point FFTs
     int prune_fixed = 0;         // experiments: transform exactly this many lines (wrong results)
     double prune_eps = 1.0e-9;   // mixed mode: line pruning of the per-wavelength stage (0 = off)
@@ -266,6 +268,7 @@ struct ProfScope {
     ProfScope(mpsfr_ctx* ctx, int kid, hipStream_t stream = nullptr, bool use_markers = true)
         : c(ctx), id(kid), st(stream ? stream : ctx->stream), markers(use_markers) {
         on = c->profile && (c->prof_only < 0 || c->prof_only == kid);
+        if (on && c->prof_every > 1 && kid >= 0 && kid < 64) on = (c->prof_count[kid]++ % (unsigned)c->prof_every) == 0;
         if (on) {
             a = get_event(c);
             b = get_event(c);
@@ -633,6 +636,9 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         c->fft_conv = value != 0.0;
     } else if (!strcmp(key, "profile")) {
         c->profile = value != 0.0;
+    } else if (!strcmp(key, "profile_every")) {
+        if (value != (int)value || value < 1.0 || value > 1024.0) return fail(MPSFR_E_INVALID, "profile_every must be 1..1024");
+        c->prof_every = (int)value;
     } else if (!strcmp(key, "profile_only")) {
         if (value != (int)value || value < -1.0 || value >= K_COUNT)
             return fail(MPSFR_E_INVALID, "profile_only must be -1 or a kernel id");
