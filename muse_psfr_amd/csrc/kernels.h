@@ -196,7 +196,8 @@ void launch_fit(hipStream_t s, int nstamp, const void* d_stamps, bool stamps_f32
 void launch_stamp_sum(hipStream_t s, int ntask, int nl, const void* d_fin, bool fin_f32, double* d_sum,
                       int accumulate);
 // the call's parameter blob from pinned host memory into device memory, as a kernel of the call's own queue
-// (bytes: a multiple of 16)
-void launch_param_copy(hipStream_t s, void* d_dst, const void* h_src_pinned, size_t bytes);
+// (bytes: a multiple of 16); h_flag_pinned: a pinned host word that receives `seq` once the blob has been read
+void launch_param_copy(hipStream_t s, void* d_dst, const void* h_src_pinned, size_t bytes,
+                       unsigned long long* h_flag_pinned = nullptr, unsigned long long seq = 0);
 
 }  // namespace mpsfr

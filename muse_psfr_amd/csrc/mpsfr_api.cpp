@@ -103,7 +103,9 @@ struct mpsfr_ctx {
         hipEvent_t done = nullptr;       // after the lane's last chunk of the most recent call (calls that join)
         hipEvent_t done_ev = nullptr;    // the event that marks the end of the lane's most recent call: `done`, or
                                          // the slot event of a call that queued a single marker (see "lean" below)
-        bool busy = false;               // `done_ev` has been recorded
+        bool busy = false;               // the lane has run a call
+        bool marked = false;             // `done_ev` marks the end of the lane's most recent call (else: no marker was
+                                         // queued for it -- lane_end() records one when somebody needs it)
         int ncu = 0;                     // CUs the lane's stream may use (0: all of them)
         DevBuf C, s00, D0t, Tq, pre, fin, dmin, dblk, vkeep, dminb, order, mown, muni, msched, mpart;
         DevBuf pP, pT, psp, dlin;        // series form of stage A: patch, its row transforms, its sum; line minima
@@ -148,11 +150,18 @@ struct mpsfr_ctx {
         bool staged_pending = false;
         hipEvent_t call_done = nullptr;  // after the call that used the slot (join stream, or the call's lane)
         bool call_pending = false;
-        int last_lane = -1;              // lane of a single-marker call (stream order covers the slot's reuse there)
+        int last_lane = -1;              // lane of a lean call (stream order covers the slot's reuse there)
+        bool has_event = true;           // `call_done` was recorded for the slot's last call
+        unsigned long long seq = 0;      // staged_mode 2: the value the parameter-copy kernel writes into seq_host[slot]
+        int staged_mode = 0;             // what frees the pinned blob: 0 `staged`, 1 `call_done`, 2 the kernel's flag
         DevBuf params, ktt;
     };
     Slot slot[NSTAGE];
     unsigned stage_next = 0;
+    // Pinned host words the parameter-copy kernels write when they have read their blob (one per slot): the host
+    // polls them instead of waiting for an event, so that a lean call queues no marker packet at all.
+    unsigned long long* seq_host = nullptr;
+    unsigned long long seq_next = 0;
     // Asynchronous host outputs (on_device = 2): a ring of result sets -- device buffers the call
     // writes, a pinned host mirror the join stream copies them to -- and the caller's arrays, filled
     // when the ticket is waited for.  The host queues up to NTICKET such calls ahead of the GPU and the
@@ -243,6 +252,18 @@ int complete_ticket(mpsfr_ctx* c, mpsfr_ctx::Ticket& tk) {
     if (tk.u_fit) memcpy(tk.u_fit, h + tk.n_psf + tk.n_sum, tk.n_fit * sizeof(double));
     tk.pending = false;
     return MPSFR_OK;
+}
+
+// The event behind the lane's most recent call; a lean call queued none, so it is recorded here, at the lane's
+// present tail (at or behind the end of that call: conservative), when somebody needs to wait for the lane.
+hipEvent_t lane_end(mpsfr_ctx* c, mpsfr_ctx::Lane& ln) {
+    if (!ln.marked) {
+        if (!ln.done) (void)hipEventCreateWithFlags(&ln.done, hipEventDisableTiming);
+        (void)hipEventRecord(ln.done, ln.stream);
+        ln.done_ev = ln.done;
+        ln.marked = true;
+    }
+    return ln.done_ev;
 }
 
 hipEvent_t get_event(mpsfr_ctx* c) {
@@ -509,6 +530,13 @@ int mpsfr_create(mpsfr_ctx** out, int device_id, int dim, int dimpsf, double pix
         delete c;
         return fail(MPSFR_E_HIP, "hipStreamCreate failed");
     }
+    {   // the pinned words of the parameter-copy kernels (optional: without them a lean call queues one marker)
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, mpsfr_ctx::NSTAGE * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess) {
+            c->seq_host = (unsigned long long*)hp;
+            for (int k = 0; k < mpsfr_ctx::NSTAGE; ++k) c->seq_host[k] = 0;
+        }
+    }
     const int rc = build_constant_tables(c);
     if (rc) {
         mpsfr_destroy(c);
@@ -558,6 +586,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
                      &c->samp_a, &c->G, &c->xtab, &c->etab, &c->gtab, &c->kmuse, &c->fit, &c->sum,
                      &c->stage, &c->lsum, &c->mfclk};
     for (auto b : all) release(*b);
+    if (c->seq_host) (void)hipHostFree(c->seq_host);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -584,6 +613,7 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
                 HIPCHK(hipStreamDestroy(ln.stream));
                 ln.stream = nullptr;
                 ln.busy = false;
+                ln.marked = false;
                 ln.ncu = 0;
             }
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -743,6 +773,8 @@ static int guarded_call(mpsfr_ctx* c, int ntask, const double* seeing, const dou
         c->lane_rr = lane_rr0;
         c->stage_next = stage0;
         c->wait_next = nullptr;
+        // (everything has drained: every pinned blob is free, whether or not the kernel that would have said so ran)
+        for (int k = 0; k < mpsfr_ctx::NSTAGE; ++k) c->slot[k].staged_pending = false;
     }
     return rc;
 }
@@ -957,7 +989,8 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     if (stagger && NLmax > 1) {
         cold_first = true;
         for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
-            if (c->lane[k].busy && hipEventQuery(c->lane[k].done_ev) != hipSuccess) cold_first = false;
+            if (c->lane[k].busy && (c->lane[k].marked ? hipEventQuery(c->lane[k].done_ev) : hipStreamQuery(c->lane[k].stream)) != hipSuccess)
+                cold_first = false;
         if (!c->stagger_ev) HIPCHK(hipEventCreateWithFlags(&c->stagger_ev, hipEventDisableTiming));
     }
 
@@ -974,7 +1007,20 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     double t_blocked = 0.0;
     if (sl.staged_pending) {        // the copy that last used the pinned blob must have left it
         const auto tb = std::chrono::steady_clock::now();
-        HIPCHK(hipEventSynchronize(sl.staged_ev));   // only blocks once the host is NSTAGE calls ahead
+        if (sl.staged_mode == 2) {               // (only blocks once the host is NSTAGE calls ahead)
+            volatile unsigned long long* flag = c->seq_host + (&sl - c->slot);
+            const auto t_lim = tb + std::chrono::seconds(5);
+            while (*flag < sl.seq) {
+                if (std::chrono::steady_clock::now() > t_lim) {         // (a failed kernel never writes its flag)
+                    if (sl.last_lane >= 0 && c->lane[sl.last_lane].stream)
+                        HIPCHK(hipStreamSynchronize(c->lane[sl.last_lane].stream));
+                    break;
+                }
+                __builtin_ia32_pause();
+            }
+        } else {
+            HIPCHK(hipEventSynchronize(sl.staged_ev));
+        }
         t_blocked = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count();
         sl.staged_pending = false;
     }
@@ -1010,22 +1056,25 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
                            dev_out ? (const void*)psf_sum_out : nullptr,
                            dev_out ? (const void*)fit_out : nullptr};
     // (the call that used this slot NSTAGE calls ago has usually finished: then no lane waits for it)
-    const bool slot_done = sl.call_pending && hipEventQuery(sl.call_done) == hipSuccess;
+    const bool slot_done = sl.call_pending && sl.has_event && hipEventQuery(sl.call_done) == hipSuccess;
     for (int j = 0; j < NL; ++j) {
         hipStream_t ls = lane_of(j).stream;
-        // (a single-marker call recorded the slot's event on its own lane: on that lane stream order suffices)
-        if (sl.call_pending && !slot_done && sl.last_lane != (int)(&lane_of(j) - c->lane))
-            HIPCHK(hipStreamWaitEvent(ls, sl.call_done, 0));
+        // (a lean call ran on one lane: on that lane stream order suffices; another lane waits for the slot's
+        // event, or -- the call queued none -- for the end of that lane as it stands now)
+        if (sl.call_pending && !slot_done && sl.last_lane != (int)(&lane_of(j) - c->lane)) {
+            if (sl.has_event) HIPCHK(hipStreamWaitEvent(ls, sl.call_done, 0));
+            else if (sl.last_lane >= 0) HIPCHK(hipStreamWaitEvent(ls, lane_end(c, c->lane[sl.last_lane]), 0));
+        }
         if (c->wait_next) HIPCHK(hipStreamWaitEvent(ls, c->wait_next, 0));
         if (c->lsum_busy && NL > 1) HIPCHK(hipStreamWaitEvent(ls, c->lsum_done, 0));
         for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k) {
-            const mpsfr_ctx::Lane& o = c->lane[k];
+            mpsfr_ctx::Lane& o = c->lane[k];
             if (&o == &lane_of(j) || !o.busy) continue;
             bool same = false;
             for (int hsl = 0; hsl < mpsfr_ctx::Lane::NHIST; ++hsl)
                 for (int a = 0; a < 3; ++a)
                     for (int b = 0; b < 3; ++b) same = same || (outs[a] && outs[a] == o.outs[hsl][b]);
-            if (same) HIPCHK(hipStreamWaitEvent(ls, o.done_ev, 0));
+            if (same) HIPCHK(hipStreamWaitEvent(ls, lane_end(c, o), 0));
         }
     }
     c->wait_next = nullptr;
@@ -1033,17 +1082,28 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     // The blob travels as a KERNEL of the call's own queue that reads the pinned host memory: a
     // hipMemcpyAsync of these ~20 KB is a hand-over to a copy engine and back, and sat at the head of every
     // call ("param_copy" = 0 brings it back).
-    if (c->param_copy_kernel) launch_param_copy(s0, sl.params.p, hb, blob);
-    else HIPCHK(hipMemcpyAsync(sl.params.p, hb, blob, hipMemcpyHostToDevice, s0));
-    // "lean" calls -- device outputs on one lane of a context whose stream nobody uses -- queue ONE marker: the
-    // slot's event at the end of the lane's chain is the end of the call for the slot, for the lane and for the
-    // pinned blob.  A marker is a packet the queue stops at (~7 us in the kernel trace: the three of a call --
-    // behind the parameter copy, the lane's, the slot's -- were a tenth of a 100-row call).
-    if (lean) {
-        sl.staged_ev = sl.call_done;
+    // "lean" calls -- device outputs on one lane of a context whose stream nobody uses -- queue NO marker packet
+    // (a marker is a packet the queue stops at: ~7 us in the kernel trace, and the three of a call -- behind the
+    // parameter copy, the lane's, the slot's -- were a tenth of a 100-row call): the copy kernel itself tells the
+    // host, through a pinned word, when the blob may be refilled; the slot and the lane get an event only when
+    // another lane has to wait for them (lane_end).  With the hipMemcpyAsync form of the copy a lean call queues
+    // one: the slot's event at the end of the lane's chain.
+    const bool zero = lean && c->param_copy_kernel && c->seq_host != nullptr;
+    if (zero) {
+        sl.seq = ++c->seq_next;
+        launch_param_copy(s0, sl.params.p, hb, blob, c->seq_host + (&sl - c->slot), sl.seq);
+        sl.staged_mode = 2;
     } else {
-        HIPCHK(hipEventRecord(sl.staged, s0));
-        sl.staged_ev = sl.staged;
+        if (c->param_copy_kernel) launch_param_copy(s0, sl.params.p, hb, blob, nullptr, 0);
+        else HIPCHK(hipMemcpyAsync(sl.params.p, hb, blob, hipMemcpyHostToDevice, s0));
+        if (lean) {
+            sl.staged_ev = sl.call_done;
+            sl.staged_mode = 1;
+        } else {
+            HIPCHK(hipEventRecord(sl.staged, s0));
+            sl.staged_ev = sl.staged;
+            sl.staged_mode = 0;
+        }
     }
     sl.staged_pending = true;
     const char* db = (const char*)sl.params.p;
@@ -1092,7 +1152,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     if (!ao_cached || !lam_cached) {
         for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
             if (c->lane[k].busy && c->lane[k].stream != s0)
-                HIPCHK(hipStreamWaitEvent(s0, c->lane[k].done_ev, 0));
+                HIPCHK(hipStreamWaitEvent(s0, lane_end(c, c->lane[k]), 0));
         if (!ao_cached) {
             ProfScope ps(c, K_AO_TABLES, s0);
             launch_ao_tables(s0, g, d_mrec, d_mres, (double*)c->aotab.p);
@@ -1419,12 +1479,16 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     hipStream_t s = c->stream;
     for (int j = 0; j < NL; ++j) {
         mpsfr_ctx::Lane& ln = lane_of(j);
-        if (lean) {
+        if (zero) {
+            ln.marked = false;               // (lane_end records a marker if somebody has to wait for the lane)
+        } else if (lean) {
             HIPCHK(hipEventRecord(sl.call_done, ln.stream));
             ln.done_ev = sl.call_done;
+            ln.marked = true;
         } else {
             HIPCHK(hipEventRecord(ln.done, ln.stream));
             ln.done_ev = ln.done;
+            ln.marked = true;
             HIPCHK(hipStreamWaitEvent(s, ln.done, 0));
         }
         ln.busy = true;
@@ -1443,6 +1507,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     if (!lean) HIPCHK(hipEventRecord(sl.call_done, s));
     sl.call_pending = true;
     sl.last_lane = lean ? (int)(&lane_of(0) - c->lane) : -1;
+    sl.has_event = !zero;
     c->last_ndir = ndir;
     c->last_nl = nl;
     c->last_mf = mf;
@@ -1797,7 +1862,7 @@ void* mpsfr_stream(mpsfr_ctx* c) {
         c->stream_exported = true;
         (void)hipSetDevice(c->device);
         for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
-            if (c->lane[k].busy) (void)hipStreamWaitEvent(c->stream, c->lane[k].done_ev, 0);
+            if (c->lane[k].busy) (void)hipStreamWaitEvent(c->stream, lane_end(c, c->lane[k]), 0);
     }
     return (void*)c->stream;
 }

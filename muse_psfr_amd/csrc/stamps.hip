@@ -1365,19 +1365,28 @@ __global__ void __launch_bounds__(256) k_stamp_sum(int ntask, int nl, const TF* 
     }
 }
 
-// K_PARAM_COPY: see launch_param_copy
-__global__ void __launch_bounds__(256) k_param_copy(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+// K_PARAM_COPY: see launch_param_copy.  One workgroup; when all of the blob has been read, thread 0 writes `seq`
+// into the pinned host word `flag` (system scope): the host may refill the blob.
+__global__ void __launch_bounds__(256) k_param_copy(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16,
+                                                    unsigned long long* flag, unsigned long long seq) {
+    for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+    if (flag != nullptr) {
+        __syncthreads();                     // (every thread's loads have returned: they fed its stores)
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 }  // namespace
 
-void launch_param_copy(hipStream_t s, void* d_dst, const void* h_src_pinned, size_t bytes) {
+void launch_param_copy(hipStream_t s, void* d_dst, const void* h_src_pinned, size_t bytes,
+                       unsigned long long* h_flag_pinned, unsigned long long seq) {
     const int n16 = (int)(bytes / 16);
     if (n16 <= 0) return;
-    int nwg = (n16 + 255) / 256;
-    if (nwg > 16) nwg = 16;
-    hipLaunchKernelGGL(k_param_copy, dim3(nwg), dim3(256), 0, s, (uint4*)d_dst, (const uint4*)h_src_pinned, n16);
+    hipLaunchKernelGGL(k_param_copy, dim3(1), dim3(256), 0, s, (uint4*)d_dst, (const uint4*)h_src_pinned, n16,
+                       h_flag_pinned, seq);
 }
 
 void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
