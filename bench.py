@@ -422,7 +422,16 @@ def main():
         # for the exchange that last read it (mpsfr_wait_event).
         # (only a run with an exchange orders its own stream behind the library's: asking for the stream makes the
         # library join its lanes into it on every call)
-        lib_streams = [torch.cuda.ExternalStream(c.stream_handle(), device=dev) for c in ctxs] if xchg else None
+        # MPSFR_BENCH_JOIN_STREAM=1: the round-4 form (torch's stream waits on the library's stream, which makes
+        # every call join its lanes into it); default: mpsfr_stream_wait -- the calls stay on their lanes
+        lib_streams = ([torch.cuda.ExternalStream(c.stream_handle(), device=dev) for c in ctxs]
+                       if xchg and os.environ.get('MPSFR_BENCH_JOIN_STREAM') else None)
+
+        def hand_over(k, cur):
+            if lib_streams is not None:
+                cur.wait_stream(lib_streams[k])
+            else:
+                ctxs[k].stream_wait(cur.cuda_stream)
 
         def step():
             k = state['i'] % nctx
@@ -435,7 +444,7 @@ def main():
                                        None, None, psum_b.data_ptr(), fit_b.data_ptr())
             if xchg:           # FIT_ROWS gather + PSF_MEAN numerator reduce
                 cur = torch.cuda.current_stream()
-                cur.wait_stream(lib_streams[k])
+                hand_over(k, cur)
                 if packed:
                     state['fit_all'], state['psum'] = exch[b].exchange_packed()
                 elif backend == 'nccl':      # all-gather of the fit tables + reduce of the stamp sums
@@ -512,7 +521,7 @@ def main():
                 ctxs[k].reconstruct_device(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin,
                                            None, None, psum_b.data_ptr(), fit_b.data_ptr())
                 cur = torch.cuda.current_stream()
-                cur.wait_stream(lib_streams[k])
+                hand_over(k, cur)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(cur)
                 th = time.perf_counter()

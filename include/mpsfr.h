@@ -250,6 +250,13 @@ int mpsfr_abandon(mpsfr_ctx* ctx);
  * sync, e.g. torch.cuda.current_stream().wait_stream(torch.cuda.ExternalStream(...)). */
 void* mpsfr_stream(mpsfr_ctx* ctx);
 
+/* Make `caller_stream` (a hipStream_t of the caller, as void*) wait, on the GPU, for every asynchronous call made so far
+ * on this context: the cheap form of "wait on mpsfr_stream()" -- the call's work stays on its lane and one event at the
+ * lane's end is all that is queued (asking for mpsfr_stream() makes every later call join its lanes into a further
+ * queue).  E.g. before a collective that reads the call's device outputs:
+ *   mpsfr_stream_wait(ctx, (void*)torch.cuda.current_stream().cuda_stream). */
+int mpsfr_stream_wait(mpsfr_ctx* ctx, void* caller_stream);
+
 /* Make the next mpsfr_reconstruct wait (on the GPU, no host sync) for `hip_event`, a recorded
  * hipEvent_t of the caller, e.g. the end of a collective that still reads the buffers the call
  * will overwrite.  One-shot: consumed by the next call. */

@@ -91,6 +91,8 @@ def load():
     lib.mpsfr_abandon.restype = C.c_int
     lib.mpsfr_stream.argtypes = [p]
     lib.mpsfr_stream.restype = C.c_void_p
+    lib.mpsfr_stream_wait.argtypes = [p, C.c_void_p]
+    lib.mpsfr_stream_wait.restype = C.c_int
     lib.mpsfr_wait_event.argtypes = [p, C.c_void_p]
     lib.mpsfr_wait_event.restype = C.c_int
     lib.mpsfr_host_time.argtypes = [p, dp, C.POINTER(C.c_long)]
@@ -118,7 +120,7 @@ def load():
 EXPORTS = ['mpsfr_create', 'mpsfr_destroy', 'mpsfr_last_error', 'mpsfr_set_option',
            'mpsfr_reconstruct', 'mpsfr_reconstruct_multi', 'mpsfr_reconstruct_multi_async', 'mpsfr_wait_multi', 'mpsfr_fit_stamps', 'mpsfr_simul_psd', 'mpsfr_psf_from_psd',
            'mpsfr_convolve_stamps', 'mpsfr_fit_rows', 'mpsfr_sync', 'mpsfr_last_ticket', 'mpsfr_wait', 'mpsfr_abandon',
-           'mpsfr_stream', 'mpsfr_wait_event',
+           'mpsfr_stream', 'mpsfr_stream_wait', 'mpsfr_wait_event',
            'mpsfr_host_time', 'mpsfr_debug_fetch',
            'mpsfr_profile_count', 'mpsfr_profile_name', 'mpsfr_profile_get',
            'mpsfr_profile_reset', 'mpsfr_version', 'mpsfr_build_id', 'mpsfr_device_count']
@@ -203,6 +205,11 @@ class Context:
         """The next reconstruct call waits on the GPU for this recorded hipEvent_t (an integer
         handle, e.g. torch.cuda.Event.cuda_event)."""
         _check(self.lib.mpsfr_wait_event(self._h, C.c_void_p(int(hip_event))))
+
+    def stream_wait(self, hip_stream):
+        """Make the caller's stream (an integer hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) wait on the
+        GPU for every call made so far (mpsfr_stream_wait): the cheap form of waiting on stream_handle()."""
+        _check(self.lib.mpsfr_stream_wait(self._h, C.c_void_p(int(hip_stream))))
 
     def host_time(self):
         """(seconds spent inside mpsfr_reconstruct, calls) since the last profile_reset()."""

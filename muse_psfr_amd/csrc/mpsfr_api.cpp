@@ -123,6 +123,7 @@ struct mpsfr_ctx {
     int cu_partition = 0;        // 1: every lane's stream owns 1/lanes of the CUs (hipExtStreamCreateWithCUMask)
     bool param_copy_kernel = true;   // the parameter blob of a call is fetched by a kernel (else hipMemcpyAsync)
     bool stream_exported = false;    // mpsfr_stream() has been called: every call joins its lanes into `stream`
+    hipEvent_t stream_tail = nullptr;    // created once a call has queued work on `stream` (mpsfr_stream_wait)
     bool pipeline_calls = true;  // successive asynchronous calls rotate over the lanes
     unsigned lane_rr = 0;        // lane of the next chunk
     hipEvent_t tables_ready = nullptr;
@@ -555,7 +556,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         (void)hipEventDestroy(p.b);
     }
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    hipEvent_t evs[] = {c->tables_ready, c->cache_ready, c->lsum_done, c->stagger_ev};
+    hipEvent_t evs[] = {c->tables_ready, c->cache_ready, c->lsum_done, c->stagger_ev, c->stream_tail};
     for (auto e : evs)
         if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k) {
@@ -1055,6 +1056,8 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     const void* outs[3] = {dev_out ? (const void*)psf_out : nullptr,
                            dev_out ? (const void*)psf_sum_out : nullptr,
                            dev_out ? (const void*)fit_out : nullptr};
+    // (an event the caller registered that has already happened is no dependency any more)
+    if (c->wait_next && hipEventQuery(c->wait_next) == hipSuccess) c->wait_next = nullptr;
     // (the call that used this slot NSTAGE calls ago has usually finished: then no lane waits for it)
     const bool slot_done = sl.call_pending && sl.has_event && hipEventQuery(sl.call_done) == hipSuccess;
     for (int j = 0; j < NL; ++j) {
@@ -1504,7 +1507,10 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         HIPCHK(hipEventRecord(c->lsum_done, s));
         c->lsum_busy = true;
     }
-    if (!lean) HIPCHK(hipEventRecord(sl.call_done, s));
+    if (!lean) {
+        HIPCHK(hipEventRecord(sl.call_done, s));
+        if (!c->stream_tail) HIPCHK(hipEventCreateWithFlags(&c->stream_tail, hipEventDisableTiming));
+    }
     sl.call_pending = true;
     sl.last_lane = lean ? (int)(&lane_of(0) - c->lane) : -1;
     sl.has_event = !zero;
@@ -1865,6 +1871,20 @@ void* mpsfr_stream(mpsfr_ctx* c) {
             if (c->lane[k].busy) (void)hipStreamWaitEvent(c->stream, lane_end(c, c->lane[k]), 0);
     }
     return (void*)c->stream;
+}
+
+int mpsfr_stream_wait(mpsfr_ctx* c, void* caller_stream) {
+    if (!c) return fail(MPSFR_E_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t cs = (hipStream_t)caller_stream;
+    for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
+        if (c->lane[k].busy) HIPCHK(hipStreamWaitEvent(cs, lane_end(c, c->lane[k]), 0));
+    // (host-output and multi-lane calls finish on the context's stream: the lane sums, the copies)
+    if (c->stream_tail) {
+        HIPCHK(hipEventRecord(c->stream_tail, c->stream));
+        HIPCHK(hipStreamWaitEvent(cs, c->stream_tail, 0));
+    }
+    return MPSFR_OK;
 }
 
 int mpsfr_profile_count(void) { return K_COUNT; }
