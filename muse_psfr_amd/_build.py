@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmpsfr.so')
 SOURCES = ['stage_a.hip', 'stage_a2.hip', 'per_lambda.hip', 'otf_mfma.hip', 'otf_mfma2.hip', 'stamps.hip', 'mpsfr_api.cpp']
-HEADERS = ['kernels.h', 'fft_lds.h', 'fft_r16.h', 'device_common.h', 'mf_common.h', 'coeff_l0_table.h', 'psd_model.h', 'dpp_groups.h',
+HEADERS = ['kernels.h', 'fft_lds.h', 'fft_r16.h', 'device_common.h', 'mf_common.h', 'coeff_l0_table.h', 'psd_model.h', 'dpp_groups.h', 'conv_frames.h',
            os.path.join('..', '..', 'include', 'mpsfr.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-result',
          '-fno-slp-vectorize']

@@ -107,8 +107,27 @@ int series_terms(bool f64);
 double series_eps0();
 inline double series_eps_max() { return 1.0 / 49.0; }
 void launch_series_coef(hipStream_t s, int N, const double* d_planes, void* d_coef, bool f64);
+// What else rides in the two launches of launch_patch (round 6; all optional):
+//  * the call's parameter blob: blob_src (pinned host) -> blob_dst (device) as extra workgroups of K_PATCH_GEN, which
+//    then reads its tasks from `tp_host` (the TaskPar array INSIDE the pinned blob); `flag`: the pinned word the
+//    first workgroup of K_PATCH_ROWS sets to `seq` -- the blob may be refilled (may be NULL);
+//  * the spectra of `khat_n` tip-tilt Moffat kernels (launch_khat) as extra workgroups of K_PATCH_ROWS.
+struct PatchExtras {
+    const void* blob_src = nullptr;
+    void* blob_dst = nullptr;
+    size_t blob_bytes = 0;
+    const TaskPar* tp_host = nullptr;
+    unsigned long long* flag = nullptr;
+    unsigned long long seq = 0;
+    int khat_n = 0;
+    const double* khat_gam = nullptr;
+    const double* khat_alp = nullptr;
+    void* khat_out = nullptr;
+    bool khat_f64 = false;
+};
 void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const double* d_aotab,
-                  double cfit, const void* d_twk, double* d_P, void* d_T, double* d_sp, bool f64);
+                  double cfit, const void* d_twk, double* d_P, void* d_T, double* d_sp, bool f64,
+                  const PatchExtras& x = PatchExtras());
 void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const void* d_T,
                         const double* d_sp, const void* d_coef, const void* d_twk, double scale2,
                         void* d_D0t, float* d_dlin, bool f64out, int* d_zero, int ncu);

@@ -63,6 +63,13 @@ struct Pending {
 
 struct mpsfr_ctx {
     int device = 0, N = 0, dimpsf = 0, prec = 0, ncu = 256;
+    // CUs the two persistent grids leave free (K_OTF_MFMA2 / K_DPHI_SERIES launch ncu - R workgroups, no CU
+    // masks): the other lane's latency-bound kernels find room beside them (VERDICT r5 #1a)
+    // -1 (default): ncu / 8 while the context's other lane has work in flight, 0 for a call that runs alone
+    int reserve_mf = -1, reserve_a = -1;
+    // the parameter blob and the tip-tilt kernel spectra ride in the two launches of the patch (series form of stage A)
+    bool head_fusion = true;
+    bool copy_fusion = false;
     double pixscale = 0.2;
     bool f64 = false;
     hipStream_t stream = nullptr;
@@ -279,6 +286,14 @@ hipEvent_t get_event(mpsfr_ctx* c) {
 }
 
 int resolve_profile(mpsfr_ctx* c);
+
+// workgroups of a persistent kernel on a lane: one per CU the lane may use, less the reserve
+template <class LaneT>
+int persist_grid(const mpsfr_ctx* c, const LaneT& ln, int reserve, bool shared) {
+    const int n = ln.ncu ? ln.ncu : c->ncu;
+    if (reserve < 0) reserve = (shared && !ln.ncu) ? n / 8 : 0;         // (CU-masked lanes are partitioned already)
+    return n - reserve >= n / 2 ? n - reserve : n / 2;
+}
 
 struct ProfScope {
     mpsfr_ctx* c;
@@ -641,6 +656,14 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
     } else if (!strcmp(key, "mf_permax")) {
         if (value != (int)value || value < 1.0 || value > 7.0) return fail(MPSFR_E_INVALID, "mf_permax must be 1..7");
         c->mf_permax = (int)value;
+    } else if (!strcmp(key, "persist_reserve") || !strcmp(key, "persist_reserve_mf") || !strcmp(key, "persist_reserve_a")) {
+        if (value != (int)value || value < -1.0 || value > 128.0) return fail(MPSFR_E_INVALID, "%s must be -1 (automatic) or 0..128", key);
+        if (key[15] == '\0' || key[16] == 'm') c->reserve_mf = (int)value;
+        if (key[15] == '\0' || key[16] == 'a') c->reserve_a = (int)value;
+    } else if (!strcmp(key, "head_fusion")) {
+        c->head_fusion = value != 0.0;
+    } else if (!strcmp(key, "copy_fusion")) {
+        c->copy_fusion = value != 0.0;
     } else if (!strcmp(key, "param_copy")) {
         c->param_copy_kernel = value != 0.0;
     } else if (!strcmp(key, "tier_eps")) {
@@ -995,15 +1018,31 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         if (!c->stagger_ev) HIPCHK(hipEventCreateWithFlags(&c->stagger_ev, hipEventDisableTiming));
     }
 
-    // ---- uploads: one pinned blob [LamPar nl][TaskPar ntask][gam][alp][mask_rec][mask_res]
+    // ---- the AO tables are cached on their inputs (geometry + cut-off masks): the masks -- 12.8 KB of the ~20 KB a
+    // call used to upload -- only travel with a call that rebuilds the tables
+    if ((rc = ensure(c, c->aotab, (size_t)2 * ndir * 3 * NAO * NAO * sizeof(double)))) return rc;
+    std::vector<unsigned char> key(sizeof(AoGeom) + 1 + (mask_rec ? 2 * NAO * NAO : 0));
+    memcpy(key.data(), &g, sizeof(AoGeom));
+    key[sizeof(AoGeom)] = mask_rec ? 1 : 0;
+    if (mask_rec) {
+        memcpy(key.data() + sizeof(AoGeom) + 1, mask_rec, NAO * NAO);
+        memcpy(key.data() + sizeof(AoGeom) + 1 + NAO * NAO, mask_res, NAO * NAO);
+    }
+    // (stage-level calls pass placeholder geometry or wavelengths for the stages they skip: those tables are
+    // neither built nor do they displace the cached ones of the last real call)
+    const bool need_ao = !io.pre_in && !io.psd_in;
+    const bool ao_cached = !need_ao || (key == c->cache_geom && c->cache_ao_ptr == c->aotab.p);
+    const bool send_masks = mask_rec && !ao_cached;
+
+    // ---- uploads: one pinned blob [LamPar nl][TaskPar ntask][gam][alp]([mask_rec][mask_res])
     auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t o_lp = 0;
     const size_t o_tp = al16(o_lp + nl * sizeof(LamPar));
     const size_t o_gam = al16(o_tp + ntask * sizeof(TaskPar));
     const size_t o_alp = al16(o_gam + gam.size() * sizeof(double));
     const size_t o_mr = al16(o_alp + alp.size() * sizeof(double));
-    const size_t o_ms = al16(o_mr + NAO * NAO);
-    const size_t blob = al16(o_ms + NAO * NAO);
+    const size_t o_ms = al16(o_mr + (send_masks ? NAO * NAO : 0));
+    const size_t blob = al16(o_ms + (send_masks ? NAO * NAO : 0));
     mpsfr_ctx::Slot& sl = c->slot[c->stage_next++ % mpsfr_ctx::NSTAGE];
     double t_blocked = 0.0;
     if (sl.staged_pending) {        // the copy that last used the pinned blob must have left it
@@ -1043,7 +1082,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     memcpy(hb + o_tp, tp.data(), ntask * sizeof(TaskPar));
     memcpy(hb + o_gam, gam.data(), gam.size() * sizeof(double));
     memcpy(hb + o_alp, alp.data(), alp.size() * sizeof(double));
-    if (mask_rec) {
+    if (send_masks) {
         memcpy(hb + o_mr, mask_rec, NAO * NAO);
         memcpy(hb + o_ms, mask_res, NAO * NAO);
     }
@@ -1082,45 +1121,9 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     }
     c->wait_next = nullptr;
     sl.call_pending = false;
-    // The blob travels as a KERNEL of the call's own queue that reads the pinned host memory: a
-    // hipMemcpyAsync of these ~20 KB is a hand-over to a copy engine and back, and sat at the head of every
-    // call ("param_copy" = 0 brings it back).
-    // "lean" calls -- device outputs on one lane of a context whose stream nobody uses -- queue NO marker packet
-    // (a marker is a packet the queue stops at: ~7 us in the kernel trace, and the three of a call -- behind the
-    // parameter copy, the lane's, the slot's -- were a tenth of a 100-row call): the copy kernel itself tells the
-    // host, through a pinned word, when the blob may be refilled; the slot and the lane get an event only when
-    // another lane has to wait for them (lane_end).  With the hipMemcpyAsync form of the copy a lean call queues
-    // one: the slot's event at the end of the lane's chain.
-    const bool zero = lean && c->param_copy_kernel && c->seq_host != nullptr;
-    if (zero) {
-        sl.seq = ++c->seq_next;
-        launch_param_copy(s0, sl.params.p, hb, blob, c->seq_host + (&sl - c->slot), sl.seq);
-        sl.staged_mode = 2;
-    } else {
-        if (c->param_copy_kernel) launch_param_copy(s0, sl.params.p, hb, blob, nullptr, 0);
-        else HIPCHK(hipMemcpyAsync(sl.params.p, hb, blob, hipMemcpyHostToDevice, s0));
-        if (lean) {
-            sl.staged_ev = sl.call_done;
-            sl.staged_mode = 1;
-        } else {
-            HIPCHK(hipEventRecord(sl.staged, s0));
-            sl.staged_ev = sl.staged;
-            sl.staged_mode = 0;
-        }
-    }
-    sl.staged_pending = true;
-    const char* db = (const char*)sl.params.p;
-    const LamPar* d_lp = (const LamPar*)(db + o_lp);
-    const TaskPar* d_tp = (const TaskPar*)(db + o_tp);
-    const double* d_gam = (const double*)(db + o_gam);
-    const double* d_alp = (const double*)(db + o_alp);
-    const uint8_t* d_mrec = mask_rec ? (const uint8_t*)(db + o_mr) : nullptr;
-    const uint8_t* d_mres = mask_rec ? (const uint8_t*)(db + o_ms) : nullptr;
-
     // ---- tables cached on their inputs (geometry + masks; wavelengths).  A rebuild waits for
     // every lane (an older call may still read the old tables) and is announced by `cache_ready`,
     // which every later call's lanes wait for.
-    if ((rc = ensure(c, c->aotab, (size_t)2 * ndir * 3 * NAO * NAO * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->samp_p, (size_t)nl * NS * sizeof(int)))) return rc;
     if ((rc = ensure(c, c->samp_a, (size_t)nl * NS * rsize(c)))) return rc;
     // G rows are padded to a multiple of 8 lines (paired-line layout of the fp32 second pass)
@@ -1135,23 +1138,56 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         if ((rc = ensure(c, c->etab, mf_etab_bytes(N, nl)))) return rc;
         if ((rc = ensure(c, c->gtab, mf_gtab_bytes(N, nl)))) return rc;
     }
-    std::vector<unsigned char> key(sizeof(AoGeom) + 1 + (mask_rec ? 2 * NAO * NAO : 0));
-    memcpy(key.data(), &g, sizeof(AoGeom));
-    key[sizeof(AoGeom)] = mask_rec ? 1 : 0;
-    if (mask_rec) {
-        memcpy(key.data() + sizeof(AoGeom) + 1, mask_rec, NAO * NAO);
-        memcpy(key.data() + sizeof(AoGeom) + 1 + NAO * NAO, mask_res, NAO * NAO);
-    }
-    // (stage-level calls pass placeholder geometry or wavelengths for the stages they skip: those tables are
-    // neither built nor do they displace the cached ones of the last real call)
-    const bool need_ao = !io.pre_in && !io.psd_in, need_lam = !io.psd_out;
-    const bool ao_cached = !need_ao || (key == c->cache_geom && c->cache_ao_ptr == c->aotab.p);
+    const bool need_lam = !io.psd_out;
     const std::vector<double> lb_key(lbda_nm, lbda_nm + nl);
     const bool lam_cached = !need_lam || (lb_key == c->cache_lbda && c->cache_lbda_mode == (use_fft_conv ? 1 : 0) &&
                             c->cache_G_ptr == c->G.p && c->cache_kmuse_ptr == c->kmuse.p &&
                             (!r16 || (c->cache_xtab_valid && c->cache_xtab_ptr == c->xtab.p)) &&
                             (!mf || (c->cache_mf_valid && c->cache_etab_ptr == c->etab.p &&
                                      c->cache_gtab_ptr == c->gtab.p)));
+    // The blob travels as a KERNEL of the call's own queue that reads the pinned host memory: a
+    // hipMemcpyAsync of these ~20 KB is a hand-over to a copy engine and back, and sat at the head of every
+    // call ("param_copy" = 0 brings it back).
+    // "lean" calls -- device outputs on one lane of a context whose stream nobody uses -- queue NO marker packet
+    // (a marker is a packet the queue stops at: ~7 us in the kernel trace, and the three of a call -- behind the
+    // parameter copy, the lane's, the slot's -- were a tenth of a 100-row call): the copy kernel itself tells the
+    // host, through a pinned word, when the blob may be refilled; the slot and the lane get an event only when
+    // another lane has to wait for them (lane_end).  With the hipMemcpyAsync form of the copy a lean call queues
+    // one: the slot's event at the end of the lane's chain.
+    const bool zero = lean && c->param_copy_kernel && c->seq_host != nullptr;
+    // Round 6: in the series form of stage A the blob is fetched by extra workgroups of the call's FIRST kernel
+    // (K_PATCH_GEN, which reads its tasks straight from the pinned blob), and the spectra of the tip-tilt kernels
+    // are extra workgroups of its second (K_PATCH_ROWS): a call on one lane with its tables cached starts with the
+    // patch itself, two launches shorter ("head_fusion" = 0: K_PARAM_COPY and K_KHAT as kernels of their own).
+    const bool fuse_head = c->head_fusion && series && !staged;
+    const bool fuse_copy = fuse_head && c->copy_fusion && c->param_copy_kernel && NL == 1 && lam_cached && ao_cached;
+    const bool fuse_khat = fuse_head && c->fft_conv;
+    sl.seq = ++c->seq_next;
+    if (zero) {
+        if (!fuse_copy) launch_param_copy(s0, sl.params.p, hb, blob, c->seq_host + (&sl - c->slot), sl.seq);
+        sl.staged_mode = 2;
+    } else {
+        if (fuse_copy) ;     // (the event that frees the blob is recorded behind the patch kernels, below)
+        else if (c->param_copy_kernel) launch_param_copy(s0, sl.params.p, hb, blob, nullptr, 0);
+        else HIPCHK(hipMemcpyAsync(sl.params.p, hb, blob, hipMemcpyHostToDevice, s0));
+        if (lean) {
+            sl.staged_ev = sl.call_done;
+            sl.staged_mode = 1;
+        } else {
+            if (!fuse_copy) HIPCHK(hipEventRecord(sl.staged, s0));
+            sl.staged_ev = sl.staged;
+            sl.staged_mode = 0;
+        }
+    }
+    sl.staged_pending = true;
+    const char* db = (const char*)sl.params.p;
+    const LamPar* d_lp = (const LamPar*)(db + o_lp);
+    const TaskPar* d_tp = (const TaskPar*)(db + o_tp);
+    const double* d_gam = (const double*)(db + o_gam);
+    const double* d_alp = (const double*)(db + o_alp);
+    const uint8_t* d_mrec = send_masks ? (const uint8_t*)(db + o_mr) : nullptr;     // (read by K_AO_TABLES only)
+    const uint8_t* d_mres = send_masks ? (const uint8_t*)(db + o_ms) : nullptr;
+
     if (!ao_cached || !lam_cached) {
         for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k)
             if (c->lane[k].busy && c->lane[k].stream != s0)
@@ -1197,8 +1233,10 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         // launch to a side stream, off the head of the call's chain, and folding the DC sum into
         // the column-transform kernel both LOWER the two-lane throughput, by 2-4 %: the short
         // serial kernels keep the two lanes out of phase.)
+        // Round 6: in the series form of stage A they are extra workgroups of K_PATCH_ROWS, per chunk (fuse_khat).
         ProfScope ps(c, K_MOFFAT_KERNELS, s0);
-        if (use_fft_conv) launch_khat(s0, ntask, d_gam, d_alp, sl.ktt.p, c->f64);   // [n][33][64] complex
+        if (fuse_khat) ;
+        else if (use_fft_conv) launch_khat(s0, ntask, d_gam, d_alp, sl.ktt.p, c->f64);   // [n][33][64] complex
         else launch_moffat_kernels(s0, ntask, d_gam, d_alp, sl.ktt.p, c->f64);
     }
 
@@ -1305,6 +1343,18 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         if (e1 != hipSuccess || e2 != hipSuccess) return fail(MPSFR_E_HIP, "copying the PSD image failed");
         return MPSFR_OK;
     }
+    // Does this call share the GPU with another lane's kernels?  Then its two persistent kernels leave an eighth of
+    // the CUs free (persist_grid): K_OTF_MFMA2 (136 KB of LDS, 3 x 168 registers per SIMD) and K_DPHI_SERIES (two
+    // waves of 238 registers) admit nothing beside them on a CU they hold, and the other lane's latency-bound
+    // kernels (the patch, K_MF_PREP, K_MF_FINISH) stood parked behind them for 30-50 us (profiles/r05_trace_gaps.txt).
+    // A call that runs alone keeps the whole chip (one lane: -5 % with the reserve).
+    bool lanes_shared = NL > 1;
+    if (!lanes_shared && NLmax > 1 && c->pipeline_calls && (c->reserve_mf < 0 || c->reserve_a < 0))
+        for (int k = 0; k < mpsfr_ctx::MAX_LANES; ++k) {
+            const mpsfr_ctx::Lane& o = c->lane[k];
+            if (&o == &lane_of(0) || !o.busy || !o.stream) continue;
+            if ((o.marked ? hipEventQuery(o.done_ev) : hipStreamQuery(o.stream)) != hipSuccess) lanes_shared = true;
+        }
     int nchunk_lane[mpsfr_ctx::MAX_LANES] = {0, 0, 0, 0};      // by lane position j in this call
     int ci = 0;
     for (int t0 = 0; t0 < ntask; t0 += TC, ++ci) {
@@ -1347,13 +1397,31 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         } else if (series) {
             {
                 ProfScope ps(c, K_PATCH, ls);
+                PatchExtras px;
+                if (fuse_copy && t0 == 0) {
+                    px.blob_src = hb;
+                    px.blob_dst = sl.params.p;
+                    px.blob_bytes = blob;
+                    px.tp_host = (const TaskPar*)(hb + o_tp);
+                    px.flag = zero ? c->seq_host + (&sl - c->slot) : nullptr;
+                    px.seq = sl.seq;
+                }
+                if (fuse_khat) {
+                    px.khat_n = tc;
+                    px.khat_gam = d_gam + t0;
+                    px.khat_alp = d_alp + t0;
+                    px.khat_out = (char*)sl.ktt.p + (size_t)t0 * ksz;
+                    px.khat_f64 = c->f64;
+                }
                 launch_patch(ls, N, ntd, ndir, d_tp + t0, (const double*)c->aotab.p, cfit, c->stwk.p,
-                             (double*)ln.pP.p, ln.pT.p, (double*)ln.psp.p, c->f64);
+                             (double*)ln.pP.p, ln.pT.p, (double*)ln.psp.p, c->f64, px);
+                // (a call that is not lean frees its blob through an event: behind the kernels that read it)
+                if (fuse_copy && t0 == 0 && !zero && !lean) HIPCHK(hipEventRecord(sl.staged, ls));
             }
             ProfScope ps(c, K_DPHI_SERIES, ls);
             launch_dphi_series(ls, N, ntd, ndir, d_tp + t0, ln.pT.p, (const double*)ln.psp.p, c->scoef.p,
                                c->stwk.p, scale2, ln.D0t.p, prune ? (float*)ln.dlin.p : nullptr, c->f64,
-                               mf2 ? (int*)ln.msched.p : nullptr, ln.ncu ? ln.ncu : c->ncu);
+                               mf2 ? (int*)ln.msched.p : nullptr, persist_grid(c, ln, c->reserve_a, lanes_shared));
         } else {
             {
                 ProfScope ps(c, K_PSD_ROWFFT, ls);
@@ -1404,7 +1472,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             // (timed through the dispatch packet of K_OTF_MFMA2 itself: the persistent kernel alone, without
             // K_MF_FINISH and without marker packets round it)
             ProfScope ps(c, K_OTF_MFMA, ls, false);
-            launch_otf_mfma2(ls, N, tc, nl, c->mf_permax, ln.ncu ? ln.ncu : c->ncu, ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
+            launch_otf_mfma2(ls, N, tc, nl, c->mf_permax, persist_grid(c, ln, c->reserve_mf, lanes_shared), ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
                              c->gtab.p, ln.mown.p, ln.muni.p, ln.msched.p, ln.mpart.p, ln.pre.p,
                              c->mf_clock ? c->mfclk.p : nullptr, ps.a, ps.b);
         } else if (mf) {

@@ -31,6 +31,7 @@
 #include <utility>
 
 #include "device_common.h"
+#include "conv_frames.h"
 #include "dpp_groups.h"
 #include "psd_model.h"
 
@@ -363,15 +364,63 @@ constexpr size_t twiddle_entries() { return (size_t)(fold_nj<N / L>() + N / L) *
 // directions: the fitting term and the von Karman factor of the pixel -- two x^(-11/6), nearly all of
 // the arithmetic -- do not depend on the direction, only the tables do (nine directions: 21.6 -> us).
 // ------------------------------------------------------------------------------------------
+// Round 6: the call's parameter blob rides in this launch (K_PARAM_COPY, the kernel that fetched it on its own at the
+// head of every call, cost the call's queue 8 us in round 5 and 5 us as one PCIe round trip -- an empty kernel
+// costs 4, profiles/r06_ubench_pcopy.txt).  With pc.n16 > 0 the workgroups of the row blockIdx.y == gridDim.y - 1
+// copy the blob from pinned host memory to the device for the kernels BEHIND this one, every load issued before
+// the first store; the task workgroups read their task's 40 bytes from `tp` = the TaskPar array INSIDE THE PINNED
+// BLOB: five lanes of a workgroup, one PCIe read, the rest through LDS (2500 such reads beside a launch cost it
+// ~1 us, 10^4 -- one per wave -- 2.5 us: same file).  No fence, no flag between workgroups: an agent-scope acquire
+// inside a kernel invalidates the L2 of its XCD (a first version in which the task workgroups waited for the copy
+// and read the device blob made a call 60 us longer).  The host may refill the pinned blob once every workgroup here
+// has read its task: it is told by the first workgroup of the NEXT kernel of the queue (K_PATCH_ROWS, ParamFlag).
+struct ParamCopy {
+    uint4* dst;
+    const uint4* src;
+    int n16;                        // 0: no copy in this launch (tp is device memory)
+};
+struct ParamFlag {
+    unsigned long long* flag;
+    unsigned long long seq;
+};
+
 template <bool F64>
 __global__ void __launch_bounds__(256) k_patch_gen(int ndir, const TaskPar* __restrict__ tp,
                                                    const double* __restrict__ aotab, double cfit,
-                                                   double* __restrict__ P) {
+                                                   double* __restrict__ P, ParamCopy pc) {
     constexpr int NEWTON = F64 ? 2 : 1;
+    constexpr int TPW = sizeof(TaskPar) / 8;
+    static_assert(sizeof(TaskPar) % 8 == 0, "TaskPar is read in 8-byte words");
+    __shared__ unsigned long long tps[TPW];
+    const int task = blockIdx.y;
+    TaskPar p;
+    if (pc.n16 > 0) {
+        if (blockIdx.y == gridDim.y - 1) {
+            constexpr int PER = 4;
+            for (int base = blockIdx.x * 256 * PER; base < pc.n16; base += gridDim.x * 256 * PER) {
+                uint4 v[PER];
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const int i = base + q * 256 + (int)threadIdx.x;
+                    if (i < pc.n16) v[q] = pc.src[i];
+                }
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const int i = base + q * 256 + (int)threadIdx.x;
+                    if (i < pc.n16) pc.dst[i] = v[q];
+                }
+            }
+            return;
+        }
+        if (threadIdx.x < TPW)
+            tps[threadIdx.x] = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(tp + task) + threadIdx.x);
+        __syncthreads();
+        p = *reinterpret_cast<const TaskPar*>(tps);
+    } else {
+        p = tp[task];
+    }
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= NAO * NAO) return;
-    const int task = blockIdx.y;
-    const TaskPar p = tp[task];
     const int su = pix / NAO - NAO / 2, sv = pix % NAO - NAO / 2;
     const double fit = psd_fit_value<NEWTON>(su, sv, p, cfit);
     const int ia = su < 0 ? su + NAO : su, ib = sv < 0 ? sv + NAO : sv;
@@ -423,11 +472,40 @@ __global__ void __launch_bounds__(256) k_patch_gen(int ndir, const TaskPar* __re
 template <int N>
 constexpr size_t patch_rows_smem() { return (size_t)(N / 2 + 1) * (4 * (64 / series_lanes<N>()) + 1) * sizeof(cx<double>); }
 
-template <int N>
+// Round 6: the workgroups with blockIdx.y >= ntd are not rows of the patch: they compute the spectra of the chunk's
+// tip-tilt Moffat kernels (the body of K_KHAT, conv_frames.h; KR = float / double, void: none) -- a kernel of its
+// own at the head of every call until now (8 us alone, 16-48 us parked behind the other lane's K_OTF_MFMA2 in the
+// pipelined run) whose LDS footprint is this kernel's.  Workgroup (0, 0) hands the pinned parameter blob back to the
+// host (ParamFlag above: the kernel in front of this one was its last reader).
+struct KhatArgs {
+    int nker;
+    const double* gam;
+    const double* alp;
+    void* khat;
+};
+
+template <int N, typename KR>
+constexpr size_t patch_rows_smem_all() {
+    if constexpr (std::is_void<KR>::value) return patch_rows_smem<N>();
+    else return patch_rows_smem<N>() > conv_smem_bytes<KR>(true) ? patch_rows_smem<N>() : conv_smem_bytes<KR>(true);
+}
+
+template <int N, typename KR>
 __global__ void __launch_bounds__(256) k_patch_rows(const double* __restrict__ P,
                                                     const cx<double>* __restrict__ twk,
-                                                    cx<double>* __restrict__ T, double* __restrict__ sp, int qb) {
+                                                    cx<double>* __restrict__ T, double* __restrict__ sp, int qb,
+                                                    int ntd, KhatArgs kh, ParamFlag pf) {
     constexpr int L = series_lanes<N>(), R = 64 / L, Q = N / L, H1 = N / 2 + 1, NJ = fold_nj<Q>();
+    if (pf.flag != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(pf.flag, pf.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if constexpr (!std::is_void<KR>::value) {
+        if ((int)blockIdx.y >= ntd) {
+            extern __shared__ __align__(16) unsigned char smem_k[];
+            const int kid = ((int)blockIdx.y - ntd) * (int)gridDim.x + (int)blockIdx.x;
+            if (kid < kh.nker) khat_body<KR>(kh.gam, kh.alp, (cx<KR>*)kh.khat, smem_k, kid);
+            return;
+        }
+    }
     constexpr bool WJREG = NJ <= 10;
     constexpr int NY = Q / 2 + 1;                        // values y = L k1 + k2 <= N/2 of a lane
     constexpr int RG = 4 * R, RS = RG + 1;               // rows per pass of the workgroup; padded tile row
@@ -902,12 +980,23 @@ void launch_series_coef(hipStream_t s, int N, const double* d_planes, void* d_co
 }
 
 void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const double* d_aotab,
-                  double cfit, const void* d_twk, double* d_P, void* d_T, double* d_sp, bool f64) {
-    const dim3 ggrid((NAO * NAO + 255) / 256, ntd / ndir);
+                  double cfit, const void* d_twk, double* d_P, void* d_T, double* d_sp, bool f64,
+                  const PatchExtras& x) {
+    const int ntask = ntd / ndir;
+    const bool copy = x.blob_src != nullptr;
+    const dim3 ggrid((NAO * NAO + 255) / 256, ntask + (copy ? 1 : 0));
+    ParamCopy pc;
+    pc.dst = (uint4*)x.blob_dst; pc.src = (const uint4*)x.blob_src; pc.n16 = copy ? (int)(x.blob_bytes / 16) : 0;
+    // (with the blob in this launch the task parameters are read where the host wrote them)
+    if (copy) d_tp = x.tp_host;
     if (f64)
-        hipLaunchKernelGGL(k_patch_gen<true>, ggrid, dim3(256), 0, s, ndir, d_tp, d_aotab, cfit, d_P);
+        hipLaunchKernelGGL(k_patch_gen<true>, ggrid, dim3(256), 0, s, ndir, d_tp, d_aotab, cfit, d_P, pc);
     else
-        hipLaunchKernelGGL(k_patch_gen<false>, ggrid, dim3(256), 0, s, ndir, d_tp, d_aotab, cfit, d_P);
+        hipLaunchKernelGGL(k_patch_gen<false>, ggrid, dim3(256), 0, s, ndir, d_tp, d_aotab, cfit, d_P, pc);
+    ParamFlag pf;
+    pf.flag = copy ? x.flag : nullptr; pf.seq = x.seq;
+    KhatArgs kh;
+    kh.nker = x.khat_n; kh.gam = x.khat_gam; kh.alp = x.khat_alp; kh.khat = x.khat_out;
     DISPATCH_N(N, {
         constexpr int NG = NAO * series_lanes<NN>() / 256;       // passes (of 4 x 64 / L rows) per td
         // passes per workgroup: around 512 workgroups in all (1024: +2 us at 512^2, +4 at 1280^2; 256: +2)
@@ -916,10 +1005,23 @@ void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, 
         if (nb < 1) nb = 1;
         const int qb = (NG + nb - 1) / nb;
         nb = (NG + qb - 1) / qb;
-        constexpr size_t sm = patch_rows_smem<NN>();
-        allow_smem((k_patch_rows<NN>), sm);
-        hipLaunchKernelGGL((k_patch_rows<NN>), dim3(nb, ntd), dim3(256), sm, s, (const double*)d_P,
-                           (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), (cx<double>*)d_T, d_sp, qb);
+        const int ky = kh.nker > 0 ? (kh.nker + nb - 1) / nb : 0;       // rows of workgroups for the kernel spectra
+        if (kh.nker <= 0) {
+            constexpr size_t sm = patch_rows_smem_all<NN, void>();
+            allow_smem((k_patch_rows<NN, void>), sm);
+            hipLaunchKernelGGL((k_patch_rows<NN, void>), dim3(nb, ntd), dim3(256), sm, s, (const double*)d_P,
+                               (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), (cx<double>*)d_T, d_sp, qb, ntd, kh, pf);
+        } else if (x.khat_f64) {
+            constexpr size_t sm = patch_rows_smem_all<NN, double>();
+            allow_smem((k_patch_rows<NN, double>), sm);
+            hipLaunchKernelGGL((k_patch_rows<NN, double>), dim3(nb, ntd + ky), dim3(256), sm, s, (const double*)d_P,
+                               (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), (cx<double>*)d_T, d_sp, qb, ntd, kh, pf);
+        } else {
+            constexpr size_t sm = patch_rows_smem_all<NN, float>();
+            allow_smem((k_patch_rows<NN, float>), sm);
+            hipLaunchKernelGGL((k_patch_rows<NN, float>), dim3(nb, ntd + ky), dim3(256), sm, s, (const double*)d_P,
+                               (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), (cx<double>*)d_T, d_sp, qb, ntd, kh, pf);
+        }
     })
 }
 

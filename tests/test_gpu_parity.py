@@ -584,6 +584,106 @@ def test_consecutive_calls_overlap_on_lanes_and_stay_ordered_per_buffer(api):
     ctx.close()
 
 
+@pytest.mark.parametrize('prec', ['mixed', 'f64'])
+def test_reserved_cus_and_head_fusion_change_no_bit(api, prec):
+    """Round 6: where the work of a call is queued changes no bit of its results -- the persistent grids of
+    K_OTF_MFMA2 / K_DPHI_SERIES with R CUs left free ("persist_reserve": 0, 32, 100, automatic), the kernel spectra of
+    the tip-tilt kernels as workgroups of K_PATCH_ROWS or as a kernel of their own ("head_fusion"), the parameter
+    blob fetched by workgroups of K_PATCH_GEN ("copy_fusion") -- for host-output calls (one chunk, several chunks on
+    two lanes) and for lean device-output calls queued back to back (series form of stage A: 512^2)."""
+    import torch
+    from muse_psfr_amd import NFIT
+    n = 37
+    see, gl, l0 = api.synthetic_rows(n, seed=77)
+    three = (np.arange(n) % 4 == 0).astype(np.uint8)
+    lb = np.linspace(480, 930, 7)
+    ps = api.grid_pixscale(512)
+    dev = torch.device('cuda', 0)
+    variants = (('base', {'persist_reserve': 0, 'head_fusion': 0}),
+                ('reserve32', {'persist_reserve': 32, 'head_fusion': 0}),
+                ('reserve100_fused', {'persist_reserve': 100}),
+                ('defaults', {}),
+                ('copy_fused', {'copy_fusion': 1}),
+                ('copy_fused_chunks', {'copy_fusion': 1, 'chunk_tasks': 10, 'streams': 2}),
+                ('fused_chunks', {'chunk_tasks': 10, 'streams': 2}))
+    ref = None
+    for key, opts in variants:
+        ctx = api.Context(dim=512, pixscale=ps, precision=prec)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        for _ in range(2):                                   # (the second call finds every table cached)
+            r = ctx.reconstruct(lb, see, gl, l0, three, H)
+        # lean calls: device outputs, no host synchronisation in between, buffers reused
+        fits = [torch.zeros((n, 7, NFIT), dtype=torch.float64, device=dev) for _ in range(2)]
+        sums = [torch.zeros((7, 40, 40), dtype=torch.float64, device=dev) for _ in range(2)]
+        torch.cuda.synchronize()
+        for rep in range(6):
+            ctx.reconstruct_device(lb, see, gl, l0, three, H, 12.0, 1, None, None, sums[rep % 2].data_ptr(),
+                                   fits[rep % 2].data_ptr())
+        ctx.sync()
+        if ref is None:
+            ref = r
+        for name in ('psf', 'fit', 'psf_sum'):
+            if name == 'psf_sum' and 'chunk_tasks' in opts:  # (per-lane partial sums: another order of additions)
+                np.testing.assert_allclose(r[name], ref[name], rtol=1e-13, err_msg=key)
+            else:
+                assert np.array_equal(r[name], ref[name]), (key, name)
+        if 'chunk_tasks' not in opts:
+            for b in range(2):
+                assert np.array_equal(fits[b].cpu().numpy(), ref['fit']), (key, b)
+                assert np.array_equal(sums[b].cpu().numpy(), ref['psf_sum']), (key, b)
+        ctx.close()
+    with pytest.raises(api.MpsfrError):
+        api.Context(dim=512, pixscale=ps).set_option('persist_reserve', 300)
+
+
+def test_stream_wait_hands_results_to_a_caller_stream(api):
+    """mpsfr_stream_wait is how `bench.py --gpus N` hands a call's device outputs to the stream of the
+    collectives.  Lean calls (device outputs, one lane, the context's stream never asked for) into REUSED buffers;
+    the caller's stream waits through stream_wait and copies with no host synchronisation: the copies equal the
+    blocking call's results bit for bit -- also with the chunks of a call on two lanes (the join + stream_tail case)."""
+    import torch
+    from muse_psfr_amd import NFIT
+    n, nl = 60, 9
+    lb = np.linspace(465, 930, nl)
+    ps = api.grid_pixscale(512)
+    dev = torch.device('cuda', 0)
+    batches = [api.synthetic_rows(n, seed=900 + k) for k in range(4)]
+    z = np.zeros(n, np.uint8)
+    ref = api.Context(dim=512, pixscale=ps)
+    want = [ref.reconstruct(lb, *b, z, H, want_psf=False) for b in batches]
+    ref.close()
+    for opts in ({}, {'chunk_tasks': 16, 'streams': 2}):
+        ctx = api.Context(dim=512, pixscale=ps)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        fit = torch.zeros((n, nl, NFIT), dtype=torch.float64, device=dev)
+        psum = torch.zeros((nl, 40, 40), dtype=torch.float64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        got_fit, got_sum = [], []
+        torch.cuda.synchronize()
+        for k, b in enumerate(batches):
+            # the call that overwrites the buffers waits for the copy that last read them
+            if k:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                ctx.wait_event(ev.cuda_event)
+            ctx.reconstruct_device(lb, *b, z, H, 12.0, 1, None, None, psum.data_ptr(), fit.data_ptr())
+            ctx.stream_wait(side.cuda_stream)
+            with torch.cuda.stream(side):
+                got_fit.append(fit.clone())
+                got_sum.append(psum.clone())
+        side.synchronize()
+        ctx.sync()
+        for k in range(len(batches)):
+            assert np.array_equal(got_fit[k].cpu().numpy(), want[k]['fit']), (opts, k)
+            if opts:
+                np.testing.assert_allclose(got_sum[k].cpu().numpy(), want[k]['psf_sum'], rtol=1e-13)
+            else:
+                assert np.array_equal(got_sum[k].cpu().numpy(), want[k]['psf_sum']), (opts, k)
+        ctx.close()
+
+
 def _oracle_rows(api, lb, see, gl, l0, three, dim, ps, npl, rows, lam_idx):
     """Oracle (fit, final stamps) for a sample of rows at a sample of wavelengths."""
     out = {}
