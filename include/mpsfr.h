@@ -276,9 +276,10 @@ int mpsfr_host_time(mpsfr_ctx* ctx, double* seconds, long* calls);
  *   "pre"        [chunk tasks][nl][dimpsf][dimpsf] stamps before the convolutions (psfrec.py:685)
  *   "vkeep"      [chunk tasks][(nl+1)/2] lines of the half plane transformed per wavelength pair
  *                (option "prune_eps")
- *   "mf_work"    [5] (the first 3 if capacity < 5) matrix-core stage, last chunk: tile steps executed,
+ *   "mf_work"    [7] (the first 3 / 5 if capacity < 5 / 7) matrix-core stage, last chunk: tile steps executed,
  *                m-tiles with a second pass, tile steps without pruning, tile steps with all three
- *                products, tile steps without the low half of the OTF
+ *                products, tile steps without the low half of the OTF, blocks kept by at least one
+ *                wavelength summed over the tasks, blocks inside the support of the telescope OTF x tasks
  * Returns the number of doubles written (<= capacity) or a negative error. */
 long mpsfr_debug_fetch(mpsfr_ctx* ctx, const char* what, double* out, size_t capacity);
 

@@ -130,7 +130,11 @@ void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, 
                   const PatchExtras& x = PatchExtras());
 void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const void* d_T,
                         const double* d_sp, const void* d_coef, const void* d_twk, double scale2,
-                        void* d_D0t, float* d_dlin, bool f64out, int* d_zero, int ncu);
+                        void* d_D0t, float* d_dlin, bool f64out, int* d_zero, int ncu,
+                        const unsigned* d_support = nullptr);
+// d_support [N/2+1]: per line, the pieces of series_lanes(N) columns inside the support of the telescope OTF
+// (launch_series_support from d_tel, once per context); launch_dphi_series neither evaluates nor stores the others
+void launch_series_support(hipStream_t s, int N, const void* d_tel, bool f64, unsigned* d_support);
 // d_dlin: [ntd][N/2+1][N/32] minima of max(D, 0) per line and block of 32 columns, written by
 // launch_dphi_series when not nullptr; launch_dmin16 turns them into what launch_dmin computes from D
 void launch_dmin16(hipStream_t s, int N, int ntd, const float* d_dlin, float* d_dline, float* d_dblk);

@@ -69,6 +69,8 @@ struct mpsfr_ctx {
     int reserve_mf = -1, reserve_a = -1;
     // the parameter blob and the tip-tilt kernel spectra ride in the two launches of the patch (series form of stage A)
     bool head_fusion = true;
+    // stage A (series form) skips what lies outside the support of the telescope OTF
+    bool support_skip = true;
     bool copy_fusion = false;
     double pixscale = 0.2;
     bool f64 = false;
@@ -98,7 +100,7 @@ struct mpsfr_ctx {
                                  // transforms, 2 = series + patch form on every grid
     DevBuf mfclk;
     // constant tables
-    DevBuf tw64, tel, rows, tlmax, tl2, tlb, scoef, stwk;
+    DevBuf tw64, tel, rows, tlmax, tl2, tlb, scoef, stwk, ssup;
     // per-call tables
     DevBuf aotab, samp_p, samp_a, G, kmuse, xtab, etab, gtab;
     // Pipeline lanes: each lane owns a HIP stream and a set of chunk workspaces.  Consecutive
@@ -444,6 +446,8 @@ int build_series_tables(mpsfr_ctx* c) {
     launch_series_coef(c->stream, N, (const double*)planes.p, c->scoef.p, c->f64);
     if ((rc = ensure(c, c->stwk, series_twiddle_bytes(N)))) return done(rc);
     launch_series_twiddles(c->stream, N, c->tw64.p, c->stwk.p);
+    if ((rc = ensure(c, c->ssup, (size_t)H1 * sizeof(unsigned)))) return done(rc);
+    launch_series_support(c->stream, N, c->tel.p, c->f64, (unsigned*)c->ssup.p);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
         return done(fail(MPSFR_E_HIP, "building the series tables of stage A failed"));
     return done(MPSFR_OK);
@@ -598,7 +602,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         release(tk.dsum);
         release(tk.dfit);
     }
-    DevBuf* all[] = {&c->scoef, &c->stwk, &c->tw64, &c->tel, &c->rows, &c->tlmax, &c->tl2, &c->tlb, &c->aotab, &c->samp_p,
+    DevBuf* all[] = {&c->scoef, &c->stwk, &c->ssup, &c->tw64, &c->tel, &c->rows, &c->tlmax, &c->tl2, &c->tlb, &c->aotab, &c->samp_p,
                      &c->samp_a, &c->G, &c->xtab, &c->etab, &c->gtab, &c->kmuse, &c->fit, &c->sum,
                      &c->stage, &c->lsum, &c->mfclk};
     for (auto b : all) release(*b);
@@ -660,6 +664,8 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         if (value != (int)value || value < -1.0 || value > 128.0) return fail(MPSFR_E_INVALID, "%s must be -1 (automatic) or 0..128", key);
         if (key[15] == '\0' || key[16] == 'm') c->reserve_mf = (int)value;
         if (key[15] == '\0' || key[16] == 'a') c->reserve_a = (int)value;
+    } else if (!strcmp(key, "support_skip")) {
+        c->support_skip = value != 0.0;
     } else if (!strcmp(key, "head_fusion")) {
         c->head_fusion = value != 0.0;
     } else if (!strcmp(key, "copy_fusion")) {
@@ -1421,7 +1427,8 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             ProfScope ps(c, K_DPHI_SERIES, ls);
             launch_dphi_series(ls, N, ntd, ndir, d_tp + t0, ln.pT.p, (const double*)ln.psp.p, c->scoef.p,
                                c->stwk.p, scale2, ln.D0t.p, prune ? (float*)ln.dlin.p : nullptr, c->f64,
-                               mf2 ? (int*)ln.msched.p : nullptr, persist_grid(c, ln, c->reserve_a, lanes_shared));
+                               mf2 ? (int*)ln.msched.p : nullptr, persist_grid(c, ln, c->reserve_a, lanes_shared),
+                               c->support_skip ? (const unsigned*)c->ssup.p : nullptr);
         } else {
             {
                 ProfScope ps(c, K_PSD_ROWFFT, ls);
@@ -1859,7 +1866,7 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
             HIPCHK(hipMemcpy(dm.data(), ln.dminb.p, dm.size() * sizeof(float), hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(tb.data(), c->tlb.p, tb.size() * sizeof(float), hipMemcpyDeviceToHost));
         }
-        double steps = 0.0, tiles = 0.0, steps_full = 0.0, steps_mid = 0.0;
+        double steps = 0.0, tiles = 0.0, steps_full = 0.0, steps_mid = 0.0, steps_union = -1.0, steps_support = -1.0;
         if (c->last_mf2) {          // the masks the thin-wave kernel ran on (K_MF_PREP)
             std::vector<unsigned long long> own((size_t)tc * nl * nmt * 2);
             HIPCHK(hipMemcpy(own.data(), ln.mown.p, own.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1870,6 +1877,22 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
                 tiles += (nf + nm) > 0;
             }
             steps = steps_full + steps_mid;
+            // the blocks ANY wavelength of a task keeps (what stage A has to deliver at all), and the blocks inside
+            // the support of the telescope OTF
+            steps_union = 0.0;
+            for (int t = 0; t < tc; ++t)
+                for (int mt = 0; mt < nmt; ++mt) {
+                    unsigned long long u = 0;
+                    for (int l = 0; l < nl; ++l) {
+                        const size_t i = (((size_t)t * nl + l) * nmt + mt) * 2;
+                        u |= own[i] | own[i + 1];
+                    }
+                    steps_union += __builtin_popcountll(u);
+                }
+            HIPCHK(hipMemcpy(tb.data(), c->tlb.p, tb.size() * sizeof(float), hipMemcpyDeviceToHost));
+            steps_support = 0.0;
+            for (size_t i = 0; i < tb.size(); ++i) steps_support += std::isfinite(tb[i]) ? 1.0 : 0.0;
+            steps_support *= tc;
         } else {
         std::vector<float> thrf((size_t)tc, -1.0e30f);
         if (c->last_pruned && c->last_floor_per_task)
@@ -1896,7 +1919,10 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
         if (capacity < 5) return 3;
         out[3] = steps_full;         // tile steps with all three products (9 MFMA)
         out[4] = steps_mid;          // tile steps without the low half of the OTF (6 MFMA)
-        return 5;
+        if (capacity < 7) return 5;
+        out[5] = steps_union;        // blocks kept by at least one wavelength, summed over the tasks (-1: not the thin-wave kernel)
+        out[6] = steps_support;      // blocks with a non-zero telescope OTF, times the tasks
+        return 7;
     } else if (!strcmp(what, "mf_clock")) {
         if (!c->mfclk.p) return fail(MPSFR_E_INVALID, "mf_clock is off");
         n = capacity < (size_t)65536 * 64 ? capacity : (size_t)65536 * 64;

@@ -598,8 +598,13 @@ template <int N, typename RO, int L>
 __device__ __forceinline__ void series_line(const cx<double>* xv, const cx<double>* wjp,
                                             const cx<double>* swr, const RO* scoef, double r0m53,
                                             double delta, double spv, double scale2, RO* dst, float* dlin,
-                                            bool valid, int lane) {
+                                            bool valid, int lane, unsigned kmask) {
+    // kmask (wave-uniform): bit k1 set = some column x in [L k1, L k1 + L) of this line lies inside the support of
+    // the telescope OTF (K_SERIES_SUPPORT).  Outside it the OTF is identically zero whatever the structure function
+    // (psfrec.py:784-797): the polynomial, the store and the minimum of such a piece are skipped -- 21 % of the half
+    // plane; what the per-wavelength stage reads there is the zero the buffer was allocated with.
     constexpr int Q = N / L, K = SeriesCfg<RO>::K;
+    constexpr float kSkipped = 3.0e38f;
     const int k2 = lane & (L - 1);
     double xr[kNX], xi[kNX];
 #pragma unroll
@@ -664,6 +669,10 @@ __device__ __forceinline__ void series_line(const cx<double>* xv, const cx<doubl
         const float df = (float)delta, rf = (float)r0m53;
 #pragma unroll
         for (int k1 = 0; k1 < Q; ++k1) {
+            if (!((kmask >> k1) & 1u)) {
+                dq[k1] = kSkipped;
+                continue;
+            }
             const float4 h = *reinterpret_cast<const float4*>(scoef + (size_t)(L * k1 + k2) * K);
             const float dF = rf * fmaf(fmaf(fmaf(h.w, df, h.z), df, h.y), df, h.x);
             const float d = (float)(fma(scale2, spv - out[k1], (double)dF));
@@ -673,6 +682,10 @@ __device__ __forceinline__ void series_line(const cx<double>* xv, const cx<doubl
     } else {
 #pragma unroll
         for (int k1 = 0; k1 < Q; ++k1) {
+            if (!((kmask >> k1) & 1u)) {
+                dq[k1] = kSkipped;
+                continue;
+            }
             const double* h = scoef + (size_t)(L * k1 + k2) * K;
             double a = h[K - 1];
 #pragma unroll
@@ -752,7 +765,7 @@ __global__ void __launch_bounds__((series_threads<N, RO>()), (512 / series_threa
 k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
               const TaskPar* __restrict__ tp, int ndir, int ntd, const RO* __restrict__ coef,
               const cx<double>* __restrict__ twk, double scale2, RO* __restrict__ D0t,
-              float* __restrict__ dlin, int* __restrict__ zero17) {
+              float* __restrict__ dlin, int* __restrict__ zero17, const unsigned* __restrict__ support) {
     constexpr int L = series_lanes<N>(), R = 64 / L, Q = N / L, H1 = N / 2 + 1, K = SeriesCfg<RO>::K;
     constexpr int THREADS = series_threads<N, RO>(), NW = THREADS / 64, NJ = fold_nj<Q>();
     constexpr bool WJREG = NJ <= 10;         // the twiddles W_L^(j k2) of a lane in registers
@@ -808,9 +821,10 @@ k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
 #pragma unroll
             for (int j = 0; j < NJ; ++j) wl[j] = twk[j * L + k2];
         }
+        const unsigned kmask = support != nullptr ? (unsigned)__builtin_amdgcn_readfirstlane((int)support[y]) : 0xffffffffu;
         series_line<N, RO, L>(xv, WJREG ? wjr : wl, swr, scoef + (size_t)(y & 1) * LINE, r0m53, delta, spv, scale2,
                               D0t + ((size_t)td * H1 + y) * N + k2,
-                              dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, valid, lane);
+                              dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, valid, lane, kmask);
     };
     // every wave runs the same number of rounds (the barriers below are met by all of them); a round
     // is one unit per active wave: c = cb + wave.  (With fewer units per y than waves a round would
@@ -853,7 +867,7 @@ __global__ void __launch_bounds__(256)
 k_dphi_series1(const cx<double>* __restrict__ T, const double* __restrict__ sp,
                const TaskPar* __restrict__ tp, int ndir, int ntd, int tg, const RO* __restrict__ coef,
                const cx<double>* __restrict__ twk, double scale2, RO* __restrict__ D0t,
-               float* __restrict__ dlin, int* __restrict__ zero17) {
+               float* __restrict__ dlin, int* __restrict__ zero17, const unsigned* __restrict__ support) {
     constexpr int Q = N / 64, H1 = N / 2 + 1, K = SeriesCfg<RO>::K, THREADS = 256;
     constexpr int NJ = fold_nj<Q>(), JMIN = fold_jmin<Q>();
     constexpr bool WJREG = NJ <= 10;
@@ -887,6 +901,7 @@ k_dphi_series1(const cx<double>* __restrict__ T, const double* __restrict__ sp,
         for (int j = 0; j < NJ; ++j) wjr[j] = twk[j * 64 + lane];
     }
     __syncthreads();
+    const unsigned kmask = support != nullptr ? (unsigned)__builtin_amdgcn_readfirstlane((int)support[y]) : 0xffffffffu;
     auto line = [&](int td, const cx<double>* xv) {
         const int task = td / ndir;
         const double r0m53 = tp[task].r0m53, delta = tp[task].inv_l0sq - kEps0;
@@ -898,7 +913,7 @@ k_dphi_series1(const cx<double>* __restrict__ T, const double* __restrict__ sp,
         }
         series_line<N, RO, 64>(xv, WJREG ? wjr : wl, swr, scoef, r0m53, delta, spv, scale2,
                                D0t + ((size_t)td * H1 + y) * N + lane,
-                               dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, true, lane);
+                               dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, true, lane, kmask);
     };
     constexpr int STEP = THREADS / 64;
     while (td < td_end) {
@@ -910,6 +925,21 @@ k_dphi_series1(const cx<double>* __restrict__ T, const double* __restrict__ sp,
         line(td, xvb);
         td += STEP;
     }
+}
+
+// K_SERIES_SUPPORT: support[y] bit k1 = some column x in [L k1, L k1 + L) of line y has a non-zero telescope OTF
+// (L = series_lanes<N>(): the pieces a lane of K_DPHI_SERIES owns).  Once per context.
+template <int N, typename RT>
+__global__ void __launch_bounds__(64) k_series_support(const RT* __restrict__ tel, unsigned* __restrict__ support) {
+    constexpr int L = series_lanes<N>(), Q = N / L;
+    const int y = blockIdx.x, lane = threadIdx.x;
+    unsigned m = 0;
+    for (int k1 = 0; k1 < Q; ++k1) {
+        bool any = false;
+        for (int x = L * k1 + lane; x < L * k1 + L; x += 64) any = any || tel[(size_t)y * N + x] > (RT)0;
+        if (__ballot(any) != 0ull) m |= 1u << k1;
+    }
+    if (lane == 0) support[y] = m;
 }
 
 // Hd planes [K][H1][N] (fp64, the output of K_COLFFT_DPHI for the basis tasks) -> coef[y][x][K]
@@ -969,6 +999,15 @@ void launch_series_twiddles(hipStream_t s, int N, const void* d_tw64, void* d_tw
 int series_terms(bool f64) { return f64 ? SeriesCfg<double>::K : SeriesCfg<float>::K; }
 double series_eps0() { return kEps0; }
 
+void launch_series_support(hipStream_t s, int N, const void* d_tel, bool f64, unsigned* d_support) {
+    DISPATCH_N(N, {
+        if (f64)
+            hipLaunchKernelGGL((k_series_support<NN, double>), dim3(NN / 2 + 1), dim3(64), 0, s, (const double*)d_tel, d_support);
+        else
+            hipLaunchKernelGGL((k_series_support<NN, float>), dim3(NN / 2 + 1), dim3(64), 0, s, (const float*)d_tel, d_support);
+    })
+}
+
 void launch_series_coef(hipStream_t s, int N, const double* d_planes, void* d_coef, bool f64) {
     const int n = (N / 2 + 1) * N;
     if (f64)
@@ -1027,7 +1066,7 @@ void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, 
 
 void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const void* d_T,
                         const double* d_sp, const void* d_coef, const void* d_twk, double scale2,
-                        void* d_D0t, float* d_dlin, bool f64out, int* d_zero, int ncu) {
+                        void* d_D0t, float* d_dlin, bool f64out, int* d_zero, int ncu, const unsigned* d_support) {
     const int H1 = N / 2 + 1;
     auto first_form = [&](auto kernel, size_t sm) {
         // task groups: enough workgroups to fill the GPU several times over, every workgroup's table load
@@ -1048,21 +1087,21 @@ void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* 
                 allow_smem((k_dphi_series<NN, double>), sm);
                 hipLaunchKernelGGL((k_dphi_series<NN, double>), dim3(ncu), dim3(series_threads<NN, double>()), sm, s,
                                    (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, (const double*)d_coef,
-                                   (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), scale2, (double*)d_D0t, d_dlin, d_zero);
+                                   (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), scale2, (double*)d_D0t, d_dlin, d_zero, d_support);
             } else {
                 constexpr size_t sm = series1_smem<NN, double>();
                 allow_smem((k_dphi_series1<NN, double>), sm);
                 const auto gt = first_form(0, sm);
                 hipLaunchKernelGGL((k_dphi_series1<NN, double>), gt.first, dim3(256), sm, s,
                                    (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, gt.second, (const double*)d_coef,
-                                   (const cx<double>*)d_twk, scale2, (double*)d_D0t, d_dlin, d_zero);
+                                   (const cx<double>*)d_twk, scale2, (double*)d_D0t, d_dlin, d_zero, d_support);
             }
         } else {
             constexpr size_t sm = series_smem<NN, float>();
             allow_smem((k_dphi_series<NN, float>), sm);
             hipLaunchKernelGGL((k_dphi_series<NN, float>), dim3(ncu), dim3(series_threads<NN, float>()), sm, s,
                                (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, (const float*)d_coef,
-                               (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), scale2, (float*)d_D0t, d_dlin, d_zero);
+                               (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), scale2, (float*)d_D0t, d_dlin, d_zero, d_support);
         }
     })
 }

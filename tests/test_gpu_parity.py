@@ -58,7 +58,13 @@ def test_every_stage_against_the_oracle(api, dim, npl, prec):
     for k, (s, g_, l, th) in enumerate(cases):
         psd = O.residual_psd([g_, 1 - g_], H, s, l, npl, dim, bool(th), tables=tabs[th])
         od0 = np.array([O.structure_function0(p) for p in psd])
-        assert rel_err(d0[k], np.swapaxes(od0, -1, -2)[:, :dim // 2 + 1, :]) < eps
+        od0 = np.swapaxes(od0, -1, -2)[:, :dim // 2 + 1, :]
+        # (the series form of stage A neither evaluates nor stores the structure function where the telescope
+        # OTF vanishes, psfrec.py:784-797: there the buffer keeps the zero it was allocated with)
+        inside = np.broadcast_to(tel > 0, d0[k].shape)
+        assert np.abs(d0[k] - od0)[inside].max() / np.abs(od0).max() < eps
+        out = d0[k][~inside]          # (whole pieces of a line outside the support are skipped, the others computed)
+        assert np.all((out == 0) | (np.abs(out - od0[~inside]) / np.abs(od0).max() < eps))
         opre = O.psf_stamps_refshaped(psd, lb, 40, ps)
         assert rel_err(pre[k], opre) < TOL[prec]['stamp']
         ofin = O.convolve_final_psf(lb, s, g_, l, opre, ps)
@@ -868,6 +874,7 @@ def test_series_form_of_stage_a_against_the_full_size_transforms(api, dim, npl, 
         ctx.set_option('stage_a', mode)
         r = ctx.reconstruct(lb, see, gl, l0, three, H, npsflin=npl)
         d0 = ctx.debug_fetch('dphi0', (see.size, ndir, dim // 2 + 1, dim))
+        tel = ctx.debug_fetch('tel', (dim // 2 + 1, dim))
         if mode == 2:       # an outer scale below the radius of the expansion: the call falls back by itself
             r_short = ctx.reconstruct(lb, see[:2], gl[:2], np.array([5.0, 25.0]), three[:2], H, npsflin=npl)
         ctx.close()
@@ -879,8 +886,21 @@ def test_series_form_of_stage_a_against_the_full_size_transforms(api, dim, npl, 
     np.testing.assert_array_equal(r_short['psf'], r_short0['psf'])
     (ra, da), (rb, db) = res[0], res[2]
     tol_d = 1.5e-7 if prec == 'mixed' else 1e-14
+    # The series form skips the pieces of a line (series_lanes(N) = 16 / 32 / 64 columns) on which the telescope OTF
+    # vanishes identically: compared is the kept region; the skipped one holds the zeros the buffer was allocated
+    # with, lies wholly outside the support (so the per-wavelength stage multiplies it by zero, psfrec.py:784-797),
+    # and is most of what lies outside it (21 % of the half plane).
+    inside = tel > 0
+    L = 16 if dim <= 256 else (32 if dim == 512 else 64)
+    zero = np.all(db == 0, axis=(0, 1))
+    skipped = np.repeat(zero.reshape(dim // 2 + 1, dim // L, L).all(axis=2), L, axis=1)      # whole pieces only
+    if dim >= 256:
+        assert not np.any(skipped & inside)
+        assert skipped.sum() > 0.6 * (~inside).sum(), (skipped.sum(), (~inside).sum())
+    kept = np.broadcast_to(~skipped, da[0].shape)
     for k in range(see.size):
-        assert np.abs(db[k] - da[k]).max() / np.abs(da[k]).max() < tol_d, (k, np.abs(db[k] - da[k]).max() / np.abs(da[k]).max())
+        err = np.abs(db[k] - da[k])[kept].max() / np.abs(da[k]).max()
+        assert err < tol_d, (k, err)
     peak = ra['psf'].max(axis=(2, 3), keepdims=True)
     dst = float((np.abs(rb['psf'] - ra['psf']) / peak).max())
     assert dst < (5e-7 if prec == 'mixed' else 1e-12), dst
