@@ -308,9 +308,14 @@ class Context:
                       float(wind_speed), int(npsflin), nl, _dptr(lbda), _u8ptr(mrec), _u8ptr(mres),
                       vp(psf), vp(psum), vp(fit)))
         except MpsfrError:
-            if _async:                      # (the library has abandoned the shards it had queued)
+            if _async:
+                # The library abandoned the shards it had queued on ctxs[0..k-1]; earlier reconstruct_async tickets
+                # of the failing and the later contexts are still pending in C with pointers into arrays this side
+                # would otherwise forget.  abandon() on EVERY context makes the two sides agree: the library drains
+                # and drops what it holds, and the tickets land in `_abandoned` so that a later wait() raises
+                # instead of handing back arrays nobody wrote.
                 for c in ctxs:
-                    c._pending.clear()
+                    c.abandon()
             raise
         if _async:
             # the library holds pointers into `arrays` until mpsfr_wait_multi: every context keeps them alive

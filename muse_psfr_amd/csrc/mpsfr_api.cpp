@@ -267,7 +267,9 @@ int complete_ticket(mpsfr_ctx* c, mpsfr_ctx::Ticket& tk) {
 // The event behind the lane's most recent call; a lean call queued none, so it is recorded here, at the lane's
 // present tail (at or behind the end of that call: conservative), when somebody needs to wait for the lane.
 hipEvent_t lane_end(mpsfr_ctx* c, mpsfr_ctx::Lane& ln) {
-    if (!ln.marked) {
+    // (a lane whose stream has been dropped -- "streams" / "cu_partition" reset -- has drained: nothing to record,
+    // and recording on the NULL stream would synchronise with every blocking stream)
+    if (!ln.marked && ln.stream != nullptr) {
         if (!ln.done) (void)hipEventCreateWithFlags(&ln.done, hipEventDisableTiming);
         (void)hipEventRecord(ln.done, ln.stream);
         ln.done_ev = ln.done;
@@ -637,6 +639,13 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
                 ln.ncu = 0;
             }
             HIPCHK(hipStreamSynchronize(c->stream));
+            // everything has drained: no slot is owed to a lane any more (a lean call leaves call_pending /
+            // last_lane behind, which the next call on another lane would chase through lane_end)
+            for (int k = 0; k < mpsfr_ctx::NSTAGE; ++k) {
+                c->slot[k].call_pending = false;
+                c->slot[k].last_lane = -1;
+                c->slot[k].staged_pending = false;
+            }
         }
         if (lanes) c->nlanes = (int)value;
         else c->cu_partition = (int)value;
@@ -1056,13 +1065,25 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
         if (sl.staged_mode == 2) {               // (only blocks once the host is NSTAGE calls ahead)
             volatile unsigned long long* flag = c->seq_host + (&sl - c->slot);
             const auto t_lim = tb + std::chrono::seconds(5);
-            while (*flag < sl.seq) {
-                if (std::chrono::steady_clock::now() > t_lim) {         // (a failed kernel never writes its flag)
+            // (spin briefly -- the flag is usually there: the host is NSTAGE calls ahead -- then yield the core
+            // between looks; a failed kernel never writes its flag: after 5 s the lane is synchronised instead)
+            for (long spins = 0; *flag < sl.seq; ++spins) {
+                if (spins < 4096) {
+#if defined(__x86_64__) || defined(__i386__)
+                    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+                    asm volatile("yield" ::: "memory");
+#endif
+                    continue;
+                }
+                std::this_thread::yield();
+                if ((spins & 255) == 0 && std::chrono::steady_clock::now() > t_lim) {
                     if (sl.last_lane >= 0 && c->lane[sl.last_lane].stream)
                         HIPCHK(hipStreamSynchronize(c->lane[sl.last_lane].stream));
+                    else
+                        HIPCHK(hipDeviceSynchronize());
                     break;
                 }
-                __builtin_ia32_pause();
             }
         } else {
             HIPCHK(hipEventSynchronize(sl.staged_ev));
