@@ -183,7 +183,11 @@ int mpsfr_reconstruct_multi(mpsfr_ctx* const* ctxs, int nctx, int ntask, const d
  * the per-row outputs to the caller's arrays and adds the shards' stamp sums in context order into the
  * psf_sum_out of the call.  One such call may be pending per ctxs[0]; the output arrays must stay allocated
  * until mpsfr_wait_multi returns (or mpsfr_abandon on every context gives them up).  Several tables -- or the
- * parts of one -- can so be kept in flight on several devices, like on_device = 2 does on one. */
+ * parts of one -- can so be kept in flight on several devices, like on_device = 2 does on one.
+ * A shard that fails (the error names its context) ABANDONS every pending asynchronous call of EVERY context of
+ * the call -- the shards already queued and any single on_device = 2 call still in flight on them: their arrays
+ * are never written, mpsfr_wait on their tickets fails.  The refusals made before anything is queued (NULL
+ * context, a multi-context call already pending on ctxs[0], contexts of different shape) touch nothing. */
 int mpsfr_reconstruct_multi_async(mpsfr_ctx* const* ctxs, int nctx, int ntask, const double* seeing,
                             const double* gl, const double* l0, const uint8_t* three_lgs,
                             const double h[2], double wind_speed, int npsflin, int nl,

@@ -303,6 +303,16 @@ class Context:
         handles = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
         fn = ctxs[0].lib.mpsfr_reconstruct_multi_async if _async else ctxs[0].lib.mpsfr_reconstruct_multi
         arrays = dict(psf=psf, psf_sum=psum, fit=fit)
+        if _async:
+            # the refusals the library makes BEFORE it queues anything are made here, with nothing touched:
+            # whatever the library itself reports below is a failed shard, after which it has abandoned every
+            # pending asynchronous call of every context of the call
+            if any(isinstance(t, tuple) for t in ctxs[0]._pending):
+                raise MpsfrError(-1, 'a multi-context call is pending on this context: wait for it first')
+            c0 = ctxs[0]
+            if any((c.dim, c.dimpsf, c.pixscale, c.precision) != (c0.dim, c0.dimpsf, c0.pixscale, c0.precision)
+                   for c in ctxs[1:]):
+                raise MpsfrError(-1, 'the contexts must share dim, dimpsf, pixscale and precision')
         try:
             _check(fn(handles, len(ctxs), nt, _dptr(seeing), _dptr(gl), _dptr(l0), _u8ptr(three), _dptr(hh),
                       float(wind_speed), int(npsflin), nl, _dptr(lbda), _u8ptr(mrec), _u8ptr(mres),

@@ -1728,9 +1728,11 @@ int mpsfr_reconstruct_multi_async(mpsfr_ctx* const* ctxs, int nctx, int ntask, c
                                          psf_sum_out ? m.sums.data() + (size_t)k * m.n : nullptr,
                                          fit_out ? fit_out + (size_t)a * nl * NFIT : nullptr, 2);
         if (rc != MPSFR_OK) {
-            // the shards already queued still point at the caller's arrays and at m.sums: give them up
+            // the shards already queued still point at the caller's arrays and at m.sums: give them up -- on EVERY
+            // context of the call, so that what is left pending does not depend on which shard failed (a caller
+            // that also has single asynchronous calls in flight on these contexts loses them: include/mpsfr.h)
             const std::string msg = g_err;
-            for (int q = 0; q < k; ++q) (void)mpsfr_abandon(ctxs[q]);
+            for (int q = 0; q < nctx; ++q) (void)mpsfr_abandon(ctxs[q]);
             return fail(rc, "context %d: %s", k, msg.c_str());
         }
         m.tickets[k] = mpsfr_last_ticket(ctxs[k]);
