@@ -51,8 +51,15 @@ typedef struct mpsfr_ctx mpsfr_ctx;
 /* fit_out[k]: 0 peak  1 p0 (row centre, px)  2 q0 (col centre, px)  3 alpha (px)  4 n (beta)
  *             5 fwhm (px) = 2 alpha sqrt(2^(1/n) - 1)   6 chi2   7 iterations
  *             8 err_peak  9 err_p0  10 err_q0  11 err_alpha  12 err_n  13 err_fwhm (px)
- *             14 status (0 converged, 1 iteration cap, 2 singular)  15 flux = peak pi alpha^2/(n-1)
+ *             14 status (0 converged, 1 iteration cap, 2 singular; + MPSFR_FIT_ILL_CONDITIONED: see below)
+ *             15 flux = peak pi alpha^2/(n-1)
+ * Status bit MPSFR_FIT_ILL_CONDITIONED (4): the least-squares minimum was found, but the stamp does not pin
+ * (fwhm, n) to the parity tolerance: n^2 sqrt((J^T J)^-1[eta, eta]) * peak >= 100, i.e. iid pixel noise of 1e-6 of
+ * the peak moves n by 1e-4 or more (the covariance is the one err_n comes from).  That is the case where the stamp
+ * is narrower than the PSF core (the 128^2 / 256^2 grids with the rescaled pixel scale, seeing > 2 arcsec at 512^2);
+ * on the 512^2 ... 1280^2 grids with the SPARTA range of inputs the number stays below 30.
  */
+#define MPSFR_FIT_ILL_CONDITIONED 4
 
 /* Side of the AO-corrected zone grid (psfrec.py:103, 138: Dimpup * 2). */
 #define MPSFR_DIM_AO       80

@@ -5,7 +5,7 @@ create_sparta_table, fit_psf_cube, muse_intrinsic_psf, fit_psf_with_polynom, and
 simul_psd_wfm, psf_muse, convolve_final_psf.
 Low level: Context (ctypes binding of libmpsfr.so).
 """
-from ._lib import Context, ContextPool, MpsfrError, NFIT  # noqa: F401
+from ._lib import Context, ContextPool, MpsfrError, NFIT, FIT_ILL_CONDITIONED  # noqa: F401
 from .synthetic import synthetic_rows, grid_pixscale  # noqa: F401
 from .psfrec import (MAX_L0, MIN_L0, compute_psf, compute_psf_from_sparta,  # noqa: F401
                      create_sparta_table, direction_perf, fit_psf_cube, fit_psf_with_polynom,

@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MPSFR_LIB_PATH') or os.path.join(HERE, 'libmpsfr.so')
 
 NFIT = 16
+FIT_ILL_CONDITIONED = 4      # status bit of fit_out[14] (MPSFR_FIT_ILL_CONDITIONED, include/mpsfr.h)
 DIM_AO = 80
 PREC_MIXED, PREC_F64 = 0, 1
 E_GRID = -3

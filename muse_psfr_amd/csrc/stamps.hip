@@ -868,6 +868,8 @@ __device__ __forceinline__ bool spd_inverse(const NormEqT<T>& ne, double cov[5][
 template <typename RE>
 constexpr int fit_min_waves() { return sizeof(RE) == 4 ? MPSFR_FIT_WAVES : 2; }
 
+constexpr double kFitIllCond = 100.0;       // MPSFR_FIT_ILL_CONDITIONED, include/mpsfr.h
+
 #ifndef MPSFR_FIT_MOMENT_START
 #define MPSFR_FIT_MOMENT_START 1
 #endif
@@ -1140,6 +1142,15 @@ k_fit(int nstamp, const TS* __restrict__ stamps, double* __restrict__ fit, doubl
             o[11] = sqrt(fmax(var * s, 0.0));
             o[12] = n * n * sqrt(fmax(cov[4][4] * s, 0.0));                        // |dn/d eta| = n^2
             o[13] = sqrt(fmax(cov[3][3] * s, 0.0));
+            // Ill-conditioned fits (status bit 4, round 6).  With iid pixel noise of standard deviation sigma the
+            // least-squares n has the standard deviation n^2 sqrt(cov[eta][eta]) sigma: the number below is that
+            // for sigma = the peak, i.e. the change of n per unit of relative pixel noise.  From kFitIllCond = 100
+            // on, noise of 1e-6 of the peak moves n by 1e-4 -- the parity tolerance -- or more: the minimum is
+            // still the minimum, but stamps known to a few 1e-7 of their peak (mixed precision) do not determine
+            // (fwhm, n) to the tolerance.  Stamps narrower than the PSF core are the case: 256^2 / 128^2 grids
+            // with the rescaled pixel scale (FWHM 30 px in a 40 px stamp: 180-200); the bench rows at 512^2 stay
+            // below 8 (profiles/r06_small_grid_margin.txt).
+            if (n * n * sqrt(fmax(cov[4][4], 0.0)) * fabs(vd[0]) >= kFitIllCond) status |= 4;
         } else {
             for (int k = 0; k < 6; ++k) o[8 + k] = 0.0;
             if (status == 0) status = 2;

@@ -26,7 +26,9 @@ for dim in (128, 256, 512, 1024, 1280):
         a, b = res['mixed'], res['f64']
         ok = all(np.isfinite(r[k]).all() for r in (a, b) for k in ('psf', 'fit', 'psf_sum'))
         ds = np.abs(a['psf'] - b['psf']).max() / b['psf'].max()
-        well = (b['fit'][..., 14] == 0) & (b['fit'][..., 4] < 20) & (b['fit'][..., 5] > 2.5)
+        # well-posed: status 0 in both precisions (round 6: the fit kernel flags stamps that do not pin (fwhm, n) to the
+        # tolerance -- MPSFR_FIT_ILL_CONDITIONED, from its own covariance -- instead of the ad-hoc  beta < 20 & fwhm > 2.5 px)
+        well = (b['fit'][..., 14] == 0) & (a['fit'][..., 14] == 0)
         df = np.abs(a['fit'][..., 5] - b['fit'][..., 5])[well].max() * 0.2 if well.any() else 0.0
         dn = np.abs(a['fit'][..., 4] - b['fit'][..., 4])[well].max() if well.any() else 0.0
         flag = '' if ok and ds < 1e-5 and df < 1e-4 and dn < 1e-4 else '   <-- CHECK'
