@@ -218,7 +218,10 @@ def e2e_sparta_leg(ncalls):
         med = float(np.median(ts))
         assert len(res['FIT_ROWS'].data) == nrows * 35
         return {'rows': nrows, 'dim': dim_, 'nl': 35, 'calls': ncall, 'ms_per_call_median': round(med * 1e3, 4),
-                'ms_per_call_min': round(min(ts) * 1e3, 4), 'value': round(nrows * 35 / med, 1)}
+                'ms_per_call_min': round(min(ts) * 1e3, 4), 'ms_per_call_max': round(max(ts) * 1e3, 4),
+                'ms_per_call_p10_p90': [round(float(np.percentile(ts, 10)) * 1e3, 4), round(float(np.percentile(ts, 90)) * 1e3, 4)],
+                'value': round(nrows * 35 / med, 1), 'value_min': round(nrows * 35 / max(ts), 1),
+                'value_max': round(nrows * 35 / min(ts), 1)}
     a512 = run(1000, 512, ncalls)
     a1280 = run(100, 1280, ncalls)
     return {'value': a512['value'], 'unit': 'PSFs/sec', 'table_1000_rows_512': a512, 'table_100_rows_native1280': a1280,
@@ -226,6 +229,20 @@ def e2e_sparta_leg(ncalls):
             'what': 'compute_psf_from_sparta(HDUList) -> HDUList with FIT_ROWS, FIT_MEAN, PSF_MEAN (psfrec.py:981-1120): '
                     'host logic, asynchronous host-output parts, table assembly and the FIT_MEAN refit included; '
                     'median wall time per call'}
+
+
+LEG_REGIONS = 5        # timed regions per secondary leg: `value` = their median, min / max beside it
+
+
+def spread(values, npsf_per_region=None, seconds=None):
+    """Median / min / max of a leg's regions.  `values`: PSFs/s per region."""
+    v = [float(x) for x in values]
+    d = {'regions': len(v), 'value_median': round(float(np.median(v)), 1), 'value_min': round(min(v), 1),
+         'value_max': round(max(v), 1), 'value_first': round(v[0], 1),
+         'note': '`value` of this leg is the median of its regions (each bracketed by synchronisations like the main one)'}
+    if seconds is not None:
+        d['seconds_each'] = round(float(np.median(seconds)), 4)
+    return d
 
 
 def series_flops_per_line(dim):
@@ -770,22 +787,35 @@ def main():
                 pend.pop(0).wait()
         while pend:
             pend.pop(0).wait()
-        t0 = time.perf_counter()
-        for _ in range(nh2):
-            pend.append(c.reconstruct_async(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, want_psf=False))
-            if len(pend) > 2:
+        dths = []
+        for _ in range(LEG_REGIONS):
+            t0 = time.perf_counter()
+            for _ in range(nh2):
+                pend.append(c.reconstruct_async(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, want_psf=False))
+                if len(pend) > 2:
+                    rh = pend.pop(0).wait()
+            while pend:
                 rh = pend.pop(0).wait()
-        while pend:
-            rh = pend.pop(0).wait()
-        dth = time.perf_counter() - t0
+            dths.append(time.perf_counter() - t0)
+        dth = float(np.median(dths))
+        # (the blocking form too)
+        dtss = [dts]
+        for _ in range(LEG_REGIONS - 1):
+            t0 = time.perf_counter()
+            for _ in range(nhost):
+                rs = c.reconstruct(lb, see[sl], gl[sl], l0[sl], three, h, 12.0, a.npsflin, want_psf=False)
+            dtss.append(time.perf_counter() - t0)
+        dts = float(np.median(dtss))
         c.close()
         host_leg = {'value': round(rows * nl * nh2 / dth, 1), 'unit': 'PSFs/sec', 'steps': nh2,
+                    'spread': spread([rows * nl * nh2 / d for d in dths], seconds=dths),
                     'ms_per_call': round(dth / nh2 * 1e3, 4), 'calls_in_flight': 2,
                     'outputs': 'fit table [rows][nl][16] + stamp sum [nl][40][40] (float64) in host memory, '
                                'asynchronous host-output calls (on_device = 2), results collected one call behind: '
                                'what compute_psf_from_sparta hands back (psfrec.py:978, 1104-1113)',
                     'sync': {'value': round(rows * nl * nhost / dts, 1), 'ms_per_call': round(dts / nhost * 1e3, 4),
-                             'steps': nhost, 'note': 'blocking calls (on_device = 0), one at a time'},
+                             'steps': nhost, 'note': 'blocking calls (on_device = 0), one at a time',
+                             'spread': spread([rows * nl * nhost / d for d in dtss], seconds=dtss)},
                     'async_equals_sync': bool(np.array_equal(rh['fit'], rs['fit']) and np.array_equal(rh['psf_sum'], rs['psf_sum']))}
         if cpu_fits is not None:
             n = cpu_fits.shape[0]
@@ -807,7 +837,8 @@ def main():
         Rn = make_runner('mixed', 1, dim=1280, ps=0.2, lb=lb_nat)
         for _ in range(100):        # (priming: 60 ms of load, like the 1200 steps before the main region -- with 8 the
             Rn['step']()            # 20-step region came out 10 % below the same workload run on its own)
-        dtn, _ = Rn['timed'](nnat)
+        dtns = [Rn['timed'](nnat)[0] for _ in range(LEG_REGIONS)]
+        dtn = float(np.median(dtns))
         fitn = Rn['fits'][0].cpu().numpy()
         Rn['close']()
         # per-kernel times with one call in flight (one lane: nothing else on the GPU beside a kernel)
@@ -818,6 +849,7 @@ def main():
         mfn = probe_mf_work(Rn['ctxs'][0], lb_nat)
         Rn['close']()
         native = {'value': round(rows * nl * nnat / dtn, 1), 'unit': 'PSFs/sec', 'steps': nnat,
+                  'spread': spread([rows * nl * nnat / d for d in dtns], seconds=dtns),
                   'ms_per_step': round(dtn / nnat * 1e3, 4),
                   'workload': '%d rows x %d lambda (490-930 nm), 1280^2 grid, pixscale 0.2' % (rows, nl),
                   'kernel_ms_per_launch_one_call_in_flight': {k: round(v, 4) for k, v in ktn.items()}}
@@ -864,10 +896,12 @@ def main():
         R3 = make_runner('mixed', max(1, a.inflight), prune_eps=0.0)
         for _ in range(100):        # (priming, as for the native leg)
             R3['step']()
-        dt3, _ = R3['timed'](nunp)
+        dt3s = [R3['timed'](nunp)[0] for _ in range(LEG_REGIONS)]
+        dt3 = float(np.median(dt3s))
         fit3 = R3['fits'][0].cpu().numpy()
         R3['close']()
         unpruned = {'value': round(total_rows * nl * nunp / dt3, 1), 'unit': 'PSFs/sec', 'steps': nunp,
+                    'spread': spread([total_rows * nl * nunp / d for d in dt3s], seconds=dt3s),
                     'ms_per_step': round(dt3 / nunp * 1e3, 4),
                     'max_abs_diff_fwhm_px_vs_pruned': float(np.abs(fit3[:, :, 5] - fitg[:, :, 5]).max()),
                     'max_abs_diff_beta_vs_pruned': float(np.abs(fit3[:, :, 4] - fitg[:, :, 4]).max())}
@@ -880,7 +914,8 @@ def main():
         R2 = make_runner('f64', max(1, a.inflight))
         for _ in range(100):        # (priming, as for the native leg: with 4 the leg read 4.7 M where the
             R2['step']()            # primed run of the same workload gives 4.9 M)
-        dt2, _ = R2['timed'](nf64)
+        dt2s = [R2['timed'](nf64)[0] for _ in range(LEG_REGIONS)]
+        dt2 = float(np.median(dt2s))
         fit2 = R2['fits'][0].cpu().numpy()
         R2['close']()
         R2 = make_runner('f64', 1, streams=1)        # per-kernel times with one call in flight
@@ -894,6 +929,7 @@ def main():
             vk2 = None
         R2['close']()
         f64 = {'value': round(total_rows * nl * nf64 / dt2, 1), 'unit': 'PSFs/sec',
+               'spread': spread([total_rows * nl * nf64 / d for d in dt2s], seconds=dt2s),
                'steps': nf64, 'ms_per_step': round(dt2 / nf64 * 1e3, 4), 'dtype': 'f64',
                'kernel_ms_per_launch_one_call_in_flight': {k: round(v, 4) for k, v in kt2.items()}}
         if 'otf_rowfft' in kt2:

@@ -17,7 +17,7 @@ for blk in re.split(r'\n(?=\S)', txt):
         key = 'k_otf_rowfft' if m.group(1) == 'k_otf_r16' else m.group(1)
         kern[key] = {'fetch_kib': float(f.group(2)), 'write_kib': float(w.group(2)), 'symbol': name}
 print(json.dumps({
-    'round': 4,
+    'round': 6,
     'command': 'scripts/prof_all.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes, no tracing) '
                '-- python3 bench.py --steps 3 --warmup 1 --cpu-rows 0 --f64-steps 0 --profile-steps 0 --unpruned-steps 0 --host-steps 0 --native-steps 0 --e2e-steps 0',
     'workload': '100 rows x 35 lambda x 512^2, mixed precision, one context with two lanes, one launch of '
