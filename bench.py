@@ -407,7 +407,7 @@ def main():
                 c.set_option('prune_eps', prune_eps)
             if os.environ.get('MPSFR_OTF_MFMA') and precision == 'mixed':     # experiments: 0 = FFT path
                 c.set_option('otf_mfma', int(os.environ['MPSFR_OTF_MFMA']))
-            for key in ('mf_floor', 'mf_kernel', 'mf_permax', 'mf_mid_log2', 'mf_floor_log2', 'tier_eps', 'cold_stagger', 'stage_a', 'cu_partition', 'param_copy', 'persist_reserve', 'persist_reserve_mf', 'persist_reserve_a', 'head_fusion', 'copy_fusion', 'support_skip'):      # experiments
+            for key in ('mf_floor', 'mf_kernel', 'mf_permax', 'mf_mid_log2', 'mf_floor_log2', 'tier_eps', 'cold_stagger', 'stage_a', 'cu_partition', 'param_copy', 'persist_reserve', 'persist_reserve_mf', 'persist_reserve_a', 'head_fusion', 'copy_fusion', 'support_skip', 'finish_fusion'):      # experiments
                 if os.environ.get('MPSFR_' + key.upper()) and (precision == 'mixed' or key == 'stage_a'):
                     c.set_option(key, float(os.environ['MPSFR_' + key.upper()]))
             if os.environ.get('MPSFR_PRUNE_FIXED') and precision == 'mixed':
@@ -619,8 +619,10 @@ def main():
                 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(fl / t / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                 'avg_launch_ms': round(ms_launch, 4), 'executed_flops_per_launch': fl,
                 'tile_steps_executed_fraction': round(mfw['tile_steps_per_row'] / mfw['tile_steps_unpruned_per_row'], 4),
-                'blocks_kept_by_any_wavelength_fraction': round(mfw['union_steps_per_row'] * nl / mfw['tile_steps_unpruned_per_row'], 4),
-                'blocks_inside_telescope_support_fraction': round(mfw['support_steps_per_row'] * nl / mfw['tile_steps_unpruned_per_row'], 4),
+                'blocks_kept_by_any_wavelength_fraction': round(float(mfw['union_steps_per_row']) * nl / mfw['tile_steps_unpruned_per_row'], 4)
+                if mfw.get('union_steps_per_row', -1) >= 0 else None,
+                'blocks_inside_telescope_support_fraction': round(float(mfw['support_steps_per_row']) * nl / mfw['tile_steps_unpruned_per_row'], 4)
+                if mfw.get('support_steps_per_row', -1) >= 0 else None,
                 'unpruned_fp32_equivalent': {
                     'flops_per_launch': fl32_all, 'rate_TFLOPs': round(fl32_all / t / 1e12, 1),
                     'over_fp32_peak': round(fl32_all / t / 1e12 / PEAK_FP32_TFLOPS, 3),
@@ -1101,10 +1103,12 @@ def main():
                          'lines_transformed_fraction': round(kept_frac, 4),
                          # what stage A has to deliver at all: blocks some wavelength of the task keeps, and blocks
                          # inside the support of the telescope OTF (fractions of the half plane)
-                         'blocks_kept_by_any_wavelength_fraction': mf_work and mf_work.get('union_steps_per_row', -1) >= 0 and round(
-                             mf_work['union_steps_per_row'] * nl / mf_work['tile_steps_unpruned_per_row'], 4),
-                         'blocks_inside_telescope_support_fraction': mf_work and mf_work.get('support_steps_per_row', -1) >= 0 and round(
-                             mf_work['support_steps_per_row'] * nl / mf_work['tile_steps_unpruned_per_row'], 4),
+                         'blocks_kept_by_any_wavelength_fraction': round(
+                             float(mf_work['union_steps_per_row']) * nl / mf_work['tile_steps_unpruned_per_row'], 4)
+                         if (mf_work and mf_work.get('union_steps_per_row', -1) >= 0) else None,
+                         'blocks_inside_telescope_support_fraction': round(
+                             float(mf_work['support_steps_per_row']) * nl / mf_work['tile_steps_unpruned_per_row'], 4)
+                         if (mf_work and mf_work.get('support_steps_per_row', -1) >= 0) else None,
                          'valu_issue': u and u.get('valu_issue'),
                          'mfma_busy': u and u.get('mfma_busy'),
                          'lds_busy': u and u.get('lds_array_busy'),

@@ -186,7 +186,18 @@ void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const L
 void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int ncu, const void* d_D0t,
                       const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,
                       const void* d_own, const void* d_uni, void* d_sched, void* d_part, void* d_pre,
-                      void* d_clk = nullptr, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                      void* d_clk = nullptr, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                      bool finish = true);
+// finish = false: K_MF_FINISH is not launched -- the stamps of the (task, wavelength group)s that ran as several sweeps
+// stay partial tiles, which K_CONV_FFT adds up on its way (round 6: one launch less between the per-wavelength stage
+// and the convolutions).  MfFinishArgs tells it where they lie; launch_mf_finish completes `pre` for other readers.
+struct MfFinishArgs {
+    const int* gsw = nullptr;      // [ntask][ngr] sweep masks; nullptr: `pre` is complete
+    const void* part = nullptr;    // partial tiles
+    int per = 1, ngr = 1, nsw = 1;
+};
+MfFinishArgs mf2_finish_args(int N, int ntask, int nl, int permax, void* d_sched, const void* d_part);
+void launch_mf_finish(hipStream_t s, int N, int ntask, int nl, int permax, void* d_sched, const void* d_part, void* d_pre);
 void launch_gtable(hipStream_t s, int N, int nl, const LamPar* d_lp, const void* d_tw64,
                    int* d_samp_p, void* d_samp_a, void* d_G, bool f64);
 void launch_moffat_kernels(hipStream_t s, int nker, const double* d_gamma, const double* d_alpha,
@@ -211,7 +222,8 @@ void launch_khat(hipStream_t s, int nker, const double* d_gamma, const double* d
 // fin_f32 / stamps_f32: the final stamps are float (inside the pipeline) instead of double
 // f64: double stamps in and out, fp64 transforms, khat tables of complex double
 void launch_conv_fft(hipStream_t s, int ntask, int nl, const void* d_pre, const void* d_khat_tt,
-                     const void* d_khat_muse, void* d_fin, bool fin_f32, bool f64 = false);
+                     const void* d_khat_muse, void* d_fin, bool fin_f32, bool f64 = false,
+                     const MfFinishArgs& finish = MfFinishArgs());
 // (sum_*: the deterministic sum of the stamps over the sum_ntask tasks of the chunk -- [sum_nl][40][40] into d_sum,
 // added to it if sum_accumulate -- as the first workgroups of the same launch; d_sum = nullptr: none)
 void launch_fit(hipStream_t s, int nstamp, const void* d_stamps, bool stamps_f32, double* d_fit,

@@ -101,6 +101,50 @@ __host__ __device__ constexpr int mf_nmt(int N) { return (N / 2 + 1 + MTL - 1) /
             }
 }
 
+// Which lanes of the second-pass result tiles the epilogue (write_stamp) reads: columns
+// 16 jt + lr < 21; of R2x rows 0..4 (lane groups lk = 0, 1), of R2y rows 8..12 (lk = 2, 3).  Only
+// those travel through memory between K_OTF_MFMA2 and whoever finishes the stamp (half of the 8 KB per sweep).
+[[maybe_unused]] __device__ __forceinline__ bool part_col(int jt, int lr) { return 16 * jt + lr < NSH; }
+[[maybe_unused]] __device__ __forceinline__ bool part_r2x(int lk) { return lk < 2; }
+[[maybe_unused]] __device__ __forceinline__ bool part_r2y(int lk) { return lk >= 2; }
+
+constexpr int kT2 = 8;                  // m-tiles staged per sweep over the k-steps (K_OTF_MFMA2)
+
+// What finishes a stamp whose (task, wavelength group) K_OTF_MFMA2 ran as several sweeps: where the partial
+// result tiles lie and which sweeps wrote one.
+struct MfFinish {
+    const int* gsw;          // [ntask][ngr] bit mask of the sweeps of a (task, group); nullptr: nothing to finish
+    const f4* part;          // [ntask][nl][nsw][4 NJT][64] partial tiles
+    int per, ngr, nsw;
+};
+
+// One wave: the partial tiles of stamp (task, l) added in sweep order, then the epilogue of K_OTF_MFMA2
+// (write_stamp) into `out` (global memory, or LDS for a consumer that takes the stamp from there).  `m`: the
+// sweep mask of the stamp's (task, group), more than one bit set.
+[[maybe_unused]] __device__ __forceinline__ void finish_stamp(const MfFinish& f, int m, int task, int nl, int l,
+                                                             int lane, float* __restrict__ out) {
+    f4 P0[NJT], Q0[NJT], R2x[NJT], R2y[NJT];
+    bool first = true;
+    for (int sw = 0; sw < f.nsw; ++sw) {
+        if (!((m >> sw) & 1)) continue;
+        const f4* pt = f.part + (((size_t)task * nl + l) * f.nsw + sw) * (4 * NJT * 64) + lane;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const f4 z = {0.f, 0.f, 0.f, 0.f};
+            const bool col = part_col(jt, lane & 15);
+            const f4 p = col ? pt[(0 * NJT + jt) * 64] : z, q = col ? pt[(1 * NJT + jt) * 64] : z;
+            const f4 x = col && part_r2x(lane >> 4) ? pt[(2 * NJT + jt) * 64] : z;
+            const f4 y = col && part_r2y(lane >> 4) ? pt[(3 * NJT + jt) * 64] : z;
+            P0[jt] = first ? p : P0[jt] + p;
+            Q0[jt] = first ? q : Q0[jt] + q;
+            R2x[jt] = first ? x : R2x[jt] + x;
+            R2y[jt] = first ? y : R2y[jt] + y;
+        }
+        first = false;
+    }
+    write_stamp(P0, Q0, R2x, R2y, lane & 15, lane >> 4, out);
+}
+
 #ifndef MPSFR_MF_BASE_NOP
 #define MPSFR_MF_BASE_NOP 4      // s_nop N opening every LDS-DMA statement (see below)
 #endif

@@ -69,6 +69,10 @@ struct mpsfr_ctx {
     int reserve_mf = -1, reserve_a = -1;
     // the parameter blob and the tip-tilt kernel spectra ride in the two launches of the patch (series form of stage A)
     bool head_fusion = true;
+    // K_CONV_FFT adds up the partial tiles of the stamps K_OTF_MFMA2 split into sweeps (no K_MF_FINISH launch)
+    bool finish_fusion = false;     // (measured: -1 % with two lanes, 0 with one -- profiles/r06_experiments.md)
+    bool last_pre_partial = false;
+    int last_permax = 6;   // the last chunk's `pre` lacks those stamps (a debug fetch completes it)
     // stage A (series form) skips what lies outside the support of the telescope OTF
     bool support_skip = true;
     bool copy_fusion = false;
@@ -675,6 +679,8 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         if (key[15] == '\0' || key[16] == 'a') c->reserve_a = (int)value;
     } else if (!strcmp(key, "support_skip")) {
         c->support_skip = value != 0.0;
+    } else if (!strcmp(key, "finish_fusion")) {
+        c->finish_fusion = value != 0.0;
     } else if (!strcmp(key, "head_fusion")) {
         c->head_fusion = value != 0.0;
     } else if (!strcmp(key, "copy_fusion")) {
@@ -1160,6 +1166,9 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     const bool mf = !c->f64 && c->otf_mfma;
     const bool mf2 = mf && ndir == 1 && c->mf_kernel == 2;      // thin-wave kernel (otf_mfma2.hip)
     const bool r16 = !mf && otf_uses_r16(N, c->f64, nl, ndir);
+    // (the stamps K_OTF_MFMA2 leaves as partial tiles are finished by the FFT convolution kernel itself; a call
+    // that hands out the stamps before the convolutions -- psf_muse -- or skips stage B keeps K_MF_FINISH)
+    const bool fuse_finish = mf2 && c->finish_fusion && c->fft_conv && !io.stop_pre && !io.pre_in;
     if (r16 && (rc = ensure(c, c->xtab, xtab_bytes(nl)))) return rc;
     if (mf) {
         if ((rc = ensure(c, c->etab, mf_etab_bytes(N, nl)))) return rc;
@@ -1502,7 +1511,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             ProfScope ps(c, K_OTF_MFMA, ls, false);
             launch_otf_mfma2(ls, N, tc, nl, c->mf_permax, persist_grid(c, ln, c->reserve_mf, lanes_shared), ln.D0t.p, (const float*)c->tl2.p, d_lp, c->etab.p,
                              c->gtab.p, ln.mown.p, ln.muni.p, ln.msched.p, ln.mpart.p, ln.pre.p,
-                             c->mf_clock ? c->mfclk.p : nullptr, ps.a, ps.b);
+                             c->mf_clock ? c->mfclk.p : nullptr, ps.a, ps.b, !fuse_finish);
         } else if (mf) {
             ProfScope ps(c, K_OTF_MFMA, ls);
             if (floor_per_task)
@@ -1550,7 +1559,8 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             const size_t koff = (size_t)t0 * ksz;
             if (use_fft_conv)
                 launch_conv_fft(ls, tc, nl, ln.pre.p, (const char*)sl.ktt.p + koff,
-                                c->kmuse.p, d_fin, fin_f32, c->f64);
+                                c->kmuse.p, d_fin, fin_f32, c->f64,
+                                fuse_finish ? mf2_finish_args(N, tc, nl, c->mf_permax, ln.msched.p, ln.mpart.p) : MfFinishArgs());
             else
                 launch_conv(ls, tc, nl, ln.pre.p, (const char*)sl.ktt.p + koff,
                             c->kmuse.p, (double*)d_fin, c->f64);
@@ -1614,6 +1624,8 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     c->last_nl = nl;
     c->last_mf = mf;
     c->last_mf2 = mf2;
+    c->last_pre_partial = fuse_finish;
+    c->last_permax = c->mf_permax;
     c->last_pruned = prune;
     c->last_thr_blk = thr_blk;
     c->last_floor_per_task = floor_per_task;
@@ -1871,7 +1883,14 @@ long mpsfr_debug_fetch(mpsfr_ctx* c, const char* what, double* out, size_t capac
         is_real_r = true;
     } else if (!strcmp(what, "pre")) {
         n = (size_t)c->last_chunk_tasks * c->last_nl * NS * NS;
-        src = c->lane[c->last_lane].pre.p;
+        mpsfr_ctx::Lane& lnp = c->lane[c->last_lane];
+        if (c->last_pre_partial) {       // the stamps the convolution kernel finished on its way: complete them here
+            if (lnp.stream) HIPCHK(hipStreamSynchronize(lnp.stream));
+            launch_mf_finish(c->stream, N, c->last_chunk_tasks, c->last_nl, c->last_permax, lnp.msched.p, lnp.mpart.p, lnp.pre.p);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->last_pre_partial = false;
+        }
+        src = lnp.pre.p;
         is_real_r = true;
     } else if (!strcmp(what, "mf_work")) {
         // Work of the matrix-core per-wavelength kernel in the last chunk, recomputed on the host

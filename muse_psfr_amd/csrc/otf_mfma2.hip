@@ -52,7 +52,6 @@ namespace {
 
 typedef unsigned long long u64;
 
-constexpr int kT2 = 8;                  // m-tiles staged per sweep over the k-steps
 constexpr int kTW = 4;                  // m-tiles per wave: tiles 2 i + half of the sweep
 constexpr int kStage2 = kT2 * 4096;     // one staging buffer: 8 x (D 2 KB | log2 tel 2 KB)
 constexpr int kSlab = 6 * 1024;         // E slab of one wavelength and k-step: 3 column tiles x (hi | lo)
@@ -248,13 +247,6 @@ __global__ void __launch_bounds__(64 * 8) k_mf_prep(const MaskArgs a) {
         }
     }
 }
-
-// Which lanes of the second-pass result tiles the epilogue (write_stamp) reads: columns
-// 16 jt + lr < 21; of R2x rows 0..4 (lane groups lk = 0, 1), of R2y rows 8..12 (lk = 2, 3).  Only
-// those travel through memory between K_OTF_MFMA2 and K_MF_FINISH (half of the 8 KB per sweep).
-__device__ __forceinline__ bool part_col(int jt, int lr) { return 16 * jt + lr < NSH; }
-__device__ __forceinline__ bool part_r2x(int lk) { return lk < 2; }
-__device__ __forceinline__ bool part_r2y(int lk) { return lk >= 2; }
 
 // the 64-bit word that lane `src` (wave-uniform) holds, into scalar registers
 __device__ __forceinline__ u64 lane_word(u64 w, int src) {
@@ -728,27 +720,9 @@ __global__ void __launch_bounds__(64) k_mf_finish(int N, int nl, int per, int ng
     const int l = blockIdx.x, task = blockIdx.y, lane = threadIdx.x;
     const int m = gsw[task * ngr + l / per];
     if (__builtin_popcount(m) <= 1) return;
-    const int nmt = mf_nmt(N), nsw = (nmt + kT2 - 1) / kT2;
-    f4 P0[NJT], Q0[NJT], R2x[NJT], R2y[NJT];
-    bool first = true;
-    for (int sw = 0; sw < nsw; ++sw) {
-        if (!((m >> sw) & 1)) continue;
-        const f4* pt = part + (((size_t)task * nl + l) * nsw + sw) * (4 * NJT * 64) + lane;
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            const f4 z = {0.f, 0.f, 0.f, 0.f};
-            const bool col = part_col(jt, lane & 15);
-            const f4 p = col ? pt[(0 * NJT + jt) * 64] : z, q = col ? pt[(1 * NJT + jt) * 64] : z;
-            const f4 x = col && part_r2x(lane >> 4) ? pt[(2 * NJT + jt) * 64] : z;
-            const f4 y = col && part_r2y(lane >> 4) ? pt[(3 * NJT + jt) * 64] : z;
-            P0[jt] = first ? p : P0[jt] + p;
-            Q0[jt] = first ? q : Q0[jt] + q;
-            R2x[jt] = first ? x : R2x[jt] + x;
-            R2y[jt] = first ? y : R2y[jt] + y;
-        }
-        first = false;
-    }
-    write_stamp(P0, Q0, R2x, R2y, lane & 15, lane >> 4, pre + ((size_t)task * nl + l) * NS * NS);
+    MfFinish f;
+    f.gsw = gsw; f.part = part; f.per = per; f.ngr = ngr; f.nsw = (mf_nmt(N) + kT2 - 1) / kT2;
+    finish_stamp(f, m, task, nl, l, lane, pre + ((size_t)task * nl + l) * NS * NS);
 }
 
 }  // namespace
@@ -814,7 +788,7 @@ void launch_mf_prep(hipStream_t s, int N, int ntask, int nl, int permax, const L
 void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int ncu, const void* d_D0t,
                       const float* d_tl2, const LamPar* d_lp, const void* d_E, const void* d_G,
                       const void* d_own, const void* d_uni, void* d_sched, void* d_part, void* d_pre,
-                      void* d_clk, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                      void* d_clk, hipEvent_t ev_start, hipEvent_t ev_stop, bool finish) {
     Mf2Args a;
     a.N = N; a.ntask = ntask; a.nl = nl;
     mf2_groups(nl, permax, &a.per, &a.ngr);
@@ -851,8 +825,29 @@ void launch_otf_mfma2(hipStream_t s, int N, int ntask, int nl, int permax, int n
         else
             hipLaunchKernelGGL(k_otf_mfma2<3>, dim3(nwg), dim3(128 * a.per), sm, s, a);
     }
-    hipLaunchKernelGGL(k_mf_finish, dim3(nl, ntask), dim3(64), 0, s, N, nl, a.per, a.ngr, (const int*)p.gsw,
-                       (const f4*)a.part, a.pre);
+    if (finish)
+        hipLaunchKernelGGL(k_mf_finish, dim3(nl, ntask), dim3(64), 0, s, N, nl, a.per, a.ngr, (const int*)p.gsw,
+                           (const f4*)a.part, a.pre);
+}
+
+// K_MF_FINISH on its own (launch_otf_mfma2 with finish = false leaves the stamps of the (task, group)s with several
+// sweeps as partial tiles: K_CONV_FFT finishes them on its way -- MfFinishArgs -- and a reader of `pre` itself,
+// debug fetches and psf_muse, asks for this)
+void launch_mf_finish(hipStream_t s, int N, int ntask, int nl, int permax, void* d_sched, const void* d_part, void* d_pre) {
+    int per, ngr;
+    mf2_groups(nl, permax, &per, &ngr);
+    const SchedPtrs p = sched_ptrs(d_sched, ntask, nl);
+    hipLaunchKernelGGL(k_mf_finish, dim3(nl, ntask), dim3(64), 0, s, N, nl, per, ngr, (const int*)p.gsw,
+                       (const f4*)d_part, (float*)d_pre);
+}
+
+MfFinishArgs mf2_finish_args(int N, int ntask, int nl, int permax, void* d_sched, const void* d_part) {
+    MfFinishArgs f;
+    mf2_groups(nl, permax, &f.per, &f.ngr);
+    f.gsw = sched_ptrs(d_sched, ntask, nl).gsw;
+    f.part = d_part;
+    f.nsw = (int)mf2_nsw(N);
+    return f;
 }
 
 }  // namespace mpsfr

@@ -5,6 +5,7 @@
 // Stamp stage: Moffat kernels, the two convolutions (direct / 64-point FFT), Moffat fit, stamp sum.
 #include "device_common.h"
 #include "conv_frames.h"
+#include "mf_common.h"
 
 namespace mpsfr {
 
@@ -167,7 +168,7 @@ template <typename R, typename TF>
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? MPSFR_CONV_WAVES : 2)))
 k_conv_fft(int nl, const R* __restrict__ pre, const cx<R>* __restrict__ khat_tt,
-           const cx<R>* __restrict__ khat_muse, TF* __restrict__ fin) {
+           const cx<R>* __restrict__ khat_muse, TF* __restrict__ fin, MfFinish mf) {
     extern __shared__ __align__(16) unsigned char conv_smem[];
     cx<R> (*F)[CFP] = reinterpret_cast<cx<R> (*)[CFP]>(conv_smem);
     cx<R> (*bufs)[CFB] = reinterpret_cast<cx<R> (*)[CFB]>(conv_smem + sizeof(cx<R>) * CF * CFP);
@@ -180,12 +181,36 @@ k_conv_fft(int nl, const R* __restrict__ pre, const cx<R>* __restrict__ khat_tt,
     // The image never sits in LDS: a slot reads its row pair of the input from global memory, and
     // the rows it produces in the first convolution are exactly the ones it transforms in the
     // second (taken from its own line buffer).
+    // Round 6 -- unless the stamp is one K_OTF_MFMA2 left as the partial tiles of several sweeps: then the first wave
+    // adds them up and runs that kernel's epilogue into LDS (the frame F is free until the first barrier of the
+    // pass loop), and the slots take their rows from there.  K_MF_FINISH, which did this through `pre` as a launch
+    // of its own between the two kernels, was 7 us of a call's chain alone and 11-14 beside the other lane.
     cx<R> x[8];
+    bool from_lds = false;
+    if constexpr (sizeof(R) == 4) {
+        if (mf.gsw != nullptr) {
+            const int m = mf.gsw[task * mf.ngr + l / mf.per];
+            if (__builtin_popcount(m) > 1) {           // (uniform over the workgroup)
+                float* st = reinterpret_cast<float*>(conv_smem);
+                if (threadIdx.x < 64) finish_stamp(mf, m, task, nl, l, (int)threadIdx.x, st);
+                __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = t + 8 * e;
-        const bool in = c < NS && slot < NS / 2;
-        x[e] = {in ? src[2 * slot * NS + c] : (R)0, in ? src[(2 * slot + 1) * NS + c] : (R)0};
+                for (int e = 0; e < 8; ++e) {
+                    const int c = t + 8 * e;
+                    const bool in = c < NS && slot < NS / 2;
+                    x[e] = {in ? st[2 * slot * NS + c] : 0.f, in ? st[(2 * slot + 1) * NS + c] : 0.f};
+                }
+                from_lds = true;
+            }
+        }
+    }
+    if (!from_lds) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = t + 8 * e;
+            const bool in = c < NS && slot < NS / 2;
+            x[e] = {in ? src[2 * slot * NS + c] : (R)0, in ? src[(2 * slot + 1) * NS + c] : (R)0};
+        }
     }
     for (int pass = 0; pass < 2; ++pass) {
         const cx<R>* __restrict__ kh = pass == 0 ? khat_tt + (size_t)task * (CFH + 1) * CF
@@ -1274,21 +1299,24 @@ void launch_khat(hipStream_t s, int nker, const double* d_gamma, const double* d
 }
 
 void launch_conv_fft(hipStream_t s, int ntask, int nl, const void* d_pre, const void* d_khat_tt,
-                     const void* d_khat_muse, void* d_fin, bool fin_f32, bool f64) {
+                     const void* d_khat_muse, void* d_fin, bool fin_f32, bool f64, const MfFinishArgs& finish) {
     const dim3 grid(nl, ntask);
+    MfFinish mf;
+    mf.gsw = f64 ? nullptr : finish.gsw; mf.part = (const f4*)finish.part;
+    mf.per = finish.per; mf.ngr = finish.ngr; mf.nsw = finish.nsw;
     if (f64) {          // double stamps in, double arithmetic, double stamps out
         allow_smem((k_conv_fft<double, double>), conv_smem_bytes<double>(false));
         hipLaunchKernelGGL((k_conv_fft<double, double>), grid, dim3(256), conv_smem_bytes<double>(false), s, nl,
                            (const double*)d_pre, (const cx<double>*)d_khat_tt, (const cx<double>*)d_khat_muse,
-                           (double*)d_fin);
+                           (double*)d_fin, mf);
     } else if (fin_f32) {
         hipLaunchKernelGGL((k_conv_fft<float, float>), grid, dim3(256), conv_smem_bytes<float>(false), s, nl,
                            (const float*)d_pre, (const cx<float>*)d_khat_tt, (const cx<float>*)d_khat_muse,
-                           (float*)d_fin);
+                           (float*)d_fin, mf);
     } else {
         hipLaunchKernelGGL((k_conv_fft<float, double>), grid, dim3(256), conv_smem_bytes<float>(false), s, nl,
                            (const float*)d_pre, (const cx<float>*)d_khat_tt, (const cx<float>*)d_khat_muse,
-                           (double*)d_fin);
+                           (double*)d_fin, mf);
     }
 }
 

@@ -595,7 +595,8 @@ def test_reserved_cus_and_head_fusion_change_no_bit(api, prec):
     """Round 6: where the work of a call is queued changes no bit of its results -- the persistent grids of
     K_OTF_MFMA2 / K_DPHI_SERIES with R CUs left free ("persist_reserve": 0, 32, 100, automatic), the kernel spectra of
     the tip-tilt kernels as workgroups of K_PATCH_ROWS or as a kernel of their own ("head_fusion"), the parameter
-    blob fetched by workgroups of K_PATCH_GEN ("copy_fusion") -- for host-output calls (one chunk, several chunks on
+    blob fetched by workgroups of K_PATCH_GEN ("copy_fusion"), the stamps K_OTF_MFMA2 split into sweeps finished by
+    K_CONV_FFT or by K_MF_FINISH ("finish_fusion") -- for host-output calls (one chunk, several chunks on
     two lanes) and for lean device-output calls queued back to back (series form of stage A: 512^2)."""
     import torch
     from muse_psfr_amd import NFIT
@@ -610,6 +611,7 @@ def test_reserved_cus_and_head_fusion_change_no_bit(api, prec):
                 ('reserve100_fused', {'persist_reserve': 100}),
                 ('defaults', {}),
                 ('copy_fused', {'copy_fusion': 1}),
+                ('finish_fused', {'finish_fusion': 1}),           # K_CONV_FFT finishes the split stamps itself
                 ('copy_fused_chunks', {'copy_fusion': 1, 'chunk_tasks': 10, 'streams': 2}),
                 ('fused_chunks', {'chunk_tasks': 10, 'streams': 2}))
     ref = None
