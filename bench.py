@@ -34,7 +34,7 @@ PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector / fp32 matrix peak (MI355X_MIC
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak (same guide)
 PEAK_HBM_GBPS = 8000.0
 PEAK_FP64_TFLOPS = 78.6        # fp64 vector (= fp64 matrix) peak (same guide)
-PROFILE_ROUND = 'r05'          # profiles/<round>_kernel_util.json, _traffic.json, _parity_margins.json
+PROFILE_ROUND = 'r06'          # profiles/<round>_kernel_util.json, _traffic.json, _parity_margins.json
 PIPELINE_HAS_TQ = True       # FFT form of the per-wavelength stage: the sampled first-pass lines go through HBM
 sys.path.insert(0, ROOT)
 
@@ -97,6 +97,27 @@ def series_form(dim, npsflin):
     return dim >= 512 or (dim >= 256 and npsflin >= 2)
 
 
+def support_piece_fraction(dim):
+    """Fraction of the half plane stage A's series form evaluates and stores (round 6): the pieces of L =
+    series_lanes(N) columns of a line that touch the support of the telescope OTF -- the autocorrelation of a pupil of
+    diameter N/2: the disc u^2 + y^2 < (N/2)^2 around the origin of the (wrapped) u axis."""
+    L = 16 if dim <= 256 else (32 if dim == 512 else 64)
+    H1, q = dim // 2 + 1, dim // L
+    kept = 0
+    for y in range(H1):
+        w2 = (dim / 2) ** 2 - y * y
+        if w2 <= 0:
+            kept += 0
+            continue
+        w = w2 ** 0.5
+        for k1 in range(q):
+            lo, hi = L * k1, L * k1 + L - 1
+            # columns u in [lo, hi] (u and u - N are the same frequency): inside if min(|u|, |u - N|) < w somewhere
+            dmin = min(lo, dim - hi) if lo > 0 else 0
+            kept += 1 if dmin < w else 0
+    return kept / (H1 * q)
+
+
 def hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac=1.0, has_tq=True, series=False):
     """Algorithmic HBM bytes of one step of the pipeline AS BUILT (DESIGN.md sections 3, 5):
     every intermediate written once and read once by the next kernel, inputs/outputs once."""
@@ -109,7 +130,8 @@ def hbm_model_bytes(dim, nl, rows, ndir, mixed, kept_frac=1.0, has_tq=True, seri
         b['P (corrected-zone patch 80 x 80 fp64, write + read)'] = 2 * td * 80 * 80 * 8
         b['T (row transforms of the patch, 80 x (N/2+1) complex fp64, write + read)'] = 2 * td * 16 * 80 * H1
         b['series coefficients (one read per launch)'] = H1 * dim * (16 if mixed else 64)
-        b['D_phi0 (write + read)'] = 2 * td * p * H1 * dim
+        # (written only inside the telescope OTF's support, read in full tiles by the per-wavelength stage)
+        b['D_phi0 (write inside the support of the telescope OTF + read)'] = int((1 + support_piece_fraction(dim)) * td * p * H1 * dim)
         b['block minima per line (write + read)'] = 2 * td * H1 * (dim // 32) * 4
     else:
         b['C (fp64 row transforms of the PSD, write + read)'] = 2 * td * 16 * H1 * NR
@@ -564,8 +586,29 @@ def main():
         def host_lib():
             tot = [c.host_time() for c in ctxs]
             return sum(t[0] for t in tot) / max(1, sum(t[1] for t in tot))
+
+        def exchange_check():
+            """what the collectives of the LAST step gathered against what the library wrote for it.
+            After the fence: this rank's rows of the gathered table equal, bit for bit, the fit table of the last
+            call's buffer set, and (rank 0) the reduced stamp sum is finite and at least this rank's own.  A missed
+            dependency between the library's lane and the stream of the collectives would gather stale rows.
+            Every rank's verdict is combined (MIN).  None without an exchange."""
+            if not xchg or 'fit_all' not in state:
+                return None
+            fence()
+            b = (state['i'] - 1) % nset
+            lo, hi = bounds[rank]
+            mine = state['fit_all'][lo:hi]
+            ok = bool(torch.equal(mine.cpu(), fits[b].cpu()[:hi - lo])) and bool(torch.isfinite(state['fit_all']).all())
+            if rank == 0 and state.get('psum') is not None and not packed:
+                ps_ = state['psum']
+                ok = ok and bool(torch.isfinite(ps_).all())
+            t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item() == 1.0)
         return dict(ctxs=ctxs, step=step, fence=fence, timed=timed, profile_sum=profile_sum,
-                    fits=fits, close=close, host_lib=host_lib, rank_times=rank_times, exchange_times=exchange_times)
+                    fits=fits, close=close, host_lib=host_lib, rank_times=rank_times, exchange_times=exchange_times,
+                    exchange_check=exchange_check)
 
     def parity_block(fitg, n):
         return {'rows_checked': n,
@@ -693,6 +736,7 @@ def main():
     for _ in range(a.warmup):
         R['step']()
     dt, t_enq = R['timed'](a.steps)
+    exch_ok = R['exchange_check']()
     rank_dt = R['rank_times']()
     prof = R['profile_sum']()
     host_lib_s = R['host_lib']()
@@ -1164,6 +1208,7 @@ def main():
         if exch_ms:
             out['exchange_ms_per_step'] = round(max(exch_ms), 4)
             out['exchange'] = {'ms_per_step_by_rank': [round(v, 4) for v in exch_ms],
+                               'gathered_table_equals_the_last_call': exch_ok,
                                'share_of_step': round(max(exch_ms) / (dt / a.steps * 1e3), 4),
                                'collectives': 'all-gather of the fit tables [rows][nl][16] f64 + sum-reduce of the stamp '
                                               'sums [nl][40][40] f64 to rank 0 (SURVEY.md 8(e))',

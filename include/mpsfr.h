@@ -116,6 +116,21 @@ const char* mpsfr_last_error(void);
  * transform of the 80 x 80 corrected zone (stage_a2.hip); below, and for any call with L0 < 7 m, the
  * full-size fp64 transforms of the PSD (stage_a.hip); 0 = always the full-size transforms, 2 = the
  * series form on every grid; the two forms agree to the rounding of the stored structure function).
+ * Round 6, where a call's work is queued (results do not depend on any of these, bit for bit):
+ * "persist_reserve" / "persist_reserve_mf" / "persist_reserve_a" (default -1 = automatic; 0..128): the two persistent
+ * kernels (the matrix-core per-wavelength kernel / the column kernel of stage A's series form) launch ncu - R
+ * workgroups instead of one per CU, so that R CUs -- R / 8 per XCD -- stay free for the latency-bound kernels of the
+ * context's other lane while the big kernel runs; automatic: R = ncu / 8 when the call has chunks on several lanes
+ * or the other lane still has work in flight, 0 for a call that runs alone (one lane loses 5 % to a reserve of 32,
+ * two lanes gain 5 %: profiles/r06_experiments.md);
+ * "head_fusion" (default 1: in the series form of stage A the spectra of a chunk's tip-tilt Moffat kernels are
+ * computed by trailing workgroups of the patch's row kernel; 0: by a kernel of their own at the head of the call);
+ * "copy_fusion" (default 0; 1: the parameter blob is fetched by workgroups of the call's first kernel, which reads
+ * its tasks straight from pinned host memory -- measured, no gain); "finish_fusion" (default 0; 1: the FFT
+ * convolution kernel adds up the partial tiles of the stamps the matrix-core kernel split into sweeps instead of
+ * a kernel between the two -- measured, -1 %); "support_skip" (default 1: the series form of stage A neither
+ * evaluates nor stores the structure function on the pieces of a line where the telescope OTF is identically zero
+ * -- a fifth of the half plane; the buffer keeps the zero it was allocated with there).
  * "cold_stagger" (default 0 = off; 1 / 2: after the GPU has drained, the second lane's first chunk
  * waits once for the first lane's column transforms / per-wavelength preparation, so that the two
  * lanes do not start in step: +3 % in a sustained run of 100-row calls, -1 % on a burst of 20;

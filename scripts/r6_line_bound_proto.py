@@ -26,7 +26,7 @@ eps = 1e-9
 thr = np.log2(0.5 * eps / (2 * 1 * 16 * 32 * nblocks))
 c2 = -0.5 * (2 * np.pi / lam_max) ** 2 * np.log2(np.e)
 with np.errstate(divide='ignore'):
-    tlmax = np.log2(tel.max(axis=0)[:H1])        # per line y of the half plane (tel is symmetric)
+    tlmax = np.log2(tel.max(axis=0)[:H1])        # per line y of the half plane (second index, like D)
 half = 40
 fr = []
 pick = np.linspace(0, 99, nrows).astype(int)
@@ -46,15 +46,12 @@ for r in pick:
     W = np.exp(-2j * np.pi * np.outer(sv, y) / dim)           # [sv][y]
     T = Pz @ W                                     # [su][y]
     B = np.abs(T).sum(axis=0)                      # [y]
-    scale = dP.max() / (2 * Pz.sum()) if Pz.sum() > 0 else 0  # calibrate 2 s from D_P's plateau upper bound? no: exact below
-    # exact scale: D_P(rho) = 2 s (sum P - Re FFT2 P); at rho where Re FFT2 P = 0 ... use the definition instead
     L = 2 * O.DPUP
     s2 = 2.0 * (1.0 / L ** 2)                      # structure_function0: bg = ifft2(psd) * size / L^2 -> sum P / L^2
     Lb = s2 * (Pz.sum() - B)
-    true_min_full = d0[:H1, :].min(axis=1) if True else None
-    # which axis is y?  D is symmetric under transposition only for symmetric P; take the line minimum over the other axis
-    true_min = np.minimum(d0[:H1, :].min(axis=1), d0[:, :H1].min(axis=0))
-    dPmin = np.minimum(dP[:H1, :].min(axis=1), dP[:, :H1].min(axis=0))
+    # line y of the half plane = second index of the (FFT-layout) structure function: T transforms along sv (axis 1)
+    true_min = d0[:, :H1].min(axis=0)
+    dPmin = dP[:, :H1].min(axis=0)
     ok = np.all(Lb <= dPmin * (1 + 1e-9) + 1e-6 * dP.max())
     skip = (c2 * np.maximum(Lb, 0) + tlmax < thr)
     skip_true = (c2 * true_min + tlmax < thr)

@@ -92,6 +92,8 @@ def test_bench_starts_its_own_ranks():
     assert out['scaling'] == 'strong' and out['config']['rows_total'] == 31
     assert 'row-sharded over 2 GPUs (16/15 rows per GPU)' in out['config']['workload']
     assert abs(out['value'] - 31 * 5 * 4 / (out['ms_per_step'] * 4e-3)) < 1e-3 * out['value']
+    # (ragged shards, two ranks: every rank's rows of the gathered table equal its last call's fit table)
+    assert out['exchange']['gathered_table_equals_the_last_call'] is True
 
 
 _RCCL_ONE_RANK = r"""
@@ -172,6 +174,9 @@ def test_bench_step_with_collectives_on_rccl_one_rank():
     assert r.returncode == 0 and line, r.stderr[-3000:]
     out = json.loads(line[-1])
     assert out['n_gpus'] == 1 and out['value'] > 0 and out['steps'] == 10
+    # after the fence the table the collectives gathered for the LAST step equals what the library wrote
+    # for it (mpsfr_stream_wait is the only thing that orders the two)
+    assert out['exchange']['gathered_table_equals_the_last_call'] is True
 
 
 def test_multi_context_call_selects_every_device(tmp_path):
