@@ -429,7 +429,7 @@ def main():
                 c.set_option('prune_eps', prune_eps)
             if os.environ.get('MPSFR_OTF_MFMA') and precision == 'mixed':     # experiments: 0 = FFT path
                 c.set_option('otf_mfma', int(os.environ['MPSFR_OTF_MFMA']))
-            for key in ('mf_floor', 'mf_kernel', 'mf_permax', 'mf_mid_log2', 'mf_floor_log2', 'tier_eps', 'cold_stagger', 'stage_a', 'cu_partition', 'param_copy', 'persist_reserve', 'persist_reserve_mf', 'persist_reserve_a', 'head_fusion', 'copy_fusion', 'support_skip', 'finish_fusion'):      # experiments
+            for key in ('mf_floor', 'mf_kernel', 'mf_permax', 'mf_mid_log2', 'mf_floor_log2', 'tier_eps', 'cold_stagger', 'stage_a', 'cu_partition', 'param_copy', 'persist_reserve', 'persist_reserve_mf', 'persist_reserve_a', 'head_fusion', 'copy_fusion', 'support_skip', 'finish_fusion', 'stage_a_queue'):      # experiments
                 if os.environ.get('MPSFR_' + key.upper()) and (precision == 'mixed' or key == 'stage_a'):
                     c.set_option(key, float(os.environ['MPSFR_' + key.upper()]))
             if os.environ.get('MPSFR_PRUNE_FIXED') and precision == 'mixed':

@@ -131,6 +131,11 @@ const char* mpsfr_last_error(void);
  * a kernel between the two -- measured, -1 %); "support_skip" (default 1: the series form of stage A neither
  * evaluates nor stores the structure function on the pieces of a line where the telescope OTF is identically zero
  * -- a fifth of the half plane; the buffer keeps the zero it was allocated with there).
+ * "stage_a_queue" (default 0; 1: the lines of stage A's series form dealt in blocks from a queue instead of equal
+ * contiguous shares -- bit-identical, 13 % slower; 2: and the lines of a task on which a lower bound of the
+ * structure function from the patch's row transforms puts the whole OTF line below the eps rule of "prune_eps", or
+ * its mass below tier_eps / (8 (N/2+1)), at the longest wavelength, are skipped: 28 % of the lines on the bench
+ * rows, stamps within 1e-7 -- and 2 % of the kernel's time: measured, lost, profiles/r06_experiments.md).
  * "cold_stagger" (default 0 = off; 1 / 2: after the GPU has drained, the second lane's first chunk
  * waits once for the first lane's column transforms / per-wavelength preparation, so that the two
  * lanes do not start in step: +3 % in a sustained run of 100-row calls, -1 % on a burst of 20;

@@ -107,6 +107,16 @@ int series_terms(bool f64);
 double series_eps0();
 inline double series_eps_max() { return 1.0 / 49.0; }
 void launch_series_coef(hipStream_t s, int N, const double* d_planes, void* d_coef, bool f64);
+// Round 6: the queue-fed form of launch_dphi_series (K_DPHI_SERIES_Q) and the lines it may skip.  queue: one int the
+// launch in front (launch_patch: PatchExtras::queue_zero) sets to zero; perm [ntd]: the order in which the lines of
+// a y are dealt (nullptr: as they come); tlmax [N/2+1] (launch_tel_linemax) + c2max (log2(e) c of the longest
+// wavelength) + thr_elem / thr_mass (log2): see SeriesSkip in stage_a2.hip; tlmax = nullptr: nothing is skipped.
+struct SeriesQueue {
+    int* queue = nullptr;
+    const int* perm = nullptr;
+    const float* tlmax = nullptr;
+    float c2max = 0.f, thr_elem = -3.0e38f, thr_mass = -3.0e38f;
+};
 // What else rides in the two launches of launch_patch (round 6; all optional):
 //  * the call's parameter blob: blob_src (pinned host) -> blob_dst (device) as extra workgroups of K_PATCH_GEN, which
 //    then reads its tasks from `tp_host` (the TaskPar array INSIDE the pinned blob); `flag`: the pinned word the
@@ -119,6 +129,7 @@ struct PatchExtras {
     const TaskPar* tp_host = nullptr;
     unsigned long long* flag = nullptr;
     unsigned long long seq = 0;
+    int* queue_zero = nullptr;
     int khat_n = 0;
     const double* khat_gam = nullptr;
     const double* khat_alp = nullptr;
@@ -131,7 +142,7 @@ void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, 
 void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const void* d_T,
                         const double* d_sp, const void* d_coef, const void* d_twk, double scale2,
                         void* d_D0t, float* d_dlin, bool f64out, int* d_zero, int ncu,
-                        const unsigned* d_support = nullptr);
+                        const unsigned* d_support = nullptr, const SeriesQueue& qx = SeriesQueue());
 // d_support [N/2+1]: per line, the pieces of series_lanes(N) columns inside the support of the telescope OTF
 // (launch_series_support from d_tel, once per context); launch_dphi_series neither evaluates nor stores the others
 void launch_series_support(hipStream_t s, int N, const void* d_tel, bool f64, unsigned* d_support);

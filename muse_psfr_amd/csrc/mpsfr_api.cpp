@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -75,6 +76,9 @@ struct mpsfr_ctx {
     int last_permax = 6;   // the last chunk's `pre` lacks those stamps (a debug fetch completes it)
     // stage A (series form) skips what lies outside the support of the telescope OTF
     bool support_skip = true;
+    // K_DPHI_SERIES_Q: stage A's lines dealt in blocks from a queue (0: equal contiguous shares); 2: + the lines
+    // stage B provably drops are skipped (SeriesSkip, stage_a2.hip)
+    int stage_a_queue = 0;
     bool copy_fusion = false;
     double pixscale = 0.2;
     bool f64 = false;
@@ -122,6 +126,7 @@ struct mpsfr_ctx {
         int ncu = 0;                     // CUs the lane's stream may use (0: all of them)
         DevBuf C, s00, D0t, Tq, pre, fin, dmin, dblk, vkeep, dminb, order, mown, muni, msched, mpart;
         DevBuf pP, pT, psp, dlin;        // series form of stage A: patch, its row transforms, its sum; line minima
+        DevBuf squeue;                   // the block queue of K_DPHI_SERIES_Q (one int, zeroed by K_PATCH_ROWS)
         DevBuf thrf;                     // [tasks] floor of the kernel for several directions (K_PEAK_FLOOR)
         // device outputs of its most recent calls: `done` is recorded behind every call of the lane,
         // so waiting for it covers all of them (a caller that rotates more buffer sets than lanes
@@ -589,7 +594,7 @@ void mpsfr_destroy(mpsfr_ctx* c) {
         if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
         if (ln.done) (void)hipEventDestroy(ln.done);
         DevBuf* lb[] = {&ln.C, &ln.s00, &ln.D0t, &ln.Tq, &ln.pre, &ln.fin, &ln.dmin, &ln.dblk, &ln.vkeep, &ln.dminb, &ln.order, &ln.mown, &ln.muni, &ln.msched, &ln.mpart,
-                         &ln.pP, &ln.pT, &ln.psp, &ln.dlin, &ln.thrf};
+                         &ln.pP, &ln.pT, &ln.psp, &ln.dlin, &ln.thrf, &ln.squeue};
         for (auto b : lb) release(*b);
     }
     for (int k = 0; k < mpsfr_ctx::NSTAGE; ++k) {
@@ -677,6 +682,9 @@ int mpsfr_set_option(mpsfr_ctx* c, const char* key, double value) {
         if (value != (int)value || value < -1.0 || value > 128.0) return fail(MPSFR_E_INVALID, "%s must be -1 (automatic) or 0..128", key);
         if (key[15] == '\0' || key[16] == 'm') c->reserve_mf = (int)value;
         if (key[15] == '\0' || key[16] == 'a') c->reserve_a = (int)value;
+    } else if (!strcmp(key, "stage_a_queue")) {
+        if (value != 0.0 && value != 1.0 && value != 2.0) return fail(MPSFR_E_INVALID, "stage_a_queue must be 0, 1 or 2");
+        c->stage_a_queue = (int)value;
     } else if (!strcmp(key, "support_skip")) {
         c->support_skip = value != 0.0;
     } else if (!strcmp(key, "finish_fusion")) {
@@ -1063,7 +1071,10 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     const size_t o_alp = al16(o_gam + gam.size() * sizeof(double));
     const size_t o_mr = al16(o_alp + alp.size() * sizeof(double));
     const size_t o_ms = al16(o_mr + (send_masks ? NAO * NAO : 0));
-    const size_t blob = al16(o_ms + (send_masks ? NAO * NAO : 0));
+    // (queue-fed stage A: per chunk, its lines in the order of how much uncorrected turbulence a task carries)
+    const bool want_perm = c->stage_a_queue != 0 && series;
+    const size_t o_perm = al16(o_ms + (send_masks ? NAO * NAO : 0));
+    const size_t blob = al16(o_perm + (want_perm ? (size_t)ntask * ndir * sizeof(int) : 0));
     mpsfr_ctx::Slot& sl = c->slot[c->stage_next++ % mpsfr_ctx::NSTAGE];
     double t_blocked = 0.0;
     if (sl.staged_pending) {        // the copy that last used the pinned blob must have left it
@@ -1115,6 +1126,24 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     memcpy(hb + o_tp, tp.data(), ntask * sizeof(TaskPar));
     memcpy(hb + o_gam, gam.data(), gam.size() * sizeof(double));
     memcpy(hb + o_alp, alp.data(), alp.size() * sizeof(double));
+    if (want_perm) {
+        // K_DPHI_SERIES_Q deals the lines of a y in this order (indices relative to the chunk): tasks by descending
+        // (L0 / r0)^(5/3) x (weight of the high layer) -- the residual a ground-layer correction leaves -- so that the
+        // tasks whose lines the skip rule drops sit together (a block of waves, and at 512^2 the two tasks of a
+        // wave, then skip or compute alike).  A heuristic for speed only: no result depends on the order.
+        int* pm = reinterpret_cast<int*>(hb + o_perm);
+        std::vector<int> idx;
+        for (int t0 = 0; t0 < ntask; t0 += TC) {
+            const int tc = (ntask - t0) < TC ? (ntask - t0) : TC;
+            idx.resize(tc);
+            for (int k = 0; k < tc; ++k) idx[k] = k;
+            // (variance of the uncorrected layer ~ (L0 / r0)^(5/3) x its weight)
+            auto key = [&](int k) { return tp[t0 + k].r0m53 * tp[t0 + k].cn2_1 * std::pow(tp[t0 + k].inv_l0sq, -5.0 / 6.0); };
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key(a) > key(b); });
+            for (int k = 0; k < tc; ++k)
+                for (int d = 0; d < ndir; ++d) pm[(size_t)(t0 + k) * ndir + d] = idx[k] * ndir + d;
+        }
+    }
     if (send_masks) {
         memcpy(hb + o_mr, mask_rec, NAO * NAO);
         memcpy(hb + o_ms, mask_res, NAO * NAO);
@@ -1308,7 +1337,18 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
     float c2min = 0.f;             // log2-scaled exponent factor of the shortest wavelength (the most negative)
     for (int l = 0; l < nl; ++l) c2min = std::fmin(c2min, (float)(lp[l].c * 1.44269504088896340736));
     const float thr_mid = (tiers && c->mf_floor) ? (float)c->mf_mid_log2 : -1.0e30f;
-    const float tier_half = std::isfinite(c->tier_eps) ? (float)(0.5 * c->tier_eps) : 0.f;
+    float tier_half = std::isfinite(c->tier_eps) ? (float)(0.5 * c->tier_eps) : 0.f;
+    // Lines stage A may skip (stage_a_queue = 2; the thin-wave matrix-core path, where the eps rule and the tier budget
+    // are defined): SeriesSkip in stage_a2.hip.  The mass rule takes a quarter of the floor tier's half of the budget
+    // -- tier_eps / 8 over all lines of a task -- and K_MF_PREP works with the other three quarters.
+    const bool line_skip = c->stage_a_queue == 2 && mf2 && series && prune && !staged;
+    float c2max = -3.0e38f;         // log2-scaled exponent factor of the LONGEST wavelength (the least negative)
+    for (int l = 0; l < nl; ++l) c2max = std::fmax(c2max, (float)(lp[l].c * 1.44269504088896340736));
+    float line_mass_log2 = -3.0e38f;
+    if (line_skip && tiers && c->mf_floor && tier_half > 0.f) {
+        line_mass_log2 = (float)std::log2(c->tier_eps / 8.0 / (double)H1);
+        tier_half *= 0.75f;
+    }
     for (int j = 0; j < NL; ++j) {
         mpsfr_ctx::Lane& ln = lane_of(j);
         if ((rc = ensure(c, ln.pre, (size_t)TC * nl * per_stamp * (c->f64 ? 8 : 4)))) return rc;
@@ -1318,6 +1358,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
             if ((rc = ensure(c, ln.pP, (size_t)TC * ndir * NAO * NAO * sizeof(double)))) return rc;
             if ((rc = ensure(c, ln.pT, (size_t)TC * ndir * H1 * NAO * 2 * sizeof(double)))) return rc;
             if ((rc = ensure(c, ln.psp, (size_t)TC * ndir * sizeof(double)))) return rc;
+            if (c->stage_a_queue && (rc = ensure(c, ln.squeue, 64))) return rc;
             if (prune && (rc = ensure(c, ln.dlin, (size_t)TC * ndir * H1 * (N / 32) * sizeof(float)))) return rc;
         } else {
             // row FFTs of the PSD: only the N/2 + 40 distinct rows are stored (K_PSD_ROWFFT)
@@ -1442,6 +1483,7 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
                     px.flag = zero ? c->seq_host + (&sl - c->slot) : nullptr;
                     px.seq = sl.seq;
                 }
+                if (c->stage_a_queue) px.queue_zero = (int*)ln.squeue.p;
                 if (fuse_khat) {
                     px.khat_n = tc;
                     px.khat_gam = d_gam + t0;
@@ -1455,10 +1497,21 @@ static int reconstruct_impl(mpsfr_ctx* c, int ntask, const double* seeing, const
                 if (fuse_copy && t0 == 0 && !zero && !lean) HIPCHK(hipEventRecord(sl.staged, ls));
             }
             ProfScope ps(c, K_DPHI_SERIES, ls);
+            SeriesQueue sq;
+            if (c->stage_a_queue) {
+                sq.queue = (int*)ln.squeue.p;
+                sq.perm = reinterpret_cast<const int*>(db + o_perm) + (size_t)t0 * ndir;
+                if (line_skip) {
+                    sq.tlmax = (const float*)c->tlmax.p;
+                    sq.c2max = c2max;
+                    sq.thr_elem = thr_eps;
+                    sq.thr_mass = line_mass_log2;
+                }
+            }
             launch_dphi_series(ls, N, ntd, ndir, d_tp + t0, ln.pT.p, (const double*)ln.psp.p, c->scoef.p,
                                c->stwk.p, scale2, ln.D0t.p, prune ? (float*)ln.dlin.p : nullptr, c->f64,
                                mf2 ? (int*)ln.msched.p : nullptr, persist_grid(c, ln, c->reserve_a, lanes_shared),
-                               c->support_skip ? (const unsigned*)c->ssup.p : nullptr);
+                               c->support_skip ? (const unsigned*)c->ssup.p : nullptr, sq);
         } else {
             {
                 ProfScope ps(c, K_PSD_ROWFFT, ls);

@@ -32,6 +32,7 @@
 
 #include "device_common.h"
 #include "conv_frames.h"
+#include "mf_common.h"
 #include "dpp_groups.h"
 #include "psd_model.h"
 
@@ -382,6 +383,7 @@ struct ParamCopy {
 struct ParamFlag {
     unsigned long long* flag;
     unsigned long long seq;
+    int* queue_zero;
 };
 
 template <bool F64>
@@ -498,6 +500,8 @@ __global__ void __launch_bounds__(256) k_patch_rows(const double* __restrict__ P
     constexpr int L = series_lanes<N>(), R = 64 / L, Q = N / L, H1 = N / 2 + 1, NJ = fold_nj<Q>();
     if (pf.flag != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         __hip_atomic_store(pf.flag, pf.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (the block queue of K_DPHI_SERIES_Q, the next kernel of this queue, starts at zero)
+    if (pf.queue_zero != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *pf.queue_zero = 0;
     if constexpr (!std::is_void<KR>::value) {
         if ((int)blockIdx.y >= ntd) {
             extern __shared__ __align__(16) unsigned char smem_k[];
@@ -854,6 +858,198 @@ k_dphi_series(const cx<double>* __restrict__ T, const double* __restrict__ sp,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K_DPHI_SERIES_Q (round 6): the same lines, dealt in BLOCKS from a queue instead of in equal contiguous shares.
+// A block is NW units (a unit = what a wave takes at a time: R lines of one y and R consecutive tasks IN
+// THE ORDER `perm` -- the host sorts the tasks by how much uncorrected turbulence they carry, so that the units of a
+// block behave alike); wave w takes unit w of it.  The workgroups draw blocks from one counter in
+// y-major order (the first gridDim.x without a draw), the coefficients of the block's line arrive by LDS-DMA in the
+// slot the previous block does not use while that one is computed, and the block ends at one barrier.
+// Why: the lines a task can do without (SeriesSkip below) all lie at large y, and a contiguous share of the y-major
+// order would leave the workgroups with the small y the whole work.  With nothing skipped the kernel takes what
+// K_DPHI_SERIES takes (a wave's lines and their arithmetic are the same, bit for bit).
+//
+// SeriesSkip -- lines stage B provably drops.  With T[y][su] the row transforms of the patch (this kernel's input),
+//     Re X_y[x] = Re sum_su T[y][su] W^(su x) <= sum_su |T[y][su]| =: B(y)
+// for every x, so D(x, y) >= D_P(x, y) >= scale2 (sum P - B(y)) =: Lb(y) on the whole line (D_F >= 0: it is the
+// structure function of a non-negative PSD): 80 magnitudes against the column transform of the line.  The OTF of
+// the line is below tel 2^(c' D) <= 2^(tlmax(y) + c' Lb(y)) at every wavelength when c' is that of the LONGEST one.
+// A line is skipped -- D = 1e30 stored (an OTF of exactly zero), Lb in its `dlin` entries, a valid lower bound for
+// the block minima of K_MF_PREP -- when
+//   (eps rule)  tlmax(y) + c'max Lb(y) < thr_elem: every element is one the eps rule of the pruning drops anyway, or
+//   (mass rule) log2(2 N) + tlmax(y) + c'max Lb(y) < thr_mass: the line's whole mass in both half planes is below
+//               the share tier_eps / (8 (N/2+1)) of the tier budget that K_MF_PREP sets aside for the skipped lines
+//               (it works with 3/4 of its floor budget then): all skipped lines together stay below tier_eps / 8 of
+//               OTF[0][0] = 1 <= the PSF peak.
+// Both are budgets the per-wavelength stage already documents (include/mpsfr.h: prune_eps, tier_eps): nothing new is
+// given away.  y = 0 is never skipped (B(0) = sum P).
+// ------------------------------------------------------------------------------------------
+struct SeriesSkip {
+    const float* tlmax;       // [N/2+1] log2 of the line maxima of the telescope OTF; nullptr: nothing is skipped
+    float c2max;              // log2(e) c of the longest wavelength (the least negative)
+    float thr_elem;           // log2, eps rule
+    float thr_mass;           // log2, mass rule (-inf: off)
+};
+
+template <int N, typename RO>
+constexpr size_t series_q_smem() {
+    return 4 * (size_t)N * SeriesCfg<RO>::K * sizeof(RO) + (size_t)N * sizeof(cx<double>);
+}
+template <int N, typename RO>
+constexpr bool series_q_fits() { return series_q_smem<N, RO>() <= 160 * 1024; }
+
+// (a block is NW consecutive units of the y-major order c = y nq + q, one per wave: it lies in one y or straddles
+// two, so a block owns two line slots and the kernel four; a launch with fewer units per y than a block takes
+// K_DPHI_SERIES.  Blocks of 2 NW units were 15 % slower at 512^2 x 100 rows: 804 blocks on 256 workgroups are 3 or 4
+// each, where a wave's 6.3 lines are 6 or 7.)
+template <int N, typename RO>
+__global__ void __launch_bounds__((series_threads<N, RO>()), (512 / series_threads<N, RO>() > 1 ? 2 : 1))
+k_dphi_series_q(const cx<double>* __restrict__ T, const double* __restrict__ sp,
+                const TaskPar* __restrict__ tp, int ndir, int ntd, const RO* __restrict__ coef,
+                const cx<double>* __restrict__ twk, double scale2, RO* __restrict__ D0t,
+                float* __restrict__ dlin, int* __restrict__ zero17, const unsigned* __restrict__ support,
+                const int* __restrict__ perm, int* __restrict__ queue, SeriesSkip skip) {
+    constexpr int L = series_lanes<N>(), R = 64 / L, Q = N / L, H1 = N / 2 + 1, K = SeriesCfg<RO>::K;
+    constexpr int THREADS = series_threads<N, RO>(), NW = THREADS / 64, NJ = fold_nj<Q>();
+    constexpr bool WJREG = NJ <= 10;
+    constexpr int LINE = N * K;                               // coefficients of a line
+    constexpr int LINE_BYTES = LINE * (int)sizeof(RO), CHUNKS = LINE_BYTES / 1024;
+    static_assert(LINE_BYTES % 1024 == 0, "a line is whole 1 KB pieces of LDS-DMA");
+    constexpr int GB = NW;                                    // units per block: one per wave
+    extern __shared__ __align__(16) unsigned char smem[];
+    RO* scoef = reinterpret_cast<RO*>(smem);                                       // [2 sets][2 lines][N][K]
+    cx<double>* swr = reinterpret_cast<cx<double>*>(smem + 4 * (size_t)LINE * sizeof(RO));   // [Q][L]
+    __shared__ int s_next[2];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int lane = threadIdx.x & 63, rho = lane / L, k2 = lane & (L - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nq = (ntd + R - 1) / R;                         // units per y (>= GB: the host's choice of kernel)
+    const int C = H1 * nq, nblk = (C + GB - 1) / GB;
+    if (zero17 != nullptr && blockIdx.x == 0 && threadIdx.x < kMfSchedInts) zero17[threadIdx.x] = 0;
+    int blk = blockIdx.x;
+    if (blk >= nblk) return;
+    // the lines of block b into set s: wave w brings pieces w, w + NW, ... of the first and, when the block
+    // straddles two y, of the second line
+    auto issue_lines = [&](int b, int set) {
+        const int y0 = (b * GB) / nq, y1 = min(C - 1, b * GB + GB - 1) / nq;
+        for (int ln = 0; ln <= y1 - y0; ++ln) {
+            const char* src = reinterpret_cast<const char*>(coef + (size_t)(y0 + ln) * LINE);
+#pragma unroll
+            for (int c0 = 0; c0 < CHUNKS; c0 += NW) {
+                const int c = c0 + wave;
+                if (c < CHUNKS)
+                    glds16s(src + (size_t)c * 1024, (unsigned)lane * 16,
+                            lds0 + (unsigned)(2 * set + ln) * LINE_BYTES + (unsigned)c * 1024);
+            }
+        }
+    };
+    // unit u (0 .. 2 NW - 1) of block b: y and the td of this lane's row of lanes (-1: no such unit; -2: the unit
+    // exists, this row's line does not)
+    auto unit_of = [&](int b, int u, int& y) -> int {
+        const int c = b * GB + u;
+        if (c >= C) return -1;
+        y = c / nq;
+        const int r = R * (c - y * nq) + rho;
+        return r < ntd ? (perm != nullptr ? perm[r] : r) : -2;
+    };
+    const int td_last = perm != nullptr ? perm[ntd - 1] : ntd - 1;
+    cx<double> xva[kNX], xvb[kNX];
+    auto fetch = [&](int b, int u, cx<double>* xv) {
+        int y = 0;
+        const int t = unit_of(b, u, y);
+        if (t == -1) return;
+        const cx<double>* src = T + ((size_t)(t >= 0 ? t : td_last) * H1 + y) * NAO + (lane & 15);
+#pragma unroll
+        for (int a = 0; a < kNX; ++a) xv[a] = src[16 * a];
+    };
+    issue_lines(blk, 0);
+    fetch(blk, wave, xva);
+    for (int i = threadIdx.x; i < Q * L; i += THREADS) swr[i] = twk[NJ * L + i];
+    cx<double> wjr[WJREG ? NJ : 1];
+    if constexpr (WJREG) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wjr[j] = twk[j * L + k2];
+    }
+    if (threadIdx.x == 0) s_next[0] = (int)gridDim.x + atomicAdd(queue, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto unit = [&](int b, int u, const cx<double>* xv, int set) {
+        int y = 0;
+        const int t = unit_of(b, u, y);
+        if (t == -1) return;                                    // (wave-uniform: c does not depend on the lane)
+        const bool valid = t >= 0;
+        const int td = valid ? t : td_last;
+        const int task = td / ndir;
+        const double r0m53 = tp[task].r0m53, delta = tp[task].inv_l0sq - kEps0;
+        const double spv = sp[td];
+        cx<double> wl[WJREG ? 1 : NJ];
+        if constexpr (!WJREG) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) wl[j] = twk[j * L + k2];
+        }
+        const unsigned kmask = support != nullptr ? (unsigned)__builtin_amdgcn_readfirstlane((int)support[y]) : 0xffffffffu;
+        if (skip.tlmax != nullptr && y >= 4) {                  // (the first lines carry the peak's lower bound: never)
+            // B(y) = sum of the 80 magnitudes of the line: lane l holds inputs 16 a + l % 16 of ITS row's line
+            float m = 0.f;
+#pragma unroll
+            for (int a = 0; a < kNX; ++a) {
+                const float re = (float)xv[a].x, im = (float)xv[a].y;
+                m += __builtin_sqrtf(fmaf(re, re, im * im));
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) m += __shfl_xor(m, o, 64);
+            // (float magnitudes and sums carry ~1e-6 of B: 1e-5 more of it keeps Lb a LOWER bound)
+            const float lb = fmaxf((float)(scale2 * (spv - (double)m * 1.00001)), 0.f);
+            const float e = fmaf(skip.c2max, lb, skip.tlmax[y]);
+            const bool drop = e < skip.thr_elem || e + (float)(1 + __builtin_ctz(N & -N) + (N == 1280 ? 3 : 0)) < skip.thr_mass;
+            if (__all(drop || !valid)) {
+                if (valid) {
+                    RO* dst = D0t + ((size_t)td * H1 + y) * N + k2;
+#pragma unroll
+                    for (int k1 = 0; k1 < Q; ++k1)
+                        if ((kmask >> k1) & 1u) dst[L * k1] = (RO)1.0e30f;
+                    if (dlin != nullptr && k2 < N / 32) dlin[((size_t)td * H1 + y) * (N / 32) + k2] = lb;
+                }
+                return;
+            }
+        }
+        const int ln = y - (b * GB) / nq;                       // 0 or 1: which line of the block's set
+        series_line<N, RO, L>(xv, WJREG ? wjr : wl, swr, scoef + (size_t)(2 * set + ln) * LINE, r0m53, delta, spv, scale2,
+                              D0t + ((size_t)td * H1 + y) * N + k2,
+                              dlin != nullptr ? dlin + ((size_t)td * H1 + y) * (N / 32) : nullptr, valid, lane, kmask);
+    };
+    // (two blocks per turn of the loop: the register sets of the inputs alternate at compile time.  The draw for the
+    // block after next stands behind the unit: issued in front of it, the wave of thread 0 waits for the atomic's
+    // round trip before its unit's own loads come back -- vmcnt retires in order -- and the block for that wave:
+    // 42 us against 39.6 at 512^2, 205 against 193 at 1280^2.)
+    while (true) {
+        int nxt = s_next[0];
+        bool more = nxt < nblk;
+        if (more) {
+            issue_lines(nxt, 1);
+            fetch(nxt, wave, xvb);
+        }
+        unit(blk, wave, xva, 0);
+        if (more && threadIdx.x == 0) s_next[1] = (int)gridDim.x + atomicAdd(queue, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (!more) break;
+        blk = nxt;
+        nxt = s_next[1];
+        more = nxt < nblk;
+        if (more) {
+            issue_lines(nxt, 0);
+            fetch(nxt, wave, xva);
+        }
+        unit(blk, wave, xvb, 1);
+        if (more && threadIdx.x == 0) s_next[0] = (int)gridDim.x + atomicAdd(queue, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (!more) break;
+        blk = nxt;
+    }
+}
+
 // The first form, kept for what does not fit two coefficient slots in LDS (f64 mode at 1280^2):
 // workgroup = (line y, group of tasks), the coefficients of the line in LDS once, every wave then walks
 // its tasks alone.
@@ -1033,7 +1229,7 @@ void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, 
     else
         hipLaunchKernelGGL(k_patch_gen<false>, ggrid, dim3(256), 0, s, ndir, d_tp, d_aotab, cfit, d_P, pc);
     ParamFlag pf;
-    pf.flag = copy ? x.flag : nullptr; pf.seq = x.seq;
+    pf.flag = copy ? x.flag : nullptr; pf.seq = x.seq; pf.queue_zero = x.queue_zero;
     KhatArgs kh;
     kh.nker = x.khat_n; kh.gam = x.khat_gam; kh.alp = x.khat_alp; kh.khat = x.khat_out;
     DISPATCH_N(N, {
@@ -1064,10 +1260,20 @@ void launch_patch(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, 
     })
 }
 
+// the queue-fed form needs four line slots in LDS and at least a block of units per y
+template <int N, typename RO>
+bool series_q_usable(int ntd) {
+    constexpr int R = 64 / series_lanes<N>(), GB = series_threads<N, RO>() / 64;
+    return series_q_fits<N, RO>() && (ntd + R - 1) / R >= GB;
+}
+
 void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* d_tp, const void* d_T,
                         const double* d_sp, const void* d_coef, const void* d_twk, double scale2,
-                        void* d_D0t, float* d_dlin, bool f64out, int* d_zero, int ncu, const unsigned* d_support) {
+                        void* d_D0t, float* d_dlin, bool f64out, int* d_zero, int ncu, const unsigned* d_support,
+                        const SeriesQueue& qx) {
     const int H1 = N / 2 + 1;
+    SeriesSkip sk;
+    sk.tlmax = qx.tlmax; sk.c2max = qx.c2max; sk.thr_elem = qx.thr_elem; sk.thr_mass = qx.thr_mass;
     auto first_form = [&](auto kernel, size_t sm) {
         // task groups: enough workgroups to fill the GPU several times over, every workgroup's table load
         // shared by as many tasks as that allows, every wave of a workgroup the same number of lines
@@ -1084,6 +1290,15 @@ void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* 
         if (f64out) {
             if constexpr (series_fits<NN, double>()) {
                 constexpr size_t sm = series_smem<NN, double>();
+                if (qx.queue != nullptr && series_q_usable<NN, double>(ntd)) {
+                    constexpr size_t smq = series_q_smem<NN, double>() <= 160 * 1024 ? series_q_smem<NN, double>() : 0;
+                    allow_smem((k_dphi_series_q<NN, double>), smq);
+                    hipLaunchKernelGGL((k_dphi_series_q<NN, double>), dim3(ncu), dim3(series_threads<NN, double>()), smq, s,
+                                       (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, (const double*)d_coef,
+                                       (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), scale2, (double*)d_D0t, d_dlin, d_zero,
+                                       d_support, qx.perm, qx.queue, sk);
+                    return;
+                }
                 allow_smem((k_dphi_series<NN, double>), sm);
                 hipLaunchKernelGGL((k_dphi_series<NN, double>), dim3(ncu), dim3(series_threads<NN, double>()), sm, s,
                                    (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, (const double*)d_coef,
@@ -1098,6 +1313,15 @@ void launch_dphi_series(hipStream_t s, int N, int ntd, int ndir, const TaskPar* 
             }
         } else {
             constexpr size_t sm = series_smem<NN, float>();
+            if (qx.queue != nullptr && series_q_usable<NN, float>(ntd)) {
+                constexpr size_t smq = series_q_smem<NN, float>();
+                allow_smem((k_dphi_series_q<NN, float>), smq);
+                hipLaunchKernelGGL((k_dphi_series_q<NN, float>), dim3(ncu), dim3(series_threads<NN, float>()), smq, s,
+                                   (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, (const float*)d_coef,
+                                   (const cx<double>*)d_twk + twiddle_entries<NN, 64>(), scale2, (float*)d_D0t, d_dlin, d_zero,
+                                   d_support, qx.perm, qx.queue, sk);
+                return;
+            }
             allow_smem((k_dphi_series<NN, float>), sm);
             hipLaunchKernelGGL((k_dphi_series<NN, float>), dim3(ncu), dim3(series_threads<NN, float>()), sm, s,
                                (const cx<double>*)d_T, d_sp, d_tp, ndir, ntd, (const float*)d_coef,

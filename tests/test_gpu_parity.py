@@ -612,6 +612,7 @@ def test_reserved_cus_and_head_fusion_change_no_bit(api, prec):
                 ('defaults', {}),
                 ('copy_fused', {'copy_fusion': 1}),
                 ('finish_fused', {'finish_fusion': 1}),           # K_CONV_FFT finishes the split stamps itself
+                ('stage_a_queue', {'stage_a_queue': 1}),          # K_DPHI_SERIES_Q: the same lines dealt from a queue
                 ('copy_fused_chunks', {'copy_fusion': 1, 'chunk_tasks': 10, 'streams': 2}),
                 ('fused_chunks', {'chunk_tasks': 10, 'streams': 2}))
     ref = None
@@ -643,6 +644,46 @@ def test_reserved_cus_and_head_fusion_change_no_bit(api, prec):
         ctx.close()
     with pytest.raises(api.MpsfrError):
         api.Context(dim=512, pixscale=ps).set_option('persist_reserve', 300)
+
+
+def test_lines_stage_b_drops_may_be_skipped_in_stage_a(api):
+    """`stage_a_queue` = 2 (measured, not the default: profiles/r06_experiments.md): K_DPHI_SERIES_Q skips the lines of a
+    task on which a lower bound of the structure function from the patch's row transforms alone -- D(., y) >=
+    scale2 (sum P - sum_su |T[y][su]|) -- puts every element of the OTF below the eps rule of the pruning, or the
+    line's whole mass below its share of the tier budget, at the longest wavelength.  On rows with poor seeing and a
+    weak ground layer some lines go, the stamps stay within 1e-6 of their peak and the fits within 1e-6, the lines
+    that are computed are bit-identical, and what was skipped really is where the OTF is negligible: the full
+    structure function there is above the bound the rule needs."""
+    n, dim = 24, 1280
+    see = np.linspace(0.6, 1.6, n)
+    gl = np.linspace(0.9, 0.35, n)
+    l0 = np.linspace(12.0, 28.0, n)
+    lb = np.linspace(490.0, 930.0, 5)
+    res = {}
+    for mode in (0, 2):
+        ctx = api.Context(dim=dim, pixscale=0.2)
+        ctx.set_option('stage_a_queue', mode)
+        r = ctx.reconstruct(lb, see, gl, l0, None, H)
+        d = ctx.debug_fetch('dphi0', (n, 1, dim // 2 + 1, dim))[:, 0]
+        tel = ctx.debug_fetch('tel', (dim // 2 + 1, dim))
+        ctx.close()
+        res[mode] = (r, d)
+    (ra, da), (rb, db) = res[0], res[2]
+    inside = tel > 0
+    skipped = ((db >= 1e29) | ~inside[None]).all(axis=2) & inside.any(axis=1)[None]       # (task, line)
+    assert 0.02 < skipped.mean() < 0.9, skipped.mean()
+    assert not skipped[:, :4].any()
+    kept = ~skipped
+    assert np.array_equal(da[kept], db[kept])
+    # every element of a skipped line: 2^(c' D) tel below 2^-29 of OTF[0][0] = 1 even at 930 nm
+    c2 = -0.5 * (2 * np.pi / 930.0) ** 2 * np.log2(np.e)
+    with np.errstate(divide='ignore'):
+        e = c2 * da + np.log2(np.where(inside, tel, 0.0))[None]
+    assert e[skipped].max() < -29.0, e[skipped].max()
+    peak = ra['psf'].max(axis=(2, 3), keepdims=True)
+    assert (np.abs(rb['psf'] - ra['psf']) / peak).max() < 1e-6
+    well = ra['fit'][..., 14] == 0
+    assert np.abs(rb['fit'][..., 4:6] - ra['fit'][..., 4:6])[well].max() < 1e-6
 
 
 def test_stream_wait_hands_results_to_a_caller_stream(api):
