@@ -686,6 +686,30 @@ def test_lines_stage_b_drops_may_be_skipped_in_stage_a(api):
     assert np.abs(rb['fit'][..., 4:6] - ra['fit'][..., 4:6])[well].max() < 1e-6
 
 
+def test_blocks_any_wavelength_keeps_and_the_telescope_support(api):
+    """`mf_work[5..6]` (VERDICT r5 #2b): the blocks of the half plane some wavelength of a task keeps -- what stage A
+    has to deliver at all -- and the blocks inside the support of the telescope OTF.  Bounds that hold by construction:
+    executed tile steps / nl <= union <= support x tasks <= all blocks x tasks; the support is the disc of radius N/2
+    (pi / 4 of the half plane, a little more in whole blocks); a task with poor seeing and a weak ground layer keeps a
+    small core, one with good seeing everything inside the support."""
+    dim, nl = 512, 7
+    ps = api.grid_pixscale(dim)
+    lb = np.linspace(465.0, 930.0, nl)
+    ctx = api.Context(dim=dim, pixscale=ps)
+    nblocks = ((dim // 2 + 1 + 15) // 16) * (dim // 32)
+    fr = {}
+    for key, (see, gl, l0) in (('poor', (1.5, 0.45, 25.0)), ('good', (0.5, 0.9, 10.0))):
+        ctx.reconstruct(lb, [see], [gl], [l0], want_psf=False)
+        w = ctx.debug_fetch('mf_work', (7,))
+        steps, tiles, total, full, mid, union, support = w
+        assert total == nl * nblocks and steps == full + mid
+        assert steps / nl <= union <= support <= nblocks
+        assert 0.78 < support / nblocks < 0.83
+        fr[key] = union / nblocks
+    ctx.close()
+    assert fr['poor'] < 0.1 and fr['good'] > 0.7, fr
+
+
 def test_stream_wait_hands_results_to_a_caller_stream(api):
     """mpsfr_stream_wait is how `bench.py --gpus N` hands a call's device outputs to the stream of the
     collectives.  Lean calls (device outputs, one lane, the context's stream never asked for) into REUSED buffers;
